@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ from the REAL reference (oracle/_ref/libnyq_ref.so).
+
+Run in the build container only (needs /root/reference):
+
+    make -C oracle && python oracle/gen_golden.py
+
+Writes DATA only (inputs + expected outputs):
+  ifft_{input,output}_N{60,480}.bin   byte copies of the reference's own bundled test
+                                      vectors (test_data/), the IFFT-stage known answers
+  ref_tables.npz                      static 48 kHz mode tables read out of the reference
+                                      (trig[481], window[120], tw[480][2], bitrev, factors)
+  ref_imdct_s{0,1,2,3}.npz            clt_mdct_backward in/carry/out rows, stride 1
+  ref_imdct_strided.npz               stride-8 (transient layout) and B1_C2 stereo calls
+  ref_ifft_shared.npz                 opus_ifft through the mode's shared plans, all 4 sizes
+  ref_chain.npz                       consecutive blocks of one channel, long/short mixed,
+                                      emulating the decode_mem shift of celt_decoder_clean.c:625,641
+Everything is seeded; re-running reproduces the files bit for bit.
+"""
+import os
+import shutil
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle.pyoracle import HALF_OV, Ref, n2_of  # noqa: E402
+
+REFDATA = "/root/reference/test_data"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def decoder_like(rng, rows, n2):
+    """freq[]-shaped rows: rms ~30, peaks of a few thousand, top 1/6 of the band zero
+    (measured statistics of real decoder input)."""
+    x = rng.standard_normal((rows, n2)).astype(np.float32) * 30.0
+    spikes = rng.integers(0, n2 * 5 // 6, size=(rows, 4))
+    for r in range(rows):
+        x[r, spikes[r]] *= 60.0
+    x[:, n2 * 5 // 6:] = 0.0
+    return x
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = Ref()
+
+    for n in (60, 480):
+        for kind in ("input", "output"):
+            shutil.copyfile(f"{REFDATA}/ifft_{kind}_N{n}.bin", f"{OUT}/ifft_{kind}_N{n}.bin")
+
+    T = ref.tables()
+    np.savez(f"{OUT}/ref_tables.npz", **T)
+
+    rng = np.random.default_rng(20241223)
+    for s in range(4):
+        n2 = n2_of(s)
+        rows = 16
+        x = np.concatenate([
+            rng.uniform(-1, 1, (4, n2)).astype(np.float32),        # unit scale
+            decoder_like(rng, 8, n2),                              # decoder scale
+            np.zeros((1, n2), np.float32),                         # silence
+            np.eye(1, n2, 0, dtype=np.float32) * 1000.0,           # DC-bin impulse
+            np.eye(1, n2, n2 - 1, dtype=np.float32) * 1000.0,      # last-bin impulse
+            rng.uniform(-4000, 4000, (1, n2)).astype(np.float32),  # full-scale noise
+        ])
+        assert x.shape[0] == rows
+        carry = (rng.standard_normal((rows, HALF_OV)) * 30).astype(np.float32)
+        carry[::2] = 0.0                                           # every other row: zero carry
+        out = np.zeros((rows, n2 + HALF_OV), np.float32)
+        for r in range(rows):
+            out[r, :HALF_OV] = carry[r]
+            ref.imdct(x[r], out[r], s, 1)
+        np.savez(f"{OUT}/ref_imdct_s{s}.npz", x=x, carry=carry, out=out)
+
+    # transient layout: one channel-frame = 960 floats, coefficient k of short block b at X[b + 8k]
+    # (celt_decoder_clean.c:292-300); 8 sequential calls, block b writes out_mem + 120*b, so
+    # block b+1 sees block b's raw tail as carry.
+    frames = 3
+    X = decoder_like(rng, frames * 2, 960).reshape(frames, 2, 960)
+    carry0 = (rng.standard_normal((frames, 2, HALF_OV)) * 30).astype(np.float32)
+    syn = np.zeros((frames, 2, 960 + HALF_OV), np.float32)
+    for f in range(frames):
+        syn[f, :, :HALF_OV] = carry0[f]
+        for b in range(8):
+            o0 = syn[f, 0, 120 * b: 120 * b + 180]
+            o1 = syn[f, 1, 120 * b: 120 * b + 180]
+            ref.imdct_c2(X[f, 0, b:], X[f, 1, b:], o0, o1, 3, 8)
+    # long stereo frame through B1_C2, stride 1
+    XL = decoder_like(rng, 4, 960).reshape(2, 2, 960)
+    cl = (rng.standard_normal((2, 2, HALF_OV)) * 30).astype(np.float32)
+    synl = np.zeros((2, 2, 960 + HALF_OV), np.float32)
+    for f in range(2):
+        synl[f, :, :HALF_OV] = cl[f]
+        ref.imdct_c2(XL[f, 0], XL[f, 1], synl[f, 0], synl[f, 1], 0, 1)
+    # generic strided single-channel calls for shifts 1 and 2 (B = 2, 4 interleaved blocks)
+    gen = {}
+    for s, B in ((1, 2), (2, 4)):
+        n2 = n2_of(s)
+        xs = decoder_like(rng, 1, 960)[0]
+        c0 = (rng.standard_normal(HALF_OV) * 30).astype(np.float32)
+        o = np.zeros(960 + HALF_OV, np.float32)
+        o[:HALF_OV] = c0
+        for b in range(B):
+            ref.imdct(xs[b:], o[n2 * b: n2 * b + n2 + HALF_OV], s, B)
+        gen[f"g{s}_x"] = xs
+        gen[f"g{s}_carry"] = c0
+        gen[f"g{s}_out"] = o
+    np.savez(f"{OUT}/ref_imdct_strided.npz", X=X, carry0=carry0, syn=syn,
+             XL=XL, carryL=cl, synL=synl, **gen)
+
+    sh = {}
+    for s in range(4):
+        nfft = 480 >> s
+        xi = rng.uniform(-1, 1, (8, 2 * nfft)).astype(np.float32)
+        yo = np.stack([ref.ifft_shared(s, xi[r]) for r in range(8)])
+        sh[f"x{s}"] = xi
+        sh[f"y{s}"] = yo
+    np.savez(f"{OUT}/ref_ifft_shared.npz", **sh)
+
+    # one channel, 10 frames of 960 samples, kinds: L = one shift-0 block, S = 8 shift-3 blocks
+    kinds = "LLSLSSLLSL"
+    freq = decoder_like(rng, len(kinds), 960)
+    mem = np.zeros(960 * len(kinds) + HALF_OV, np.float32)
+    mem[:HALF_OV] = (rng.standard_normal(HALF_OV) * 30).astype(np.float32)
+    carry_in = mem[:HALF_OV].copy()
+    for f, k in enumerate(kinds):
+        base = 960 * f
+        if k == "L":
+            ref.imdct(freq[f], mem[base: base + 960 + HALF_OV], 0, 1)
+        else:
+            for b in range(8):
+                ref.imdct(freq[f, b:], mem[base + 120 * b: base + 120 * b + 180], 3, 8)
+    np.savez(f"{OUT}/ref_chain.npz", kinds=np.array(list(kinds)), freq=freq,
+             carry_in=carry_in, pcm=mem[: 960 * len(kinds)].copy(),
+             tail=mem[960 * len(kinds):].copy())
+    total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print(f"wrote {len(os.listdir(OUT))} files, {total/1024:.0f} KiB -> {OUT}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,521 @@
+/*
+ * oracle/nyq_oracle.c -- CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C scalar restatement of the reference's CELT inverse-MDCT hot path,
+ * used exclusively as the parity checker (tests/, __graft_entry__.smoke(),
+ * bench.py's cpu_baseline leg).  Nothing under libnyquist_amd/ or include/
+ * may link, import or call this file: the product path is the HIP library
+ * and fails loudly when it is missing.
+ *
+ * Parity status: PINNED.  tests/test_oracle.py checks this file against
+ *   - the reference's bundled golden vectors test_data/ifft_{input,output}_N{60,480}.bin
+ *     (copied as data to tests/golden/), and
+ *   - outputs of the reference itself (oracle/_ref/libnyq_ref.so, built from
+ *     /root/reference sources by oracle/Makefile; fixtures written by
+ *     oracle/gen_golden.py) -- bit-exact for every size/stride/carry case.
+ *
+ * What is restated (paths relative to /root/reference):
+ *   third_party/opus/celt/mdct.c:267-379        clt_mdct_backward
+ *   third_party/opus/celt/mdct.c:258-265        clt_mdct_backward_B1_C2
+ *   third_party/opus/celt/kiss_fft.c:696-747    opus_ifft (stage driver)
+ *   third_party/opus/celt/kiss_fft.c:82-110     ki_bfly2
+ *   third_party/opus/celt/kiss_fft.c:158-200    ki_bfly4
+ *   third_party/opus/celt/kiss_fft.c:258-306    ki_bfly3
+ *   third_party/opus/celt/kiss_fft.c:385-455    ki_bfly5
+ *   third_party/opus/celt/kiss_fft.c:461-554    digit-reversal table, factoring, twiddles
+ *   third_party/opus/celt/kiss_fft.c:749-771    test_opus_ifft (own-twiddle IFFT)
+ *   third_party/opus/celt/mdct.c:70-106         trig table formula (float PI)
+ *   third_party/opus/celt/modes.c:372-374       window formula
+ *   third_party/opus/celt/_kiss_fft_guts.h:107-153  float complex macros
+ *
+ * The arithmetic keeps the reference's operation order so that, compiled
+ * without FMA contraction, results are bit-identical to the reference build.
+ * The code structure (plan record, stage table, row drivers) is this
+ * repository's own.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define NQ_MDCT_N   1920   /* static mode: mdct.n, static_modes_float.h:591 */
+#define NQ_OVERLAP  120    /* static_modes_float.h:579 */
+#define NQ_HALF_OV  (NQ_OVERLAP / 2)
+#define NQ_TW_BASE  480    /* shared twiddle table length */
+#define NQ_MAX_STAGE 8
+
+typedef struct { float re, im; } nq_cpx;
+
+typedef struct {
+    int nfft;
+    int nstage;
+    int radix[NQ_MAX_STAGE]; /* outermost factor first (kiss "factors[2i]")   */
+    int rest[NQ_MAX_STAGE];  /* remaining length after it ("factors[2i+1]")  */
+    int tw_step;             /* step into tw[] per unit fstride (1<<shift)    */
+    const nq_cpx *tw;        /* tw[k] = exp(-2 pi i k / ntw)                  */
+    int16_t perm[NQ_TW_BASE];/* fout[perm[i]] = fin[i]                        */
+} nq_plan;
+
+/* ---- tables --------------------------------------------------------- */
+
+static float  g_trig[NQ_MDCT_N / 4 + 1];
+static float  g_window[NQ_OVERLAP];
+static nq_cpx g_tw[NQ_TW_BASE];
+static nq_plan g_plan[4];          /* index = shift, nfft = 480 >> shift */
+static int    g_ready = 0;
+
+/* kiss_fft.c:498-535: peel 4s, then 2s, then odd primes up to 5 */
+static int nq_factor(int n, int *radix, int *rest)
+{
+    int p = 4, count = 0;
+    do {
+        while (n % p) {
+            if (p == 4) p = 2;
+            else if (p == 2) p = 3;
+            else p += 2;
+            if (p > 32000 || p * p > n) p = n;
+        }
+        n /= p;
+        if (p > 5) return -1;
+        radix[count] = p;
+        rest[count] = n;
+        count++;
+    } while (n > 1);
+    return count;
+}
+
+/* kiss_fft.c:461-492: recursive mixed-radix digit reversal */
+static void nq_digit_reverse(int out_base, int16_t *slot, int slot_step,
+                             const int *radix, const int *rest, int level)
+{
+    int p = radix[level], m = rest[level], j;
+    if (m == 1) {
+        for (j = 0; j < p; j++) { *slot = (int16_t)(out_base + j); slot += slot_step; }
+    } else {
+        for (j = 0; j < p; j++) {
+            nq_digit_reverse(out_base, slot, slot_step * p, radix, rest, level + 1);
+            slot += slot_step;
+            out_base += m;
+        }
+    }
+}
+
+static int nq_plan_build(nq_plan *pl, int nfft, const nq_cpx *tw, int tw_step)
+{
+    pl->nfft = nfft;
+    pl->tw = tw;
+    pl->tw_step = tw_step;
+    pl->nstage = nq_factor(nfft, pl->radix, pl->rest);
+    if (pl->nstage <= 0 || nfft > NQ_TW_BASE) return -1;
+    nq_digit_reverse(0, pl->perm, 1, pl->radix, pl->rest, 0);
+    return 0;
+}
+
+/* kiss_fft.c:537-554 (float branch): double-precision cexp, rounded once */
+static void nq_fill_twiddles(nq_cpx *tw, int n)
+{
+    const double pi = 3.14159265358979323846264338327;
+    int k;
+    for (k = 0; k < n; k++) {
+        double ph = (-2 * pi / n) * k;
+        tw[k].re = (float)cos(ph);
+        tw[k].im = (float)sin(ph);
+    }
+}
+
+static void nq_default_tables(void)
+{
+    int i;
+    const float PIf = 3.141592653f;                  /* mathops.h:83 */
+    for (i = 0; i <= NQ_MDCT_N / 4; i++)             /* mdct.c:101-102 */
+        g_trig[i] = (float)cos(2 * PIf * i / NQ_MDCT_N);
+    for (i = 0; i < NQ_OVERLAP; i++) {               /* modes.c:372-374 */
+        double s = sin(.5 * M_PI * (i + .5) / NQ_OVERLAP);
+        g_window[i] = (float)(1.0f * sin(.5 * M_PI * s * s));
+    }
+    nq_fill_twiddles(g_tw, NQ_TW_BASE);
+}
+
+static void nq_build_plans(void)
+{
+    int s;
+    for (s = 0; s < 4; s++)
+        nq_plan_build(&g_plan[s], NQ_TW_BASE >> s, g_tw, 1 << s);
+    g_ready = 1;
+}
+
+/* Use generated tables (formulas above). */
+void nyq_oracle_init_default(void)
+{
+    nq_default_tables();
+    nq_build_plans();
+}
+
+/* Use caller tables (e.g. the reference's static tables captured in
+ * tests/golden/ref_tables.npz): trig[481], window[120], tw[480] complex. */
+void nyq_oracle_init_tables(const float *trig, const float *window, const float *tw_interleaved)
+{
+    memcpy(g_trig, trig, sizeof g_trig);
+    memcpy(g_window, window, sizeof g_window);
+    memcpy(g_tw, tw_interleaved, sizeof g_tw);
+    nq_build_plans();
+}
+
+static void nq_need_init(void) { if (!g_ready) nyq_oracle_init_default(); }
+
+void nyq_oracle_get_tables(float *trig, float *window, float *tw_interleaved)
+{
+    nq_need_init();
+    memcpy(trig, g_trig, sizeof g_trig);
+    memcpy(window, g_window, sizeof g_window);
+    memcpy(tw_interleaved, g_tw, sizeof g_tw);
+}
+
+/* perm table + factor list of the shared plan for `shift` (introspection for tests) */
+int nyq_oracle_get_plan(int shift, int16_t *perm, int *radix, int *rest)
+{
+    int i;
+    if (shift < 0 || shift > 3) return -1;
+    nq_need_init();
+    for (i = 0; i < g_plan[shift].nfft; i++) perm[i] = g_plan[shift].perm[i];
+    for (i = 0; i < g_plan[shift].nstage; i++) { radix[i] = g_plan[shift].radix[i]; rest[i] = g_plan[shift].rest[i]; }
+    return g_plan[shift].nstage;
+}
+
+/* ---- inverse butterflies -------------------------------------------- */
+/* conj-twiddle product, _kiss_fft_guts.h:111-113 (C_MULC) */
+#define NQ_MULC(d, a, w) do { (d).re = (a).re * (w).re + (a).im * (w).im; \
+                              (d).im = (a).im * (w).re - (a).re * (w).im; } while (0)
+
+static void nq_inv2(nq_cpx *f, int fs, const nq_cpx *tw, int m, int groups, int gstride)
+{
+    int g, j;
+    for (g = 0; g < groups; g++) {
+        nq_cpx *lo = f + g * gstride, *hi = lo + m;
+        for (j = 0; j < m; j++) {
+            nq_cpx t;
+            NQ_MULC(t, hi[j], tw[j * fs]);
+            hi[j].re = lo[j].re - t.re;  hi[j].im = lo[j].im - t.im;
+            lo[j].re += t.re;            lo[j].im += t.im;
+        }
+    }
+}
+
+static void nq_inv4(nq_cpx *f, int fs, const nq_cpx *tw, int m, int groups, int gstride)
+{
+    int g, j;
+    for (g = 0; g < groups; g++) {
+        nq_cpx *p0 = f + g * gstride, *p1 = p0 + m, *p2 = p0 + 2 * m, *p3 = p0 + 3 * m;
+        for (j = 0; j < m; j++) {
+            nq_cpx a, b, c, sum, dif, odd;
+            NQ_MULC(a, p1[j], tw[j * fs]);
+            NQ_MULC(b, p2[j], tw[2 * j * fs]);
+            NQ_MULC(c, p3[j], tw[3 * j * fs]);
+            odd.re = p0[j].re - b.re;      odd.im = p0[j].im - b.im;
+            p0[j].re += b.re;              p0[j].im += b.im;
+            sum.re = a.re + c.re;          sum.im = a.im + c.im;
+            dif.re = a.re - c.re;          dif.im = a.im - c.im;
+            p2[j].re = p0[j].re - sum.re;  p2[j].im = p0[j].im - sum.im;
+            p0[j].re += sum.re;            p0[j].im += sum.im;
+            p1[j].re = odd.re - dif.im;    p1[j].im = odd.im + dif.re;
+            p3[j].re = odd.re + dif.im;    p3[j].im = odd.im - dif.re;
+        }
+    }
+}
+
+static void nq_inv3(nq_cpx *f, int fs, const nq_cpx *tw, int m, int groups, int gstride)
+{
+    int g, j;
+    const float neg_s60 = -tw[fs * m].im;            /* "-epi3.i" */
+    for (g = 0; g < groups; g++) {
+        nq_cpx *p0 = f + g * gstride, *p1 = p0 + m, *p2 = p0 + 2 * m;
+        for (j = 0; j < m; j++) {
+            nq_cpx a, b, sum, dif;
+            NQ_MULC(a, p1[j], tw[j * fs]);
+            NQ_MULC(b, p2[j], tw[2 * j * fs]);
+            sum.re = a.re + b.re;   sum.im = a.im + b.im;
+            dif.re = a.re - b.re;   dif.im = a.im - b.im;
+            p1[j].re = p0[j].re - sum.re * .5f;
+            p1[j].im = p0[j].im - sum.im * .5f;
+            dif.re *= neg_s60;      dif.im *= neg_s60;
+            p0[j].re += sum.re;     p0[j].im += sum.im;
+            p2[j].re = p1[j].re + dif.im;
+            p2[j].im = p1[j].im - dif.re;
+            p1[j].re -= dif.im;
+            p1[j].im += dif.re;
+        }
+    }
+}
+
+static void nq_inv5(nq_cpx *f, int fs, const nq_cpx *tw, int m, int groups, int gstride)
+{
+    int g, u;
+    const nq_cpx ya = tw[fs * m], yb = tw[fs * 2 * m];
+    for (g = 0; g < groups; g++) {
+        nq_cpx *p0 = f + g * gstride, *p1 = p0 + m, *p2 = p0 + 2 * m, *p3 = p0 + 3 * m, *p4 = p0 + 4 * m;
+        for (u = 0; u < m; u++) {
+            nq_cpx z0 = p0[u], z1, z2, z3, z4, s14, d14, s23, d23, e, o;
+            NQ_MULC(z1, p1[u], tw[u * fs]);
+            NQ_MULC(z2, p2[u], tw[2 * u * fs]);
+            NQ_MULC(z3, p3[u], tw[3 * u * fs]);
+            NQ_MULC(z4, p4[u], tw[4 * u * fs]);
+            s14.re = z1.re + z4.re;  s14.im = z1.im + z4.im;
+            d14.re = z1.re - z4.re;  d14.im = z1.im - z4.im;
+            s23.re = z2.re + z3.re;  s23.im = z2.im + z3.im;
+            d23.re = z2.re - z3.re;  d23.im = z2.im - z3.im;
+
+            p0[u].re += s14.re + s23.re;
+            p0[u].im += s14.im + s23.im;
+
+            e.re = z0.re + s14.re * ya.re + s23.re * yb.re;
+            e.im = z0.im + s14.im * ya.re + s23.im * yb.re;
+            o.re = -(d14.im * ya.im) - d23.im * yb.im;
+            o.im = d14.re * ya.im + d23.re * yb.im;
+            p1[u].re = e.re - o.re;  p1[u].im = e.im - o.im;
+            p4[u].re = e.re + o.re;  p4[u].im = e.im + o.im;
+
+            e.re = z0.re + s14.re * yb.re + s23.re * ya.re;
+            e.im = z0.im + s14.im * yb.re + s23.im * ya.re;
+            o.re = d14.im * yb.im - d23.im * ya.im;
+            o.im = -(d14.re * yb.im) + d23.re * ya.im;
+            p2[u].re = e.re + o.re;  p2[u].im = e.im + o.im;
+            p3[u].re = e.re - o.re;  p3[u].im = e.im - o.im;
+        }
+    }
+}
+
+/* kiss_fft.c:696-747: scatter through the digit-reversal table, then run the
+ * factor list innermost-first; group count of stage i = product of the outer
+ * radices, twiddle step scaled by the plan's shift. */
+static void nq_ifft_run(const nq_plan *pl, const nq_cpx *in, nq_cpx *out)
+{
+    int outer[NQ_MAX_STAGE + 1];
+    int i, m;
+    for (i = 0; i < pl->nfft; i++) out[pl->perm[i]] = in[i];
+    outer[0] = 1;
+    for (i = 0; i < pl->nstage; i++) outer[i + 1] = outer[i] * pl->radix[i];
+    m = pl->rest[pl->nstage - 1];
+    for (i = pl->nstage - 1; i >= 0; i--) {
+        int gstride = i ? pl->rest[i - 1] : 1;
+        int fs = outer[i] * pl->tw_step;
+        switch (pl->radix[i]) {
+        case 2: nq_inv2(out, fs, pl->tw, m, outer[i], gstride); break;
+        case 4: nq_inv4(out, fs, pl->tw, m, outer[i], gstride); break;
+        case 3: nq_inv3(out, fs, pl->tw, m, outer[i], gstride); break;
+        case 5: nq_inv5(out, fs, pl->tw, m, outer[i], gstride); break;
+        }
+        m = gstride;
+    }
+}
+
+/* ---- public: IFFT stage ---------------------------------------------- */
+
+/* opus_ifft through the mode's shared plan (kfft[shift], twiddle step 1<<shift).
+ * in/out: nfft interleaved complex float32, out-of-place. */
+int nyq_oracle_ifft_shared(int shift, const float *in, float *out)
+{
+    if (shift < 0 || shift > 3 || in == out) return -1;
+    nq_need_init();
+    nq_ifft_run(&g_plan[shift], (const nq_cpx *)in, (nq_cpx *)out);
+    return 0;
+}
+
+/* test_opus_ifft (kiss_fft.c:749-771): a fresh plan with its own nfft-long
+ * twiddle table.  This is the producer shape of the bundled .bin vectors. */
+int nyq_oracle_ifft_own(int nfft, const float *in, float *out)
+{
+    nq_plan pl;
+    nq_cpx *tw;
+    int rc;
+    if (nfft <= 0 || nfft > NQ_TW_BASE || in == out) return -1;
+    tw = (nq_cpx *)malloc(sizeof(nq_cpx) * (size_t)nfft);
+    if (!tw) return -2;
+    nq_fill_twiddles(tw, nfft);
+    rc = nq_plan_build(&pl, nfft, tw, 1);
+    if (rc == 0) nq_ifft_run(&pl, (const nq_cpx *)in, (nq_cpx *)out);
+    free(tw);
+    return rc;
+}
+
+/* batch of rows through nyq_oracle_ifft_own / _shared (shared=1 needs nfft = 480>>s) */
+int nyq_oracle_ifft_batch(int nfft, int shared, const float *in, float *out, long batch, int nthreads)
+{
+    long r;
+    int shift = -1, s;
+    nq_plan own;
+    nq_cpx *tw = NULL;
+    const nq_plan *pl;
+    nq_need_init();
+    if (shared) {
+        for (s = 0; s < 4; s++) if ((NQ_TW_BASE >> s) == nfft) shift = s;
+        if (shift < 0) return -1;
+        pl = &g_plan[shift];
+    } else {
+        if (nfft <= 0 || nfft > NQ_TW_BASE) return -1;
+        tw = (nq_cpx *)malloc(sizeof(nq_cpx) * (size_t)nfft);
+        if (!tw) return -2;
+        nq_fill_twiddles(tw, nfft);
+        if (nq_plan_build(&own, nfft, tw, 1)) { free(tw); return -1; }
+        pl = &own;
+    }
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
+#endif
+    for (r = 0; r < batch; r++)
+        nq_ifft_run(pl, (const nq_cpx *)in + r * nfft, (nq_cpx *)out + r * nfft);
+    free(tw);
+    return 0;
+}
+
+/* ---- public: full IMDCT ---------------------------------------------- */
+
+/* clt_mdct_backward, mdct.c:267-379, float build, static 48 kHz mode.
+ * in : N2 = 960>>shift coefficients, element k at in[k*stride]
+ * out: N2 + overlap/2 floats, read-modify-write (out[0..60) = carry in). */
+int nyq_oracle_imdct(const float *in, float *out, int shift, int stride)
+{
+    float scratch[NQ_MDCT_N / 2];
+    int i;
+    int N, N2, N4;
+    float sine;
+    const float *t;
+    if (shift < 0 || shift > 3 || stride < 1) return -1;
+    nq_need_init();
+    t = g_trig;
+    N = NQ_MDCT_N >> shift;
+    N2 = N >> 1;
+    N4 = N >> 2;
+    sine = (float)2 * 3.141592653f * (.125f) / N;      /* mdct.c:292 */
+
+    /* pre-rotation, mdct.c:295-313 */
+    {
+        const float *fwd = in;
+        const float *bwd = in + stride * (N2 - 1);
+        float *dst = scratch;
+        for (i = 0; i < N4; i++) {
+            float c = t[i << shift], s = t[(N4 - i) << shift];
+            float yr = -(*bwd * c) + *fwd * s;
+            float yi = -(*bwd * s) - *fwd * c;
+            *dst++ = yr - yi * sine;
+            *dst++ = yi + yr * sine;
+            fwd += 2 * stride;
+            bwd -= 2 * stride;
+        }
+    }
+
+    /* N/4-point unscaled inverse FFT into out + overlap/2, mdct.c:316-317 */
+    nq_ifft_run(&g_plan[shift], (const nq_cpx *)scratch, (nq_cpx *)(out + NQ_HALF_OV));
+
+    /* post-rotation from both ends, mdct.c:322-359 */
+    {
+        float *head = out + NQ_HALF_OV;
+        float *back = out + NQ_HALF_OV + N2 - 2;
+        for (i = 0; i < (N4 + 1) >> 1; i++) {
+            float re = head[0], im = head[1];
+            float t0 = t[i << shift], t1 = t[(N4 - i) << shift];
+            float yr = re * t0 - im * t1;
+            float yi = im * t0 + re * t1;
+            re = back[0];
+            im = back[1];
+            head[0] = -(yr - yi * sine);
+            back[1] = yi + yr * sine;
+            t0 = t[(N4 - i - 1) << shift];
+            t1 = t[(i + 1) << shift];
+            yr = re * t0 - im * t1;
+            yi = im * t0 + re * t1;
+            back[0] = -(yr - yi * sine);
+            head[1] = yi + yr * sine;
+            head += 2;
+            back -= 2;
+        }
+    }
+
+    /* TDAC mirror, mdct.c:362-377 */
+    {
+        float *hi = out + NQ_OVERLAP - 1;
+        float *lo = out;
+        const float *wa = g_window;
+        const float *wb = g_window + NQ_OVERLAP - 1;
+        for (i = 0; i < NQ_OVERLAP / 2; i++) {
+            float x1 = *hi, x2 = *lo;
+            *lo++ = *wb * x2 - *wa * x1;
+            *hi-- = *wa * x2 + *wb * x1;
+            wa++;
+            wb--;
+        }
+    }
+    return 0;
+}
+
+/* clt_mdct_backward_B1_C2 (mdct.c:258-265): channel 0 then channel 1 */
+int nyq_oracle_imdct_c2(const float *in0, const float *in1, float *out0, float *out1, int shift, int stride)
+{
+    int rc = nyq_oracle_imdct(in0, out0, shift, stride);
+    if (rc) return rc;
+    return nyq_oracle_imdct(in1, out1, shift, stride);
+}
+
+/* Independent rows.  in [batch][N2] contiguous (stride 1); carry [batch][60]
+ * or NULL (= zeros); fin [batch][N2] = the reference's out[0..N2) after the
+ * call; tail [batch][60] (may be NULL) = out[N2..N2+60), the raw values the
+ * next block of the same channel receives as its carry
+ * (celt_decoder_clean.c:625,641 buffer shift). */
+int nyq_oracle_imdct_batch(int shift, const float *in, const float *carry,
+                           float *fin, float *tail, long batch, int nthreads)
+{
+    long r;
+    int N2;
+    if (shift < 0 || shift > 3) return -1;
+    nq_need_init();
+    N2 = (NQ_MDCT_N >> shift) >> 1;
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
+#endif
+    for (r = 0; r < batch; r++) {
+        float buf[NQ_MDCT_N / 2 + NQ_HALF_OV];
+        if (carry) memcpy(buf, carry + r * NQ_HALF_OV, sizeof(float) * NQ_HALF_OV);
+        else memset(buf, 0, sizeof(float) * NQ_HALF_OV);
+        nyq_oracle_imdct(in + r * N2, buf, shift, 1);
+        memcpy(fin + r * N2, buf, sizeof(float) * (size_t)N2);
+        if (tail) memcpy(tail + r * NQ_HALF_OV, buf + N2, sizeof(float) * NQ_HALF_OV);
+    }
+    return 0;
+}
+
+/* Chained rows: rows are consecutive blocks of ONE channel; row r's carry is
+ * row r-1's tail (carry0[60] or NULL seeds row 0).  pcm [batch][N2],
+ * tail_out[60] = tail of the last row.  Sequential by construction. */
+int nyq_oracle_imdct_chain(int shift, const float *in, const float *carry0,
+                           float *pcm, float *tail_out, long batch)
+{
+    long r;
+    int N2;
+    float buf[NQ_MDCT_N / 2 + NQ_HALF_OV];
+    if (shift < 0 || shift > 3) return -1;
+    nq_need_init();
+    N2 = (NQ_MDCT_N >> shift) >> 1;
+    if (carry0) memcpy(buf, carry0, sizeof(float) * NQ_HALF_OV);
+    else memset(buf, 0, sizeof(float) * NQ_HALF_OV);
+    for (r = 0; r < batch; r++) {
+        nyq_oracle_imdct(in + r * N2, buf, shift, 1);
+        memcpy(pcm + r * N2, buf, sizeof(float) * (size_t)N2);
+        memmove(buf, buf + N2, sizeof(float) * NQ_HALF_OV);
+    }
+    if (tail_out) memcpy(tail_out, buf, sizeof(float) * NQ_HALF_OV);
+    return 0;
+}
+
+int nyq_oracle_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
