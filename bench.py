@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the batched CELT inverse-MDCT path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W            (N = 1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W          (N > 1)
+
+Workload (BASELINE.json configs[2]): per GPU 2^20 rows of
+nfft-480 IMDCTs (MDCT N = 1920: 960 float32 coefficients in, 960 finished samples + 60
+tail floats out), X ~ U(-1,1) from a fixed seed, generated on the device and resident in
+HBM before the timed region; shift 0, stride 1, overlap 120, carry-in zeros.
+One "step" = one pass of nyq_imdct_batch_dev over the whole batch.  Rows shard
+embarrassingly across GPUs (each rank owns its own 2^20 rows: weak scaling, no data-path
+collective; torch.distributed is used only for the barrier and the max-over-ranks time).
+
+Rank 0 prints ONE JSON line; see README/DESIGN.md for the fields.  `roofline.achieved`
+= 7680 algorithmic bytes x rows / mean kernel duration (HIP events on the kernel's own
+stream); `cpu_baseline` = the reference's own clt_mdct_backward (oracle/_ref, kind
+"reference") or this repo's C restatement (kind "port") timed on this host's cores over a
+bounded sample of the same rows.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_BYTES_PER_IMDCT = 7680          # 960 f32 in + 960 f32 out
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N2 = 960
+HALF_OV = 60
+
+
+def shard_rows(total_rows, world, rank):
+    """Contiguous row range [lo, hi) of `rank` when `total_rows` are split over `world` ranks."""
+    base, rem = divmod(total_rows, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def cpu_baseline(x_sample, seconds=12.0):
+    """Time the CPU path on `x_sample` ([rows][960] float32) for about `seconds`."""
+    from oracle import pyoracle
+    rows = x_sample.shape[0]
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    if pyoracle.ref_available():
+        ref = pyoracle.Ref()
+        per = max(rows // ncores, 1)
+        slices = [np.ascontiguousarray(x_sample[i * per:(i + 1) * per]) for i in range(ncores)]
+        slices = [s for s in slices if s.shape[0]]
+        ref.bench(slices[0][:256], 0, 2)    # warm
+        t_one = ref.bench(slices[0], 0, 1)
+        reps = max(int(seconds / max(t_one, 1e-6)), 1)
+        secs = [0.0] * len(slices)
+
+        def work(i):
+            secs[i] = ref.bench(slices[i], 0, reps)   # ctypes releases the GIL
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(len(slices))]
+        t0 = time.perf_counter()
+        [t.start() for t in th]
+        [t.join() for t in th]
+        wall = time.perf_counter() - t0
+        done = sum(s.shape[0] for s in slices) * reps
+        return {"value": done / wall, "unit": "IMDCT/s", "cores": len(slices), "kind": "reference",
+                "sample": f"{done} nfft-480 rows ({sum(s.shape[0] for s in slices)} distinct rows of the bench batch x {reps} reps), "
+                          f"one thread per core, reference clt_mdct_backward built from /root/reference sources (oracle/_ref)",
+                "per_core": done / wall / len(slices), "seconds": wall}
+    orc = pyoracle.Oracle()
+    nt = min(ncores, orc.max_threads())
+    orc.imdct_batch(0, x_sample[:256], None, nthreads=nt)
+    t0 = time.perf_counter()
+    orc.imdct_batch(0, x_sample, None, nthreads=nt)
+    t_one = time.perf_counter() - t0
+    reps = max(int(seconds / max(t_one, 1e-6)), 1)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        orc.imdct_batch(0, x_sample, None, nthreads=nt)
+    wall = time.perf_counter() - t0
+    return {"value": rows * reps / wall, "unit": "IMDCT/s", "cores": nt, "kind": "port",
+            "sample": f"{rows * reps} nfft-480 rows ({rows} distinct rows of the bench batch x {reps} reps), OpenMP over {nt} threads, "
+                      f"oracle/nyq_oracle.c restatement", "per_core": rows * reps / wall / nt, "seconds": wall}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=1 << 20, help="rows per GPU (default 2^20)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the IMDCT path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import libnyquist_amd as nyq
+    ctx = nyq.Context(local_rank)
+    stream = torch.cuda.current_stream(dev)
+    ctx.set_stream(stream.cuda_stream)       # kernels and torch events share this stream
+    cus, devname = ctx.device_info()
+
+    rows = args.rows
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(480 + rank)
+    x = torch.rand((rows, N2), generator=gen, device=dev, dtype=torch.float32).mul_(2.0).sub_(1.0)
+    fin = torch.empty((rows, N2), device=dev, dtype=torch.float32)
+    tail = torch.empty((rows, HALF_OV), device=dev, dtype=torch.float32)
+
+    def step():
+        ctx.imdct_batch_dev(0, x.data_ptr(), 0, fin.data_ptr(), tail.data_ptr(), rows)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream)
+        step()
+        b.record(stream)
+    torch.cuda.synchronize(dev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = [a.elapsed_time(b) for a, b in ev]
+
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        k = torch.tensor([sum(kern_ms) / len(kern_ms)], device=dev, dtype=torch.float64)
+        dist.all_reduce(k, op=dist.ReduceOp.MAX)
+        kern_avg_ms = float(k.item())
+    else:
+        kern_avg_ms = sum(kern_ms) / len(kern_ms)
+
+    if rank == 0:
+        # parity spot check inside the bench: 4096 rows vs the oracle (relative RMS)
+        from oracle.pyoracle import Oracle
+        take = min(4096, rows)
+        xs = x[:take].cpu().numpy()
+        want_fin, want_tail = Oracle().imdct_batch(0, xs, None, nthreads=4)
+        got_fin, got_tail = fin[:take].cpu().numpy(), tail[:take].cpu().numpy()
+        num = np.sqrt(np.mean((got_fin.astype(np.float64) - want_fin) ** 2) + np.mean((got_tail.astype(np.float64) - want_tail) ** 2))
+        den = np.sqrt(np.mean(want_fin.astype(np.float64) ** 2) + np.mean(want_tail.astype(np.float64) ** 2))
+        parity = float(num / den)
+
+        total = world * rows * args.steps
+        value = total / elapsed
+        achieved = ALG_BYTES_PER_IMDCT * rows / (kern_avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("rows") == rows:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "nfft480_imdct_per_sec",
+            "value": value,
+            "unit": "IMDCT/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[2]: synthetic nfft-480 IMDCT batch (MDCT N=1920, shift 0, stride 1, overlap 120, zero carry)",
+                       "rows_per_gpu": rows, "global_rows": world * rows, "seed": 480,
+                       "outputs": "960 finished samples + 60-float tail per row",
+                       "parallelism": f"rows sharded over {world} GPU(s), no collective",
+                       "device": devname, "compute_units": cus},
+            "opus_stereo_20ms_frames_per_sec": value / 2.0,
+            "parity_rel_rms_vs_oracle": parity,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "imdct_rows_kernel<32>", "kernel_avg_ms": kern_avg_ms,
+                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_IMDCT * rows},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(x[: 1 << 16].cpu().numpy(), args.cpu_seconds)
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

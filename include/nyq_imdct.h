@@ -1,0 +1,117 @@
+/*
+ * nyq_imdct.h -- C ABI of libnyq_imdct.so: the MI355X (gfx950) batched CELT inverse MDCT.
+ *
+ * This is the drop-in boundary for ONE hot path of dafx/libnyquist: the path the
+ * reference itself swaps out at third_party/opus/celt/mdct.c:219-254 onto the
+ * extern "C" symbols of cuda/mdct_cuda.hpp:79-103.  Two families are exported:
+ *
+ *   1. the reference's own operator names (processMDCTCuda, processMDCTCudaB1C2,
+ *      cleanupCudaBuffers, printCudaVersion) with identical signatures and pointer
+ *      ownership, so the reference's USE_CUDA call sites link against this library
+ *      unchanged;
+ *   2. the batched entry points the reference lacks (one call = many
+ *      clt_mdct_backward rows), which is what makes a GPU worthwhile.
+ *
+ * Plain pointers and sizes only; float32 little-endian everywhere.  Every function
+ * that can fail returns an int status (0 = NYQ_OK); nyq_last_error() gives the text.
+ * There is NO CPU fallback: without a usable HIP device nyq_ctx_create() fails with
+ * NYQ_ERR_NO_DEVICE and the reference-named void shims abort() after printing why.
+ *
+ * Row semantics (one row == one clt_mdct_backward(l, in, out, window, 120, shift, 1),
+ * third_party/opus/celt/mdct.c:267-379, static 48 kHz mode, mdct.n = 1920):
+ *   N2 = 960 >> shift            coefficients in, finished samples out  (shift 0..3)
+ *   in   [N2]                    frequency coefficients, stride 1
+ *   carry[60]                    what the reference finds in out[0..60) on entry
+ *                                (= raw tail of the previous block of that channel,
+ *                                 celt_decoder_clean.c:625,641); NULL means zeros
+ *   fin  [N2]                    the reference's out[0..N2) after the call
+ *   tail [60]                    the reference's out[N2..N2+60) after the call
+ */
+#ifndef NYQ_IMDCT_H
+#define NYQ_IMDCT_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NYQ_OK             0
+#define NYQ_ERR_INVALID   (-1)  /* bad argument (NULL, shift/nfft out of range, misaligned pointer) */
+#define NYQ_ERR_NO_DEVICE (-2)  /* no HIP device / device index out of range */
+#define NYQ_ERR_HIP       (-3)  /* a HIP runtime call failed; see nyq_last_error() */
+#define NYQ_ERR_ALLOC     (-4)  /* host or device allocation failed */
+
+#define NYQ_MDCT_N   1920       /* static_modes_float.h:591 */
+#define NYQ_OVERLAP  120        /* static_modes_float.h:579 */
+#define NYQ_HALF_OV  60
+
+typedef struct nyq_ctx nyq_ctx; /* one per (device, host thread); not thread-safe, replaces the
+                                   reference's unsynchronised global state map, mdct_cuda.cu:558-559 */
+
+/* ---- context ----------------------------------------------------------- */
+int  nyq_ctx_create(nyq_ctx **out, int device);
+void nyq_ctx_destroy(nyq_ctx *ctx);
+/* text of the last failure on ctx (ctx == NULL: last failure of ctx-less calls) */
+const char *nyq_last_error(const nyq_ctx *ctx);
+/* Run on a caller-owned hipStream_t (NULL restores the context's own stream). */
+int  nyq_ctx_set_stream(nyq_ctx *ctx, void *hip_stream);
+void *nyq_ctx_get_stream(nyq_ctx *ctx);
+int  nyq_ctx_synchronize(nyq_ctx *ctx);
+/* Replace the built-in tables by the caller's (host pointers, copied): trig[481] =
+ * mode->mdct.trig (static_modes_float.h:477), window[120] = mode->window (:9-34).
+ * The built-in tables are regenerated from the reference's formulas
+ * (mdct.c:101-102 with mathops.h:83's float PI; modes.c:372-374). */
+int  nyq_ctx_set_tables(nyq_ctx *ctx, const float *trig481, const float *window120);
+int  nyq_ctx_get_tables(nyq_ctx *ctx, float *trig481, float *window120);
+/* device properties the benchmark reports: compute units, waves resident per CU for `shift` */
+int  nyq_ctx_device_info(nyq_ctx *ctx, int *compute_units, char *name, size_t name_len);
+
+/* ---- device-resident batched operators (asynchronous on the context stream) ---- */
+/* All d_* pointers are device memory, 16-byte aligned, rows contiguous. No allocation,
+ * no synchronisation inside: safe to capture in a hipGraph. */
+
+/* opus_ifft (kiss_fft.c:696-747): [batch][nfft] interleaved complex in/out, natural
+ * order, unscaled inverse; nfft in {480,240,120,60}.  Out of place. */
+int nyq_ifft_batch_dev(nyq_ctx *ctx, int nfft, const float *d_in, float *d_out, size_t batch);
+
+/* clt_mdct_backward (mdct.c:267-379) on `batch` independent rows.
+ * d_in [batch][N2], d_carry [batch][60] or NULL, d_fin [batch][N2], d_tail [batch][60] or NULL. */
+int nyq_imdct_batch_dev(nyq_ctx *ctx, int shift, const float *d_in, const float *d_carry,
+                        float *d_fin, float *d_tail, size_t batch);
+
+/* `nchains` channels of `len` consecutive same-size blocks each (rows of chain c are
+ * c*len .. c*len+len-1): block r's carry is block r-1's tail, as the decoder's buffer
+ * shift arranges (celt_decoder_clean.c:625,641).  d_carry0 [nchains][60] or NULL seeds
+ * row 0 of each chain; d_pcm [nchains*len][N2]; d_tail_out [nchains][60] or NULL gets
+ * each chain's final tail; d_work [nchains*len][60] is caller-provided scratch. */
+int nyq_imdct_chain_dev(nyq_ctx *ctx, int shift, const float *d_in, const float *d_carry0,
+                        float *d_pcm, float *d_tail_out, float *d_work,
+                        size_t nchains, size_t len);
+
+/* ---- host-buffer variants (synchronous: H2D, kernel, D2H through context scratch) ---- */
+int nyq_ifft_batch(nyq_ctx *ctx, int nfft, const float *in, float *out, size_t batch);
+int nyq_imdct_batch(nyq_ctx *ctx, int shift, const float *in, const float *carry,
+                    float *fin, float *tail, size_t batch);
+int nyq_imdct_chain(nyq_ctx *ctx, int shift, const float *in, const float *carry0,
+                    float *pcm, float *tail_out, size_t nchains, size_t len);
+
+/* ---- the reference's operator boundary, kept verbatim ------------------- */
+/* cuda/mdct_cuda.hpp:89-91 (impl mdct_cuda.cu:314-392).  Host pointers, caller-owned.
+ * N = mdct.n >> shift (already shifted, mdct.c:249-253); input element k at
+ * input[k*stride]; output is read-modify-write over N/2 + overlap/2 floats with the
+ * carry in output[0..overlap/2); trig/window are the mode's tables. */
+void processMDCTCuda(const float *input, float *output, const float *trig, int N, int shift,
+                     int stride, float sine, int overlap, const float *window);
+/* cuda/mdct_cuda.hpp:92-94 (impl mdct_cuda.cu:562-584): two channels per call. */
+void processMDCTCudaB1C2(const float *input[2], float *output[2], const float *trig, int N,
+                         int shift, int stride, float sine, int overlap, const float *window);
+/* cuda/mdct_cuda.hpp:100, called from examples/src/Main.cpp:127-129 */
+void cleanupCudaBuffers(void);
+/* cuda/mdct_cuda.hpp:83, called from examples/src/Main.cpp:26-28 */
+void printCudaVersion(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NYQ_IMDCT_H */

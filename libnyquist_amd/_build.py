@@ -1,0 +1,42 @@
+"""Compile libnyq_imdct.so (HIP kernels + C ABI) for gfx950, in-tree.
+
+hipcc cross-compiles without a GPU; the built .so travels to the GPU box with the
+repository snapshot (it is git-ignored, not gpurun-ignored).
+"""
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libnyq_imdct.so")
+SOURCES = [os.path.join(CSRC, "nyq_imdct.hip")]
+DEPS = SOURCES + [os.path.join(CSRC, "nyq_imdct_lanes.hpp"), os.path.join(CSRC, "nyq_fft_core.hpp"),
+                  os.path.join(ROOT, "include", "nyq_imdct.h")]
+
+
+def hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libnyq_imdct.so cannot be built (no CPU fallback exists)")
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(d) > t for d in DEPS)
+
+
+def build(force=False, verbose=False):
+    """Build libnyquist_amd/libnyq_imdct.so if missing or older than its sources."""
+    if not force and not stale():
+        return LIB
+    cmd = [hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
+           "-o", LIB] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB

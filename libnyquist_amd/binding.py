@@ -1,0 +1,187 @@
+"""ctypes binding of include/nyq_imdct.h -- the test/bench harness side of the C ABI.
+
+The product is libnyq_imdct.so; this module only marshals numpy arrays and torch
+device pointers into it.  It never computes anything itself and has no fallback:
+a missing library or a missing GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+HALF_OV = 60
+OVERLAP = 120
+NYQ_OK = 0
+ERRORS = {-1: "NYQ_ERR_INVALID", -2: "NYQ_ERR_NO_DEVICE", -3: "NYQ_ERR_HIP", -4: "NYQ_ERR_ALLOC"}
+
+# every symbol include/nyq_imdct.h declares (tests check the .so exports all of them)
+EXPORTS = [
+    "nyq_ctx_create", "nyq_ctx_destroy", "nyq_last_error", "nyq_ctx_set_stream", "nyq_ctx_get_stream",
+    "nyq_ctx_synchronize", "nyq_ctx_set_tables", "nyq_ctx_get_tables", "nyq_ctx_device_info",
+    "nyq_ifft_batch_dev", "nyq_imdct_batch_dev", "nyq_imdct_chain_dev",
+    "nyq_ifft_batch", "nyq_imdct_batch", "nyq_imdct_chain",
+    "processMDCTCuda", "processMDCTCudaB1C2", "cleanupCudaBuffers", "printCudaVersion",
+]
+
+
+class NyqError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"{ERRORS.get(code, code)}: {text}")
+        self.code = code
+
+
+_lib = None
+
+
+def load(path=None):
+    """dlopen libnyq_imdct.so (building it first when hipcc is available and it is stale)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or _build.LIB
+    if path is None:
+        try:
+            _build.build()
+        except Exception:
+            if not os.path.exists(p):
+                raise
+    if not os.path.exists(p):
+        raise FileNotFoundError(f"{p}: HIP extension missing -- run __graft_entry__.build(); there is no CPU fallback")
+    L = C.CDLL(p)
+    vp, i, sz, fp = C.c_void_p, C.c_int, C.c_size_t, C.c_void_p
+    L.nyq_ctx_create.argtypes = [C.POINTER(vp), i]
+    L.nyq_ctx_destroy.argtypes = [vp]
+    L.nyq_ctx_destroy.restype = None
+    L.nyq_last_error.argtypes = [vp]
+    L.nyq_last_error.restype = C.c_char_p
+    L.nyq_ctx_set_stream.argtypes = [vp, vp]
+    L.nyq_ctx_get_stream.argtypes = [vp]
+    L.nyq_ctx_get_stream.restype = vp
+    L.nyq_ctx_synchronize.argtypes = [vp]
+    L.nyq_ctx_set_tables.argtypes = [vp, fp, fp]
+    L.nyq_ctx_get_tables.argtypes = [vp, fp, fp]
+    L.nyq_ctx_device_info.argtypes = [vp, C.POINTER(i), C.c_char_p, sz]
+    L.nyq_ifft_batch_dev.argtypes = [vp, i, fp, fp, sz]
+    L.nyq_imdct_batch_dev.argtypes = [vp, i, fp, fp, fp, fp, sz]
+    L.nyq_imdct_chain_dev.argtypes = [vp, i, fp, fp, fp, fp, fp, sz, sz]
+    L.nyq_ifft_batch.argtypes = [vp, i, fp, fp, sz]
+    L.nyq_imdct_batch.argtypes = [vp, i, fp, fp, fp, fp, sz]
+    L.nyq_imdct_chain.argtypes = [vp, i, fp, fp, fp, fp, sz, sz]
+    L.processMDCTCuda.argtypes = [fp, fp, fp, i, i, i, C.c_float, i, fp]
+    L.processMDCTCuda.restype = None
+    L.processMDCTCudaB1C2.argtypes = [C.POINTER(fp), C.POINTER(fp), fp, i, i, i, C.c_float, i, fp]
+    L.processMDCTCudaB1C2.restype = None
+    L.cleanupCudaBuffers.restype = None
+    L.printCudaVersion.restype = None
+    if path is None:
+        _lib = L
+    return L
+
+
+def _np(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a if shape is None else a.reshape(shape)
+
+
+def n2_of(shift):
+    return 960 >> shift
+
+
+class Context:
+    """nyq_ctx wrapper.  Host-buffer methods take/return numpy arrays; *_dev methods take
+    raw device pointers (ints, e.g. torch.Tensor.data_ptr()) and are asynchronous."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.nyq_ctx_create(C.byref(h), int(device))
+        if rc != NYQ_OK:
+            raise NyqError(rc, (self.lib.nyq_last_error(None) or b"").decode())
+        self.h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nyq_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != NYQ_OK:
+            raise NyqError(rc, (self.lib.nyq_last_error(self.h) or b"").decode())
+
+    # -- context plumbing
+    def set_stream(self, stream_ptr):
+        self._ck(self.lib.nyq_ctx_set_stream(self.h, C.c_void_p(stream_ptr or 0)))
+
+    def synchronize(self):
+        self._ck(self.lib.nyq_ctx_synchronize(self.h))
+
+    def set_tables(self, trig, window):
+        t, w = _f32(trig), _f32(window)
+        assert t.size == 481 and w.size == 120
+        self._ck(self.lib.nyq_ctx_set_tables(self.h, _np(t), _np(w)))
+
+    def get_tables(self):
+        t, w = np.empty(481, np.float32), np.empty(120, np.float32)
+        self._ck(self.lib.nyq_ctx_get_tables(self.h, _np(t), _np(w)))
+        return t, w
+
+    def device_info(self):
+        cus = C.c_int(0)
+        name = C.create_string_buffer(256)
+        self._ck(self.lib.nyq_ctx_device_info(self.h, C.byref(cus), name, 256))
+        return cus.value, name.value.decode()
+
+    # -- host-buffer operators
+    def ifft_batch(self, nfft, x):
+        x = _f32(x, (-1, 2 * nfft))
+        y = np.empty_like(x)
+        self._ck(self.lib.nyq_ifft_batch(self.h, nfft, _np(x), _np(y), x.shape[0]))
+        return y
+
+    def imdct_batch(self, shift, x, carry=None, want_tail=True):
+        n2 = n2_of(shift)
+        x = _f32(x, (-1, n2))
+        b = x.shape[0]
+        carry = None if carry is None else _f32(carry, (b, HALF_OV))
+        fin = np.empty((b, n2), np.float32)
+        tail = np.empty((b, HALF_OV), np.float32) if want_tail else None
+        self._ck(self.lib.nyq_imdct_batch(self.h, shift, _np(x), _np(carry), _np(fin), _np(tail), b))
+        return fin, tail
+
+    def imdct_chain(self, shift, x, carry0=None, nchains=1):
+        n2 = n2_of(shift)
+        x = _f32(x, (-1, n2))
+        rows = x.shape[0]
+        assert rows % nchains == 0
+        carry0 = None if carry0 is None else _f32(carry0, (nchains, HALF_OV))
+        pcm = np.empty((rows, n2), np.float32)
+        tail = np.empty((nchains, HALF_OV), np.float32)
+        self._ck(self.lib.nyq_imdct_chain(self.h, shift, _np(x), _np(carry0), _np(pcm), _np(tail), nchains,
+                                          rows // nchains))
+        return pcm, tail
+
+    # -- device-resident operators (raw pointers)
+    def ifft_batch_dev(self, nfft, d_in, d_out, batch):
+        self._ck(self.lib.nyq_ifft_batch_dev(self.h, nfft, C.c_void_p(d_in), C.c_void_p(d_out), batch))
+
+    def imdct_batch_dev(self, shift, d_in, d_carry, d_fin, d_tail, batch):
+        self._ck(self.lib.nyq_imdct_batch_dev(self.h, shift, C.c_void_p(d_in), C.c_void_p(d_carry or 0),
+                                              C.c_void_p(d_fin), C.c_void_p(d_tail or 0), batch))
+
+    def imdct_chain_dev(self, shift, d_in, d_carry0, d_pcm, d_tail_out, d_work, nchains, length):
+        self._ck(self.lib.nyq_imdct_chain_dev(self.h, shift, C.c_void_p(d_in), C.c_void_p(d_carry0 or 0),
+                                              C.c_void_p(d_pcm), C.c_void_p(d_tail_out or 0), C.c_void_p(d_work),
+                                              nchains, length))

@@ -1,0 +1,47 @@
+"""CPU tier: the C-ABI library builds, loads and exports every symbol include/nyq_imdct.h declares;
+without a GPU the product fails loudly instead of falling back."""
+import os
+import re
+
+import pytest
+
+import libnyquist_amd as nyq
+from conftest import ROOT
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "nyq_imdct.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"^\s*(?:const\s+)?(?:int|void|char)\s*\*?\s*(\w+)\s*\(", text, flags=re.M)
+    return sorted(set(names))
+
+
+def test_header_and_binding_agree():
+    declared = _declared_functions()
+    assert len(declared) >= 19
+    assert sorted(nyq.EXPORTS) == declared
+
+
+def test_library_exports_every_declared_symbol():
+    lib = nyq.load()
+    for name in _declared_functions():
+        assert hasattr(lib, name), name
+
+
+def test_no_torch_or_oracle_in_product_sources():
+    """The product path must not reach the oracle or any CPU fallback."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "libnyquist_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "pyoracle" not in src and "nyq_oracle" not in src and "liboracle" not in src, f
+                assert "lane_emu" not in src, f
+
+
+def test_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(nyq.NyqError) as e:
+        nyq.Context(0)
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)

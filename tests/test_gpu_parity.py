@@ -1,0 +1,255 @@
+"""GPU tier (-m gpu): the HIP path, called through the C ABI, against the oracle, the committed
+golden fixtures and size-independent properties.  Tolerances: north_star's 1e-5 RMS on the
+bundled unit-scale IFFT vectors (absolute) and 1e-5 RELATIVE RMS on IMDCT outputs
+(decoder-scale inputs have rms ~30); measured errors are ~2e-7."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, abs_rms, rel_rms
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import libnyquist_amd as nyq
+    c = nyq.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def ctx_ref_tables(ref_tables):
+    """context carrying the reference's own static tables (what the drop-in shims upload)"""
+    import libnyquist_amd as nyq
+    c = nyq.Context(0)
+    c.set_tables(ref_tables["trig"], ref_tables["window"])
+    yield c
+    c.close()
+
+
+def test_native_library_is_the_one_loaded(ctx):
+    import libnyquist_amd as nyq
+    maps = open("/proc/self/maps").read()
+    assert os.path.realpath(nyq.LIB_PATH) in maps
+    cus, name = ctx.device_info()
+    assert cus > 0 and "gfx950" in name
+
+
+def test_builtin_tables_match_reference(ctx, ref_tables):
+    t, w = ctx.get_tables()
+    assert np.abs(t - ref_tables["trig"]).max() <= 6e-8
+    assert np.abs(w - ref_tables["window"]).max() <= 6e-8
+
+
+# ---- config C2: bundled IFFT vectors ------------------------------------------------
+@pytest.mark.parametrize("nfft,reps", [(60, 65536), (480, 4096)])
+def test_bundled_ifft_vectors_replicated(ctx, nfft, reps):
+    x = np.fromfile(os.path.join(GOLDEN, f"ifft_input_N{nfft}.bin"), np.float32)
+    want = np.fromfile(os.path.join(GOLDEN, f"ifft_output_N{nfft}.bin"), np.float32)
+    y = ctx.ifft_batch(nfft, np.tile(x, (reps, 1)))
+    assert y.shape == (reps, 2 * nfft)
+    err = np.sqrt(np.mean((y.astype(np.float64) - want[None, :]) ** 2, axis=1))
+    assert err.max() <= TOL                      # every row within north_star's 1e-5 RMS
+    assert err.max() <= 2e-7                      # and in fact at float rounding level
+    assert np.array_equal(y[0], y[-1]) and np.array_equal(y[0], y[reps // 2 + 3])   # batch-position independent
+
+
+@pytest.mark.parametrize("shift", [0, 1, 2, 3])
+def test_ifft_vs_reference_fixture_and_oracle(ctx, oracle, shift):
+    z = np.load(os.path.join(GOLDEN, "ref_ifft_shared.npz"))
+    x, want = z[f"x{shift}"], z[f"y{shift}"]
+    nfft = 480 >> shift
+    assert rel_rms(ctx.ifft_batch(nfft, x), want) <= TOL
+    rng = np.random.default_rng(shift)
+    xr = rng.uniform(-1, 1, (1001, 2 * nfft)).astype(np.float32)    # ragged: not a multiple of 4
+    assert rel_rms(ctx.ifft_batch(nfft, xr), oracle.ifft_batch(nfft, xr, shared=True, nthreads=4)) <= 1e-6
+
+
+# ---- full IMDCT -------------------------------------------------------------------------
+@pytest.mark.parametrize("shift", [0, 1, 2, 3])
+def test_imdct_vs_reference_fixtures(ctx_ref_tables, shift):
+    z = np.load(os.path.join(GOLDEN, f"ref_imdct_s{shift}.npz"))
+    x, carry, want = z["x"], z["carry"], z["out"]
+    n2 = 960 >> shift
+    fin, tail = ctx_ref_tables.imdct_batch(shift, x, carry)
+    assert rel_rms(fin, want[:, :n2]) <= TOL
+    assert rel_rms(tail, want[:, n2:]) <= TOL
+    for r in range(x.shape[0]):                     # row by row, incl. silence and impulses
+        ref = want[r]
+        got = np.concatenate([fin[r], tail[r]])
+        scale = max(np.sqrt(np.mean(ref.astype(np.float64) ** 2)), 1e-3)
+        assert abs_rms(got, ref) <= TOL * scale, r
+    assert rel_rms(fin, want[:, :n2]) <= 1e-6       # measured level
+
+
+@pytest.mark.parametrize("shift", [0, 1, 2, 3])
+@pytest.mark.parametrize("rows", [1, 3, 4, 5, 63, 1000, 4099])
+def test_imdct_vs_oracle_ragged(ctx, oracle, shift, rows):
+    n2 = 960 >> shift
+    rng = np.random.default_rng(1000 * shift + rows)
+    x = (rng.standard_normal((rows, n2)) * 30).astype(np.float32)
+    carry = (rng.standard_normal((rows, 60)) * 30).astype(np.float32)
+    ctx.set_tables(*oracle.tables()[:2])
+    for cy in (carry, None):
+        fin, tail = ctx.imdct_batch(shift, x, cy)
+        wf, wt = oracle.imdct_batch(shift, x, cy, nthreads=4)
+        assert rel_rms(fin, wf) <= 1e-6
+        assert rel_rms(tail, wt) <= 1e-6
+    fin2, none = ctx.imdct_batch(shift, x, carry, want_tail=False)
+    assert none is None and np.array_equal(fin2, ctx.imdct_batch(shift, x, carry)[0])
+
+
+def test_empty_batch_and_bad_arguments(ctx):
+    import libnyquist_amd as nyq
+    fin, tail = ctx.imdct_batch(0, np.zeros((0, 960), np.float32))
+    assert fin.shape == (0, 960) and tail.shape == (0, 60)
+    assert ctx.ifft_batch(60, np.zeros((0, 120), np.float32)).shape == (0, 120)
+    with pytest.raises(nyq.NyqError) as e:
+        ctx._ck(ctx.lib.nyq_imdct_batch(ctx.h, 4, None, None, None, None, 1))
+    assert e.value.code == -1
+    with pytest.raises(nyq.NyqError):
+        ctx._ck(ctx.lib.nyq_ifft_batch(ctx.h, 64, None, None, 1))
+    with pytest.raises(nyq.NyqError):
+        ctx._ck(ctx.lib.nyq_imdct_batch(ctx.h, 0, None, None, None, None, 1))     # NULL buffers
+
+
+@pytest.mark.parametrize("shift", [0, 3])
+def test_chain_vs_oracle(ctx, oracle, shift):
+    n2 = 960 >> shift
+    rng = np.random.default_rng(shift + 50)
+    nchains, length = 5, 37
+    x = (rng.standard_normal((nchains * length, n2)) * 30).astype(np.float32)
+    c0 = (rng.standard_normal((nchains, 60)) * 30).astype(np.float32)
+    ctx.set_tables(*oracle.tables()[:2])
+    pcm, tails = ctx.imdct_chain(shift, x, c0, nchains=nchains)
+    for c in range(nchains):
+        wp, wt = oracle.imdct_chain(shift, x[c * length:(c + 1) * length], c0[c])
+        assert rel_rms(pcm[c * length:(c + 1) * length], wp) <= 1e-6
+        assert rel_rms(tails[c], wt) <= 1e-6
+    pcm0, _ = ctx.imdct_chain(shift, x, None, nchains=nchains)      # NULL seed = zeros
+    wp0, _ = oracle.imdct_chain(shift, x[:length], None)
+    assert rel_rms(pcm0[:length], wp0) <= 1e-6
+
+
+def test_chain_vs_reference_mixed_fixture(ctx_ref_tables):
+    """long/short mixed channel (ref_chain.npz): each homogeneous run is one chain call."""
+    z = np.load(os.path.join(GOLDEN, "ref_chain.npz"))
+    kinds, freq = "".join(z["kinds"]), z["freq"]
+    carry = z["carry_in"].copy()
+    out = []
+    for f, k in enumerate(kinds):
+        if k == "L":
+            p, t = ctx_ref_tables.imdct_chain(0, freq[f][None, :], carry[None, :])
+        else:
+            p, t = ctx_ref_tables.imdct_chain(3, freq[f].reshape(120, 8).T.copy(), carry[None, :])
+        carry = t[0]
+        out.append(p.reshape(-1))
+    assert rel_rms(np.concatenate(out), z["pcm"]) <= 1e-6
+    assert rel_rms(carry, z["tail"]) <= 1e-6
+
+
+# ---- the reference's operator names -----------------------------------------------------
+def test_dropin_shims_vs_reference_strided_fixture(ref_tables):
+    import libnyquist_amd as nyq
+    lib = nyq.load()
+    z = np.load(os.path.join(GOLDEN, "ref_imdct_strided.npz"))
+    trig = np.ascontiguousarray(ref_tables["trig"])
+    win = np.ascontiguousarray(ref_tables["window"])
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    fp2 = C.c_void_p * 2
+    X, c0, syn = z["X"], z["carry0"], z["syn"]
+    sine3 = np.float32(2) * np.float32(3.141592653) * np.float32(.125) / np.float32(240)
+    for f in range(X.shape[0]):
+        mem = np.zeros((2, 960 + 60), np.float32)
+        mem[:, :60] = c0[f]
+        xin = np.ascontiguousarray(X[f])
+        for b in range(8):      # compute_inv_mdcts, celt_decoder_clean.c:292-300
+            ins = fp2(xin[0, b:].ctypes.data, xin[1, b:].ctypes.data)
+            outs = fp2(mem[0, 120 * b:].ctypes.data, mem[1, 120 * b:].ctypes.data)
+            lib.processMDCTCudaB1C2(ins, outs, P(trig), 240, 3, 8, sine3, 120, P(win))
+        assert rel_rms(mem, syn[f]) <= 1e-6
+    XL, cl, synl = z["XL"], z["carryL"], z["synL"]
+    sine0 = np.float32(2) * np.float32(3.141592653) * np.float32(.125) / np.float32(1920)
+    for f in range(XL.shape[0]):
+        for c in range(2):
+            mem = np.zeros(960 + 60, np.float32)
+            mem[:60] = cl[f, c]
+            lib.processMDCTCuda(P(np.ascontiguousarray(XL[f, c])), P(mem), P(trig), 1920, 0, 1, sine0, 120, P(win))
+            assert rel_rms(mem, synl[f, c]) <= 1e-6
+    lib.printCudaVersion()
+    lib.cleanupCudaBuffers()
+
+
+# ---- device-resident API at BASELINE.json's full size: properties ------------------------
+def test_full_size_device_resident_properties(ctx, oracle):
+    """2^20 rows of nfft-480 (config C3) through nyq_imdct_batch_dev: a sampled parity check,
+    linearity, and batch-position independence -- properties that do not need a full-size oracle."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rows = 1 << 20
+    ctx.set_tables(*oracle.tables()[:2])
+    s = torch.cuda.current_stream(dev)
+    ctx.set_stream(s.cuda_stream)
+    try:
+        g = torch.Generator(device=dev)
+        g.manual_seed(480)
+        a = torch.rand((rows, 960), generator=g, device=dev) * 2 - 1
+        b = torch.rand((rows, 960), generator=g, device=dev) * 2 - 1
+        fa, ta = torch.empty_like(a), torch.empty((rows, 60), device=dev)
+        fb, tb = torch.empty_like(a), torch.empty((rows, 60), device=dev)
+        fs, ts = torch.empty_like(a), torch.empty((rows, 60), device=dev)
+        ctx.imdct_batch_dev(0, a.data_ptr(), 0, fa.data_ptr(), ta.data_ptr(), rows)
+        ctx.imdct_batch_dev(0, b.data_ptr(), 0, fb.data_ptr(), tb.data_ptr(), rows)
+        ab = a + b
+        ctx.imdct_batch_dev(0, ab.data_ptr(), 0, fs.data_ptr(), ts.data_ptr(), rows)
+        torch.cuda.synchronize(dev)
+        # linearity over the whole batch
+        num = torch.sqrt(torch.mean((fs - (fa + fb)).double() ** 2))
+        den = torch.sqrt(torch.mean(fs.double() ** 2))
+        assert float(num / den) <= 2e-6
+        assert float(torch.sqrt(torch.mean((ts - (ta + tb)).double() ** 2)) / torch.sqrt(torch.mean(ts.double() ** 2))) <= 2e-6
+        # sampled rows against the oracle (first, last, strided)
+        idx = torch.cat([torch.arange(0, 1024), torch.arange(rows - 1024, rows), torch.arange(0, rows, 509)[:2048]]).to(dev)
+        xs = a[idx].cpu().numpy()
+        wf, wt = oracle.imdct_batch(0, xs, None, nthreads=4)
+        assert rel_rms(fa[idx].cpu().numpy(), wf) <= 1e-6
+        assert rel_rms(ta[idx].cpu().numpy(), wt) <= 1e-6
+        # same row anywhere in the batch gives the same bits
+        a2 = a.clone()
+        a2[rows - 7] = a[3]
+        ctx.imdct_batch_dev(0, a2.data_ptr(), 0, fb.data_ptr(), tb.data_ptr(), rows)
+        torch.cuda.synchronize(dev)
+        assert torch.equal(fb[rows - 7], fa[3]) and torch.equal(tb[rows - 7], ta[3])
+        # misaligned device pointer is rejected, not launched
+        import libnyquist_amd as nyq
+        with pytest.raises(nyq.NyqError):
+            ctx.imdct_batch_dev(0, a.data_ptr() + 4, 0, fa.data_ptr(), ta.data_ptr(), 16)
+    finally:
+        ctx.set_stream(0)
+
+
+def test_chain_dev_matches_host_chain(ctx, oracle):
+    import torch
+    dev = torch.device("cuda", 0)
+    ctx.set_tables(*oracle.tables()[:2])
+    rng = np.random.default_rng(9)
+    nchains, length = 64, 50
+    x = (rng.standard_normal((nchains * length, 960)) * 30).astype(np.float32)
+    d_x = torch.from_numpy(x).to(dev)
+    d_pcm = torch.empty_like(d_x)
+    d_tail = torch.empty((nchains, 60), device=dev)
+    d_work = torch.empty((nchains * length, 60), device=dev)
+    torch.cuda.synchronize(dev)
+    ctx.imdct_chain_dev(0, d_x.data_ptr(), 0, d_pcm.data_ptr(), d_tail.data_ptr(), d_work.data_ptr(), nchains, length)
+    ctx.synchronize()
+    wp, wt = oracle.imdct_chain(0, x[:length], None)
+    assert rel_rms(d_pcm[:length].cpu().numpy(), wp) <= 1e-6
+    wp, wt = oracle.imdct_chain(0, x[-length:], None)
+    assert rel_rms(d_pcm[-length:].cpu().numpy(), wp) <= 1e-6
+    assert rel_rms(d_tail[-1].cpu().numpy(), wt) <= 1e-6
