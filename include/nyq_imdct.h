@@ -54,8 +54,10 @@ int  nyq_ctx_create(nyq_ctx **out, int device);
 void nyq_ctx_destroy(nyq_ctx *ctx);
 /* text of the last failure on ctx (ctx == NULL: last failure of ctx-less calls) */
 const char *nyq_last_error(const nyq_ctx *ctx);
-/* Run on a caller-owned hipStream_t (NULL restores the context's own stream). */
+/* Run on a caller-owned hipStream_t, taken literally: NULL is HIP's default (null) stream.
+ * A new context runs on a private non-blocking stream; nyq_ctx_reset_stream() returns to it. */
 int  nyq_ctx_set_stream(nyq_ctx *ctx, void *hip_stream);
+int  nyq_ctx_reset_stream(nyq_ctx *ctx);
 void *nyq_ctx_get_stream(nyq_ctx *ctx);
 int  nyq_ctx_synchronize(nyq_ctx *ctx);
 /* Replace the built-in tables by the caller's (host pointers, copied): trig[481] =

@@ -18,7 +18,7 @@ ERRORS = {-1: "NYQ_ERR_INVALID", -2: "NYQ_ERR_NO_DEVICE", -3: "NYQ_ERR_HIP", -4:
 
 # every symbol include/nyq_imdct.h declares (tests check the .so exports all of them)
 EXPORTS = [
-    "nyq_ctx_create", "nyq_ctx_destroy", "nyq_last_error", "nyq_ctx_set_stream", "nyq_ctx_get_stream",
+    "nyq_ctx_create", "nyq_ctx_destroy", "nyq_last_error", "nyq_ctx_set_stream", "nyq_ctx_reset_stream", "nyq_ctx_get_stream",
     "nyq_ctx_synchronize", "nyq_ctx_set_tables", "nyq_ctx_get_tables", "nyq_ctx_device_info",
     "nyq_ifft_batch_dev", "nyq_imdct_batch_dev", "nyq_imdct_chain_dev",
     "nyq_ifft_batch", "nyq_imdct_batch", "nyq_imdct_chain",
@@ -57,6 +57,7 @@ def load(path=None):
     L.nyq_last_error.argtypes = [vp]
     L.nyq_last_error.restype = C.c_char_p
     L.nyq_ctx_set_stream.argtypes = [vp, vp]
+    L.nyq_ctx_reset_stream.argtypes = [vp]
     L.nyq_ctx_get_stream.argtypes = [vp]
     L.nyq_ctx_get_stream.restype = vp
     L.nyq_ctx_synchronize.argtypes = [vp]
@@ -123,7 +124,11 @@ class Context:
 
     # -- context plumbing
     def set_stream(self, stream_ptr):
+        """Run on the given hipStream_t (int handle); 0 is HIP's default stream."""
         self._ck(self.lib.nyq_ctx_set_stream(self.h, C.c_void_p(stream_ptr or 0)))
+
+    def reset_stream(self):
+        self._ck(self.lib.nyq_ctx_reset_stream(self.h))
 
     def synchronize(self):
         self._ck(self.lib.nyq_ctx_synchronize(self.h))

@@ -228,7 +228,13 @@ extern "C" void nyq_ctx_destroy(nyq_ctx *ctx) {
 
 extern "C" int nyq_ctx_set_stream(nyq_ctx *ctx, void *hip_stream) {
     if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_ctx_set_stream: ctx is NULL");
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = (hipStream_t)hip_stream;
+    return NYQ_OK;
+}
+
+extern "C" int nyq_ctx_reset_stream(nyq_ctx *ctx) {
+    if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_ctx_reset_stream: ctx is NULL");
+    ctx->stream = ctx->own_stream;
     return NYQ_OK;
 }
 

@@ -231,7 +231,7 @@ def test_full_size_device_resident_properties(ctx, oracle):
         with pytest.raises(nyq.NyqError):
             ctx.imdct_batch_dev(0, a.data_ptr() + 4, 0, fa.data_ptr(), ta.data_ptr(), 16)
     finally:
-        ctx.set_stream(0)
+        ctx.reset_stream()
 
 
 def test_chain_dev_matches_host_chain(ctx, oracle):
@@ -245,7 +245,7 @@ def test_chain_dev_matches_host_chain(ctx, oracle):
     d_pcm = torch.empty_like(d_x)
     d_tail = torch.empty((nchains, 60), device=dev)
     d_work = torch.empty((nchains * length, 60), device=dev)
-    torch.cuda.synchronize(dev)
+    torch.cuda.synchronize(dev)      # ctx runs on its own stream here: order it after torch's copies
     ctx.imdct_chain_dev(0, d_x.data_ptr(), 0, d_pcm.data_ptr(), d_tail.data_ptr(), d_work.data_ptr(), nchains, length)
     ctx.synchronize()
     wp, wt = oracle.imdct_chain(0, x[:length], None)
