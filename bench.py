@@ -177,6 +177,20 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms = [a.elapsed_time(b) for a, b in ev]
 
+    # measured on-node device copy (read N bytes + write N bytes), for context beside the nominal peak
+    copy_gbs = None
+    if rank == 0:
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fin.copy_(x)
+        c0.record(stream)
+        for _ in range(5):
+            fin.copy_(x)
+        c1.record(stream)
+        torch.cuda.synchronize(dev)
+        copy_gbs = 5 * 2 * x.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        step()                                  # restore fin for the parity check below
+        torch.cuda.synchronize(dev)
+
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -233,7 +247,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "imdct_rows_kernel<32>", "kernel_avg_ms": kern_avg_ms,
-                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_IMDCT * rows},
+                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_IMDCT * rows,
+                         "measured_device_copy_GBps": copy_gbs},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

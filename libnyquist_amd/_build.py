@@ -12,7 +12,8 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libnyq_imdct.so")
 SOURCES = [os.path.join(CSRC, "nyq_imdct.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, "nyq_imdct_lanes.hpp"), os.path.join(CSRC, "nyq_fft_core.hpp"),
+DEPS = SOURCES + [os.path.join(CSRC, "nyq_kernels.hpp"), os.path.join(CSRC, "nyq_imdct_lanes.hpp"),
+                  os.path.join(CSRC, "nyq_fft_core.hpp"),
                   os.path.join(ROOT, "include", "nyq_imdct.h")]
 
 
@@ -34,7 +35,9 @@ def build(force=False, verbose=False):
     """Build libnyquist_amd/libnyq_imdct.so if missing or older than its sources."""
     if not force and not stale():
         return LIB
-    cmd = [hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
+    # -fno-slp-vectorize: on gfx950 packed f32 VALU issues at half rate, so hipcc's SLP packing of
+    # the butterflies buys nothing and costs ~480 v_mov plus 70 VGPRs (218 -> 148: 2 -> 3 waves/SIMD).
+    cmd = [hipcc(), "-O3", "-fno-slp-vectorize", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
            "-o", LIB] + SOURCES
     if verbose:
         print(" ".join(cmd))

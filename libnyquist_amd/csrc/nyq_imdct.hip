@@ -1,11 +1,7 @@
 // nyq_imdct.hip -- gfx950 kernels + C ABI (include/nyq_imdct.h) of the batched CELT IMDCT.
 //
-// Kernels (all wave-autonomous: 64 lanes own 4 rows, meet only in their LDS slice):
-//   imdct_rows_kernel<N2R>   clt_mdct_backward  (mdct.c:267-379)  on independent rows
-//   ifft_rows_kernel<N2R>    opus_ifft          (kiss_fft.c:696-747)
-//   chain_fixup_kernel       adds the carry terms of the TDAC mirror (mdct.c:362-377)
-//                            for rows chained to their predecessor's tail
-//   gather_rows_kernel       strided -> contiguous rows (transient layout, stride B)
+// The kernels themselves live in nyq_kernels.hpp (lane program: nyq_imdct_lanes.hpp, register
+// DFTs: nyq_fft_core.hpp); this file is the host side: context, launch geometry, C ABI.
 // HBM traffic per row (shift 0): 3840 B read + 3840 B written (+240 B tail) -- the
 // algorithmic 7680 B of SURVEY.md section 8(d); tables (2.4 KB) stay in L2.
 #include <hip/hip_runtime.h>
@@ -18,112 +14,13 @@
 #include <string>
 
 #include "../../include/nyq_imdct.h"
-#include "nyq_imdct_lanes.hpp"
+
+#include "nyq_kernels.hpp"
 
 using namespace nyq;
 
-// Lanes of one wave exchange data through LDS without a workgroup barrier.  The LDS
-// unit executes one wave's accesses in issue order, so only the COMPILER must be told
-// not to move LDS accesses across a phase boundary.
-#define NYQ_WAVE_SYNC()                                          \
-    do {                                                         \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
-        __builtin_amdgcn_wave_barrier();                         \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
-    } while (0)
-
-constexpr int kWavesPerBlock = 2;
-
-template <int N2R>
-__global__ __launch_bounds__(kWave *kWavesPerBlock) void imdct_rows_kernel(
-    const float *__restrict__ in, const float *__restrict__ carry, float *__restrict__ fin,
-    float *__restrict__ tail, long nrows, const float *__restrict__ trig,
-    const float *__restrict__ window) {
-    using Gm = Geo<N2R>;
-    __shared__ cpx lds_all[kWavesPerBlock * Gm::LDS_CPX];
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wv = threadIdx.x >> 6;
-    cpx *lds = lds_all + wv * Gm::LDS_CPX;
-
-    LaneConst<N2R> K;
-    lane_init<N2R>(K, lane, trig, window);
-
-    const long ngroups = (nrows + kGroup - 1) / kGroup;
-    const long nwaves = (long)gridDim.x * kWavesPerBlock;
-    for (long gi = (long)blockIdx.x * kWavesPerBlock + wv; gi < ngroups; gi += nwaves) {
-        const long row0 = gi * kGroup;
-        StageRegs<N2R> R;
-        stage_in_load<N2R>(R, lane, in, row0, nrows);
-        NYQ_WAVE_SYNC();
-        stage_in_store<N2R>(R, K, lane, lds);
-        NYQ_WAVE_SYNC();
-        pass1<N2R>(lane, lds);
-        NYQ_WAVE_SYNC();
-#pragma unroll
-        for (int it = 0; it < Gm::P2_ITERS; it++) {
-            cpx v[15];
-            int g, n2;
-            bool ok = pass2_load<N2R>(lane, it, lds, v, g, n2);
-            NYQ_WAVE_SYNC();
-            if (ok) pass2_store<N2R>(g, n2, lds, v);
-        }
-        NYQ_WAVE_SYNC();
-        stage_out<N2R>(K, lane, lds, carry, fin, tail, row0, nrows);
-    }
-}
-
-template <int N2R>
-__global__ __launch_bounds__(kWave *kWavesPerBlock) void ifft_rows_kernel(
-    const float *__restrict__ in, float *__restrict__ out, long nrows) {
-    using Gm = Geo<N2R>;
-    __shared__ cpx lds_all[kWavesPerBlock * Gm::LDS_CPX];
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wv = threadIdx.x >> 6;
-    cpx *lds = lds_all + wv * Gm::LDS_CPX;
-    const long ngroups = (nrows + kGroup - 1) / kGroup;
-    const long nwaves = (long)gridDim.x * kWavesPerBlock;
-    for (long gi = (long)blockIdx.x * kWavesPerBlock + wv; gi < ngroups; gi += nwaves) {
-        const long row0 = gi * kGroup;
-        NYQ_WAVE_SYNC();
-        ifft_stage_in<N2R>(lane, in, lds, row0, nrows);
-        NYQ_WAVE_SYNC();
-        pass1<N2R>(lane, lds);
-        NYQ_WAVE_SYNC();
-#pragma unroll
-        for (int it = 0; it < Gm::P2_ITERS; it++) {
-            cpx v[15];
-            int g, n2;
-            bool ok = pass2_load<N2R>(lane, it, lds, v, g, n2);
-            NYQ_WAVE_SYNC();
-            if (ok) pass2_store<N2R>(g, n2, lds, v);
-        }
-        NYQ_WAVE_SYNC();
-        ifft_stage_out<N2R>(lane, lds, out, row0, nrows);
-    }
-}
-
-// One 64-thread block per row: lanes 0..59 add the carry terms of mdct.c:371-372 to a
-// head that was produced with zero carry:  out[i] += w[119-i]*c[i];  out[119-i] += w[i]*c[i].
-// Row r of chain c takes c[] from tails[row-1] (r > 0) or carry0[c] (r == 0, may be NULL).
-__global__ __launch_bounds__(64) void chain_fixup_kernel(float *__restrict__ pcm,
-                                                          const float *__restrict__ tails,
-                                                          const float *__restrict__ carry0,
-                                                          float *__restrict__ tail_out, int n2,
-                                                          long len, long nrows,
-                                                          const float *__restrict__ window) {
-    const int i = threadIdx.x;
-    if (i >= kHalfOv) return;
-    for (long row = blockIdx.x; row < nrows; row += gridDim.x) {
-        const long c = row / len, r = row - c * len;
-        float cv = 0.f;
-        if (r > 0) cv = tails[(row - 1) * kHalfOv + i];
-        else if (carry0) cv = carry0[c * kHalfOv + i];
-        float *o = pcm + row * (long)n2;
-        o[i] += window[kOverlap - 1 - i] * cv;
-        o[kOverlap - 1 - i] += window[i] * cv;
-        if (tail_out && r == len - 1) tail_out[c * kHalfOv + i] = tails[row * kHalfOv + i];
-    }
-}
+using Cfg = DefaultCfg;                 // the shipped kernel configuration (tools/kbench.hip picks it)
+constexpr int kWavesPerBlock = Cfg::WPB;
 
 // ---------------------------------------------------------------------------------
 // host side of the C ABI
@@ -140,6 +37,8 @@ struct nyq_ctx {
     // scratch for the host-buffer entry points
     float *d_scratch = nullptr;
     size_t scratch_bytes = 0;
+    int res_imdct[4] = {0, 0, 0, 0};   // resident blocks per kernel instance (occupancy query, cached)
+    int res_ifft[4] = {0, 0, 0, 0};
     std::string err;
     char devname[256];
 };
@@ -271,24 +170,37 @@ extern "C" int nyq_ctx_device_info(nyq_ctx *ctx, int *compute_units, char *name,
 
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// persistent grid: enough blocks to fill every CU to its LDS limit, never more than the work
-template <int N2R>
-static unsigned grid_for(const nyq_ctx *ctx, size_t batch) {
-    using Gm = Geo<N2R>;
+// persistent grid: never more blocks than the chip keeps resident (registers, LDS and wave
+// slots all counted by the occupancy query) -- a larger grid would run its surplus blocks as a
+// second, mostly idle round -- capped at the measured sweet spot of NYQ_WAVES_PER_CU, and never
+// more than the work.
+template <typename K>
+static int resident_blocks(nyq_ctx *ctx, K kernel, int *cache) {
+    if (*cache > 0) return *cache;
+    int per_cu = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kWave * kWavesPerBlock, 0);
+    if (e != hipSuccess || per_cu < 1) per_cu = 1;
+    const int want = (NYQ_WAVES_PER_CU + kWavesPerBlock - 1) / kWavesPerBlock;   // see nyq_kernels.hpp
+    if (per_cu > want) per_cu = want;
+    if (const char *o = std::getenv("NYQ_BLOCKS_PER_CU")) {   // tuning knob for profiling runs
+        int v = std::atoi(o);
+        if (v > 0) per_cu = v;
+    }
+    *cache = per_cu * ctx->cus;
+    return *cache;
+}
+
+static unsigned grid_for(size_t batch, int resident) {
     const size_t ngroups = (batch + kGroup - 1) / kGroup;
     const size_t need = (ngroups + kWavesPerBlock - 1) / kWavesPerBlock;
-    const size_t lds_per_block = sizeof(cpx) * Gm::LDS_CPX * kWavesPerBlock;
-    size_t per_cu = (160 * 1024) / lds_per_block;
-    if (per_cu > 8) per_cu = 8;    // 16 waves per CU is plenty for the small sizes
-    if (per_cu < 1) per_cu = 1;
-    const size_t cap = (size_t)ctx->cus * per_cu;
-    return (unsigned)(need < cap ? need : cap);
+    return (unsigned)(need < (size_t)resident ? need : (size_t)resident);
 }
 
 template <int N2R>
 static int launch_imdct(nyq_ctx *ctx, const float *d_in, const float *d_carry, float *d_fin, float *d_tail,
                         size_t batch) {
-    hipLaunchKernelGGL((imdct_rows_kernel<N2R>), dim3(grid_for<N2R>(ctx, batch)), dim3(kWave * kWavesPerBlock), 0,
+    const int res = resident_blocks(ctx, imdct_rows_kernel<N2R, Cfg>, &ctx->res_imdct[Geo<N2R>::SHIFT]);
+    hipLaunchKernelGGL((imdct_rows_kernel<N2R, Cfg>), dim3(grid_for(batch, res)), dim3(kWave * kWavesPerBlock), 0,
                        ctx->stream, d_in, d_carry, d_fin, d_tail, (long)batch, ctx->d_trig, ctx->d_window);
     NYQ_HIP(ctx, hipGetLastError());
     return NYQ_OK;
@@ -296,7 +208,8 @@ static int launch_imdct(nyq_ctx *ctx, const float *d_in, const float *d_carry, f
 
 template <int N2R>
 static int launch_ifft(nyq_ctx *ctx, const float *d_in, float *d_out, size_t batch) {
-    hipLaunchKernelGGL((ifft_rows_kernel<N2R>), dim3(grid_for<N2R>(ctx, batch)), dim3(kWave * kWavesPerBlock), 0,
+    const int res = resident_blocks(ctx, ifft_rows_kernel<N2R, kWavesPerBlock>, &ctx->res_ifft[Geo<N2R>::SHIFT]);
+    hipLaunchKernelGGL((ifft_rows_kernel<N2R, kWavesPerBlock>), dim3(grid_for(batch, res)), dim3(kWave * kWavesPerBlock), 0,
                        ctx->stream, d_in, d_out, (long)batch);
     NYQ_HIP(ctx, hipGetLastError());
     return NYQ_OK;

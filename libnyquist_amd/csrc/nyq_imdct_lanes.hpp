@@ -36,6 +36,32 @@ struct alignas(16) f4 {
     float x, y, z, w;
 };
 
+// 16-byte global accesses.  NT != 0 marks the access non-temporal (streamed once, do not keep
+// in L2/MALL); on the host replay it is an ordinary access.
+template <int NT>
+NYQ_HD f4 ld_f4(const float *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    if constexpr (NT != 0) {
+        v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+        return f4{v.x, v.y, v.z, v.w};
+    }
+#endif
+    return *reinterpret_cast<const f4 *>(p);
+}
+template <int NT>
+NYQ_HD void st_f4(float *p, f4 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    if constexpr (NT != 0) {
+        v4f w = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(w, reinterpret_cast<v4f *>(p));
+        return;
+    }
+#endif
+    *reinterpret_cast<f4 *>(p) = v;
+}
+
 constexpr int kOverlap = 120;   // static_modes_float.h:579
 constexpr int kHalfOv = 60;
 constexpr int kGroup = 4;       // rows per wave-group
@@ -142,7 +168,7 @@ struct StageRegs {
 };
 
 // issue every global load of the group (rows row0 .. row0+3, clipped to nrows)
-template <int N2R>
+template <int N2R, int NT = 0>
 NYQ_HD void stage_in_load(StageRegs<N2R> &R, int lane, const float *in, long row0, long nrows) {
     using Gm = Geo<N2R>;
 #pragma unroll
@@ -152,8 +178,8 @@ NYQ_HD void stage_in_load(StageRegs<N2R> &R, int lane, const float *in, long row
         stage_slot<N2R>(sub, lane, g, j, on);
         if (on && row0 + g < nrows) {
             const float *row = in + (row0 + g) * (long)Gm::NIN;
-            R.a[sub] = *reinterpret_cast<const f4 *>(row + 4 * j);
-            R.b[sub] = *reinterpret_cast<const f4 *>(row + Gm::NIN - 4 - 4 * j);
+            R.a[sub] = ld_f4<NT>(row + 4 * j);
+            R.b[sub] = ld_f4<NT>(row + Gm::NIN - 4 - 4 * j);
         } else {
             R.a[sub] = f4{0, 0, 0, 0};
             R.b[sub] = f4{0, 0, 0, 0};
@@ -228,7 +254,7 @@ NYQ_HD void pass2_store(int g, int n2, cpx *lds, cpx (&v)[15]) {
 
 // ---- phase D -----------------------------------------------------------------
 // carry: [nrows][60] or nullptr (zeros).  fin: [nrows][NIN].  tail: [nrows][60] or nullptr.
-template <int N2R>
+template <int N2R, int NT = 0>
 NYQ_HD void stage_out(const LaneConst<N2R> &K, int lane, const cpx *lds, const float *carry,
                       float *fin, float *tail, long row0, long nrows) {
     using Gm = Geo<N2R>;
@@ -262,12 +288,12 @@ NYQ_HD void stage_out(const LaneConst<N2R> &K, int lane, const cpx *lds, const f
             lo.z = K.whi[1] * C.z - K.wlo[2] * F.y;
             lo.y = K.whi[2] * C.y - K.wlo[1] * F.z;
             lo.x = K.whi[3] * C.x - K.wlo[0] * F.w;
-            *reinterpret_cast<f4 *>(orow + 60 + 4 * j) = hi;
-            *reinterpret_cast<f4 *>(orow + 56 - 4 * j) = lo;
-            if (tail) *reinterpret_cast<f4 *>(tail + r * kHalfOv + 56 - 4 * j) = Bk;
+            st_f4<NT>(orow + 60 + 4 * j, hi);
+            st_f4<NT>(orow + 56 - 4 * j, lo);
+            if (tail) st_f4<NT>(tail + r * kHalfOv + 56 - 4 * j, Bk);
         } else {
-            *reinterpret_cast<f4 *>(orow + 60 + 4 * j) = F;
-            *reinterpret_cast<f4 *>(orow + Gm::NIN + 56 - 4 * j) = Bk;
+            st_f4<NT>(orow + 60 + 4 * j, F);
+            st_f4<NT>(orow + Gm::NIN + 56 - 4 * j, Bk);
         }
     }
 }
