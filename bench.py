@@ -119,6 +119,10 @@ def main():
     ap.add_argument("--rows", type=int, default=1 << 20, help="rows per GPU (default 2^20)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for the barrier / max-time reduction (nccl = RCCL)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="map every rank to cuda:0 (multi-rank rehearsal on a 1-GPU box; use with --dist-backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -134,10 +138,16 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the IMDCT path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    red_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")
 
     import libnyquist_amd as nyq
     ctx = nyq.Context(local_rank)
@@ -192,10 +202,10 @@ def main():
         torch.cuda.synchronize(dev)
 
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        k = torch.tensor([sum(kern_ms) / len(kern_ms)], device=dev, dtype=torch.float64)
+        k = torch.tensor([sum(kern_ms) / len(kern_ms)], device=red_dev, dtype=torch.float64)
         dist.all_reduce(k, op=dist.ReduceOp.MAX)
         kern_avg_ms = float(k.item())
     else:
@@ -246,7 +256,7 @@ def main():
             "parity_rel_rms_vs_oracle": parity,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "imdct_rows_kernel<32>", "kernel_avg_ms": kern_avg_ms,
+                         "kernel": "nyq::imdct_rows_kernel<32, KCfg<1,false,0>>", "kernel_avg_ms": kern_avg_ms,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_IMDCT * rows,
                          "measured_device_copy_GBps": copy_gbs},
         }

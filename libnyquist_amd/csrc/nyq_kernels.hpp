@@ -28,8 +28,9 @@ namespace nyq {
 //   WPB       waves per workgroup (each wave is autonomous; WPB only sets the LDS granule)
 //   PREFETCH  issue the next group's global loads right after pre-rotation of the current one
 //   NT        bit 0: non-temporal loads, bit 1: non-temporal stores
-template <int WPB_, bool PREFETCH_, int NT_>
+template <int WPB_, bool PREFETCH_, int NT_, bool CHUNKED_ = false>
 struct KCfg {
+    static constexpr bool CHUNKED = CHUNKED_;   // contiguous run of groups per wave instead of grid-stride
     static constexpr int WPB = WPB_;
     static constexpr bool PREFETCH = PREFETCH_;
     static constexpr int NT_LD = NT_ & 1;
@@ -79,9 +80,14 @@ __global__ __launch_bounds__(kWave *Cfg::WPB) void imdct_rows_kernel(
     LaneConst<N2R> K;
     lane_init<N2R>(K, lane, trig, window);
 
-    const long ngroups = (nrows + kGroup - 1) / kGroup;
-    const long nwaves = (long)gridDim.x * Cfg::WPB;
-    long gi = (long)blockIdx.x * Cfg::WPB + wv;
+    const long ngroups_all = (nrows + kGroup - 1) / kGroup;
+    const long nwaves_all = (long)gridDim.x * Cfg::WPB;
+    const long wid = (long)blockIdx.x * Cfg::WPB + wv;
+    // grid-stride: wave w takes groups w, w+W, ...; chunked: wave w takes one contiguous run
+    const long per = (ngroups_all + nwaves_all - 1) / nwaves_all;
+    const long nwaves = Cfg::CHUNKED ? 1 : nwaves_all;
+    long gi = Cfg::CHUNKED ? wid * per : wid;
+    const long ngroups = Cfg::CHUNKED ? (gi + per < ngroups_all ? gi + per : ngroups_all) : ngroups_all;
     StageRegs<N2R> R;
     if constexpr (Cfg::PREFETCH) {
         // Software pipeline over this wave's groups: the float4 loads of group g+1 are issued

@@ -27,15 +27,16 @@ static long rows = 1 << 20;
 static int cus = 256;
 
 template <typename Cfg>
-static void add(std::vector<Variant> &v, const char *name, int blocks_per_cu) {
+static void add(std::vector<Variant> &v, const char *name, int blocks_per_cu, bool with_tail = true) {
     int occ = 0;
     CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, imdct_rows_kernel<32, Cfg>, kWave * Cfg::WPB, 0));
     int bpc = blocks_per_cu > 0 ? blocks_per_cu : occ;
     char nm[160];
     snprintf(nm, sizeof nm, "%-28s wpb%d blk/CU %d (occ %d)", name, Cfg::WPB, bpc, occ);
     unsigned grid = (unsigned)(cus * bpc);
-    v.push_back({nm, [grid] {
-        hipLaunchKernelGGL((imdct_rows_kernel<32, Cfg>), dim3(grid), dim3(kWave * Cfg::WPB), 0, 0, d_in, nullptr, d_fin, d_tail, rows, d_trig, d_win);
+    float *tl = with_tail ? d_tail : nullptr;
+    v.push_back({nm, [grid, tl] {
+        hipLaunchKernelGGL((imdct_rows_kernel<32, Cfg>), dim3(grid), dim3(kWave * Cfg::WPB), 0, 0, d_in, nullptr, d_fin, tl, rows, d_trig, d_win);
     }, {}});
 }
 
