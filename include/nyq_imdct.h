@@ -91,12 +91,35 @@ int nyq_imdct_chain_dev(nyq_ctx *ctx, int shift, const float *d_in, const float 
                         float *d_pcm, float *d_tail_out, float *d_work,
                         size_t nchains, size_t len);
 
+/* compute_inv_mdcts (celt_decoder_clean.c:264-312) plus the decode_mem carry of :622-656, for
+ * whole frame sequences: `nstreams` independent decoders x `nframes` frames x `channels`
+ * channels, all of frame size N = 120 << LM (LM 0..3; Opus 20 ms frames are LM 3).
+ *   d_freq      [nstreams][nframes][channels][N]  freq[] exactly as denormalise_bands leaves it
+ *                                                 (channel c at +c*N); in a transient frame the
+ *                                                 B = 2^LM short blocks are interleaved,
+ *                                                 coefficient k of block b at [b + B*k] (:292-300)
+ *   d_transient [nstreams][nframes] bytes         non-zero = transient (shortBlocks) frame;
+ *                                                 NULL = no transient frames
+ *   d_pcm       [nstreams][channels][nframes*N]   time-contiguous per channel: what out_syn /
+ *                                                 decode_mem holds before comb_filter (:663)
+ *   d_state     [nstreams*channels][60] or NULL   in: overlap carry before frame 0 (zeros after a
+ *                                                 reset, :846-859); out: carry after the last frame
+ *   d_work      nyq_celt_synth_work_floats() floats of caller-provided scratch
+ * Every raw IMDCT runs in parallel; consecutive long frames chain their carry inside a wave,
+ * all other block boundaries are completed by one tiny fix-up launch.  Asynchronous. */
+size_t nyq_celt_synth_work_floats(size_t nstreams, size_t nframes, int channels);
+int nyq_celt_synth_dev(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned char *d_transient,
+                       float *d_pcm, float *d_state, float *d_work,
+                       size_t nstreams, size_t nframes, int channels);
+
 /* ---- host-buffer variants (synchronous: H2D, kernel, D2H through context scratch) ---- */
 int nyq_ifft_batch(nyq_ctx *ctx, int nfft, const float *in, float *out, size_t batch);
 int nyq_imdct_batch(nyq_ctx *ctx, int shift, const float *in, const float *carry,
                     float *fin, float *tail, size_t batch);
 int nyq_imdct_chain(nyq_ctx *ctx, int shift, const float *in, const float *carry0,
                     float *pcm, float *tail_out, size_t nchains, size_t len);
+int nyq_celt_synth(nyq_ctx *ctx, int LM, const float *freq, const unsigned char *transient,
+                   float *pcm, float *state, size_t nstreams, size_t nframes, int channels);
 
 /* ---- the reference's operator boundary, kept verbatim ------------------- */
 /* cuda/mdct_cuda.hpp:89-91 (impl mdct_cuda.cu:314-392).  Host pointers, caller-owned.

@@ -21,6 +21,7 @@ EXPORTS = [
     "nyq_ctx_create", "nyq_ctx_destroy", "nyq_last_error", "nyq_ctx_set_stream", "nyq_ctx_reset_stream", "nyq_ctx_get_stream",
     "nyq_ctx_synchronize", "nyq_ctx_set_tables", "nyq_ctx_get_tables", "nyq_ctx_device_info",
     "nyq_ifft_batch_dev", "nyq_imdct_batch_dev", "nyq_imdct_chain_dev",
+    "nyq_celt_synth_work_floats", "nyq_celt_synth_dev", "nyq_celt_synth",
     "nyq_ifft_batch", "nyq_imdct_batch", "nyq_imdct_chain",
     "processMDCTCuda", "processMDCTCudaB1C2", "cleanupCudaBuffers", "printCudaVersion",
 ]
@@ -67,6 +68,10 @@ def load(path=None):
     L.nyq_ifft_batch_dev.argtypes = [vp, i, fp, fp, sz]
     L.nyq_imdct_batch_dev.argtypes = [vp, i, fp, fp, fp, fp, sz]
     L.nyq_imdct_chain_dev.argtypes = [vp, i, fp, fp, fp, fp, fp, sz, sz]
+    L.nyq_celt_synth_work_floats.argtypes = [sz, sz, i]
+    L.nyq_celt_synth_work_floats.restype = sz
+    L.nyq_celt_synth_dev.argtypes = [vp, i, fp, fp, fp, fp, fp, sz, sz, i]
+    L.nyq_celt_synth.argtypes = [vp, i, fp, fp, fp, fp, sz, sz, i]
     L.nyq_ifft_batch.argtypes = [vp, i, fp, fp, sz]
     L.nyq_imdct_batch.argtypes = [vp, i, fp, fp, fp, fp, sz]
     L.nyq_imdct_chain.argtypes = [vp, i, fp, fp, fp, fp, sz, sz]
@@ -177,6 +182,27 @@ class Context:
         self._ck(self.lib.nyq_imdct_chain(self.h, shift, _np(x), _np(carry0), _np(pcm), _np(tail), nchains,
                                           rows // nchains))
         return pcm, tail
+
+    def celt_synth(self, lm, freq, transient=None, state=None, channels=2):
+        """freq [nstreams][nframes][channels][120<<lm]; transient [nstreams][nframes] uint8 or None;
+        state [nstreams*channels][60] or None.  Returns (pcm [nstreams][channels][nframes*N], state_out)."""
+        n = 120 << lm
+        freq = _f32(freq)
+        assert freq.ndim == 4 and freq.shape[2] == channels and freq.shape[3] == n
+        ns, nf = freq.shape[0], freq.shape[1]
+        tr = None if transient is None else np.ascontiguousarray(transient, dtype=np.uint8).reshape(ns, nf)
+        st = None if state is None else _f32(state, (ns * channels, HALF_OV)).copy()
+        pcm = np.empty((ns, channels, nf * n), np.float32)
+        self._ck(self.lib.nyq_celt_synth(self.h, lm, _np(freq), _np(tr), _np(pcm), _np(st), ns, nf, channels))
+        return pcm, st
+
+    def celt_synth_work_floats(self, nstreams, nframes, channels):
+        return int(self.lib.nyq_celt_synth_work_floats(nstreams, nframes, channels))
+
+    def celt_synth_dev(self, lm, d_freq, d_transient, d_pcm, d_state, d_work, nstreams, nframes, channels):
+        self._ck(self.lib.nyq_celt_synth_dev(self.h, lm, C.c_void_p(d_freq), C.c_void_p(d_transient or 0),
+                                             C.c_void_p(d_pcm), C.c_void_p(d_state or 0), C.c_void_p(d_work),
+                                             nstreams, nframes, channels))
 
     # -- device-resident operators (raw pointers)
     def ifft_batch_dev(self, nfft, d_in, d_out, batch):

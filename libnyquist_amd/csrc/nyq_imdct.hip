@@ -39,6 +39,8 @@ struct nyq_ctx {
     size_t scratch_bytes = 0;
     int res_imdct[4] = {0, 0, 0, 0};   // resident blocks per kernel instance (occupancy query, cached)
     int res_ifft[4] = {0, 0, 0, 0};
+    int res_synth_long[4] = {0, 0, 0, 0};
+    int res_synth_short = 0;
     std::string err;
     char devname[256];
 };
@@ -266,6 +268,74 @@ extern "C" int nyq_imdct_chain_dev(nyq_ctx *ctx, int shift, const float *d_in, c
     return NYQ_OK;
 }
 
+// ---- frame sequences ----------------------------------------------------------------
+extern "C" size_t nyq_celt_synth_work_floats(size_t nstreams, size_t nframes, int channels) {
+    return nstreams * (size_t)(channels > 0 ? channels : 0) * (nframes + 1) * NYQ_HALF_OV;
+}
+
+template <int N2R>
+static int launch_synth_long(nyq_ctx *ctx, const SynthArgs &A) {
+    const size_t ngroups = (size_t)A.nstreams * A.channels * ((A.nframes + kGroup - 1) / kGroup);
+    const int res = resident_blocks(ctx, synth_long_kernel<N2R, Cfg>, &ctx->res_synth_long[Geo<N2R>::SHIFT]);
+    const size_t need = (ngroups + kWavesPerBlock - 1) / kWavesPerBlock;
+    const unsigned grid = (unsigned)(need < (size_t)res ? need : (size_t)res);
+    hipLaunchKernelGGL((synth_long_kernel<N2R, Cfg>), dim3(grid), dim3(kWave * kWavesPerBlock), 0, ctx->stream, A,
+                       ctx->d_trig, ctx->d_window);
+    NYQ_HIP(ctx, hipGetLastError());
+    return NYQ_OK;
+}
+
+extern "C" int nyq_celt_synth_dev(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned char *d_transient,
+                                  float *d_pcm, float *d_state, float *d_work, size_t nstreams, size_t nframes,
+                                  int channels) {
+    if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_celt_synth_dev: ctx is NULL");
+    if (LM < 0 || LM > 3) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_synth_dev: LM must be 0..3");
+    if (channels < 1 || channels > 255) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_synth_dev: channels must be 1..255");
+    if (nstreams == 0 || nframes == 0) return NYQ_OK;
+    if (!d_freq || !d_pcm || !d_work) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_synth_dev: NULL freq/pcm/work");
+    if (!aligned16(d_freq) || !aligned16(d_pcm) || !aligned16(d_work) || !aligned16(d_state))
+        return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_synth_dev: device pointers must be 16-byte aligned");
+    const size_t nsc = nstreams * (size_t)channels;
+    const size_t pitch = (nframes + 1) * NYQ_HALF_OV * sizeof(float), slot = NYQ_HALF_OV * sizeof(float);
+    // tails slot 0 of every (stream, channel) = the state handed in
+    if (d_state)
+        NYQ_HIP(ctx, hipMemcpy2DAsync(d_work, pitch, d_state, slot, slot, nsc, hipMemcpyDeviceToDevice, ctx->stream));
+    else
+        NYQ_HIP(ctx, hipMemset2DAsync(d_work, pitch, 0, slot, nsc, ctx->stream));
+    SynthArgs A;
+    A.freq = d_freq;
+    A.transient = LM > 0 ? d_transient : nullptr;   // LM 0: one block either way (B = 1)
+    A.pcm = d_pcm;
+    A.tails = d_work;
+    A.nstreams = (long)nstreams;
+    A.nframes = (long)nframes;
+    A.channels = channels;
+    int rc;
+    switch (LM) {
+    case 3: rc = launch_synth_long<32>(ctx, A); break;
+    case 2: rc = launch_synth_long<16>(ctx, A); break;
+    case 1: rc = launch_synth_long<8>(ctx, A); break;
+    default: rc = launch_synth_long<4>(ctx, A); break;
+    }
+    if (rc != NYQ_OK) return rc;
+    const size_t units = nsc * nframes;
+    if (A.transient) {
+        const int res = resident_blocks(ctx, synth_short_kernel<Cfg>, &ctx->res_synth_short);
+        const size_t need = (units + kWavesPerBlock - 1) / kWavesPerBlock;
+        const unsigned grid = (unsigned)(need < (size_t)res ? need : (size_t)res);
+        hipLaunchKernelGGL((synth_short_kernel<Cfg>), dim3(grid), dim3(kWave * kWavesPerBlock), 0, ctx->stream, A, 1 << LM,
+                           ctx->d_trig, ctx->d_window);
+        NYQ_HIP(ctx, hipGetLastError());
+    }
+    const size_t fb = units < (size_t)ctx->cus * 32 ? units : (size_t)ctx->cus * 32;
+    hipLaunchKernelGGL(synth_fixup_kernel, dim3((unsigned)fb), dim3(64), 0, ctx->stream, A, 120 << LM, ctx->d_window);
+    NYQ_HIP(ctx, hipGetLastError());
+    if (d_state)
+        NYQ_HIP(ctx, hipMemcpy2DAsync(d_state, slot, d_work + nframes * NYQ_HALF_OV, pitch, slot, nsc,
+                                      hipMemcpyDeviceToDevice, ctx->stream));
+    return NYQ_OK;
+}
+
 // ---- host-buffer variants ---------------------------------------------------------
 static int need_scratch(nyq_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->scratch_bytes) return NYQ_OK;
@@ -345,6 +415,32 @@ extern "C" int nyq_imdct_chain(nyq_ctx *ctx, int shift, const float *in, const f
     if (nchains * len == 0) return NYQ_OK;
     if (!in || !pcm) return fail(ctx, NYQ_ERR_INVALID, "nyq_imdct_chain: NULL in/pcm");
     return imdct_host(ctx, shift, in, carry0, nchains, pcm, tail_out, nchains, nchains, len, true);
+}
+
+extern "C" int nyq_celt_synth(nyq_ctx *ctx, int LM, const float *freq, const unsigned char *transient, float *pcm,
+                              float *state, size_t nstreams, size_t nframes, int channels) {
+    if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_celt_synth: ctx is NULL");
+    if (LM < 0 || LM > 3) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_synth: LM must be 0..3");
+    if (channels < 1 || channels > 255) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_synth: channels must be 1..255");
+    if (nstreams == 0 || nframes == 0) return NYQ_OK;
+    if (!freq || !pcm) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_synth: NULL freq/pcm");
+    NYQ_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t N = (size_t)120 << LM, nsc = nstreams * (size_t)channels;
+    const size_t n_x = round16f(nsc * nframes * N), n_w = round16f(nyq_celt_synth_work_floats(nstreams, nframes, channels)),
+                 n_s = round16f(nsc * NYQ_HALF_OV), n_t = round16f((nstreams * nframes + 3) / 4);
+    int rc = need_scratch(ctx, (2 * n_x + n_w + n_s + n_t) * sizeof(float));
+    if (rc != NYQ_OK) return rc;
+    float *d_x = ctx->d_scratch, *d_p = d_x + n_x, *d_w = d_p + n_x, *d_s = d_w + n_w;
+    unsigned char *d_t = reinterpret_cast<unsigned char *>(d_s + n_s);
+    NYQ_HIP(ctx, hipMemcpyAsync(d_x, freq, nsc * nframes * N * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (transient) NYQ_HIP(ctx, hipMemcpyAsync(d_t, transient, nstreams * nframes, hipMemcpyHostToDevice, ctx->stream));
+    if (state) NYQ_HIP(ctx, hipMemcpyAsync(d_s, state, nsc * NYQ_HALF_OV * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    rc = nyq_celt_synth_dev(ctx, LM, d_x, transient ? d_t : nullptr, d_p, state ? d_s : nullptr, d_w, nstreams, nframes, channels);
+    if (rc != NYQ_OK) return rc;
+    NYQ_HIP(ctx, hipMemcpyAsync(pcm, d_p, nsc * nframes * N * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (state) NYQ_HIP(ctx, hipMemcpyAsync(state, d_s, nsc * NYQ_HALF_OV * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    NYQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NYQ_OK;
 }
 
 // ---- the reference's operator names (cuda/mdct_cuda.hpp:79-103) --------------------

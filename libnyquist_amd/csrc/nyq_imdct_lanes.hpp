@@ -82,7 +82,8 @@ struct Geo {
     static constexpr int T2 = inv_mod(15, N2R);
     static constexpr int P2_ROWS = kWave / N2R;       // rows per pass-2 iteration (may exceed 4)
     static constexpr int P2_ITERS = P2_ROWS >= kGroup ? 1 : kGroup / P2_ROWS;
-    static constexpr int LDS_CPX = kGroup * S;        // per-wave LDS slice, in cpx
+    static constexpr int LDS_CPX = kGroup * S;        // per-wave LDS slice for the rows, in cpx
+    static constexpr int RING_FLOATS = (kGroup + 1) * 60;   // tail ring (chained rows only)
     // sine = 2*PI*0.125/N with the reference's float PI (mdct.c:292, mathops.h:83)
     static constexpr float SINE = (float)2 * 3.141592653f * (.125f) / (float)(4 * N4);
 };
@@ -161,25 +162,158 @@ NYQ_HD cpx postrot(cpx v, float c, float s, float sine) {
     return {-(yr - yi * sine), yi + yr * sine};
 }
 
+// ---- row sources ---------------------------------------------------------------
+// A "Rows" object tells the lane program where the 4 rows of the current group live.  It is a
+// handful of wave-uniform scalars with inline accessors, so addresses are recomputed from
+// g instead of being kept per row:
+//   static constexpr bool STRIDED   input elements are `stride()` floats apart (interleaved
+//                                   short blocks of a transient frame, celt_decoder_clean.c:292-300)
+//   static constexpr bool CHAINS    row g may take its carry from row g-1's raw tail
+//   bool valid(g); const float *in(g); int stride(); float *fin(g);
+//   float *tail(g)  (nullptr: do not store);  const float *carry(g)  (nullptr: zeros);
+//   bool chain(g)   (CHAINS only: carry of row g = raw tail of row g-1 of this group,
+//                    or for g == 0 the tail left in the ring by the previous group)
+// Independent rows of one [nrows][N2] batch (nyq_imdct_batch_dev):
+template <int N2R>
+struct IndepRows {
+    static constexpr bool STRIDED = false;
+    static constexpr bool CHAINS = false;
+    const float *in_;
+    const float *carry_;
+    float *fin_;
+    float *tail_;
+    long row0, nrows;
+    NYQ_HD bool valid(int g) const { return row0 + g < nrows; }
+    NYQ_HD const float *in(int g) const { return in_ + (row0 + g) * (long)Geo<N2R>::NIN; }
+    NYQ_HD int stride() const { return 1; }
+    NYQ_HD float *fin(int g) const { return fin_ + (row0 + g) * (long)Geo<N2R>::NIN; }
+    NYQ_HD float *tail(int g) const { return tail_ ? tail_ + (row0 + g) * kHalfOv : nullptr; }
+    NYQ_HD const float *carry(int g) const { return carry_ ? carry_ + (row0 + g) * kHalfOv : nullptr; }
+    NYQ_HD bool chain(int) const { return false; }
+};
+
+// ---- frame sequences (compute_inv_mdcts, celt_decoder_clean.c:264-312,622-656) ----------
+// `nstreams` independent decoders, each `nframes` frames of `channels` channels, all of frame
+// size N = 120 << LM.  Layouts:
+//   freq      [stream][frame][channel][N]   as the decoder leaves freq[] (channel c at freq + c*N);
+//                                           a transient frame holds B = 2^LM interleaved short
+//                                           blocks, coefficient k of block b at [b + B*k]
+//   transient [stream][frame]               non-zero = transient (shortBlocks) frame
+//   pcm       [stream][channel][frame*N..]  time-contiguous per channel (the out_syn history)
+//   tails     [stream*channels][nframes+1][60]   slot f+1 = raw tail after frame f; slot 0 = the
+//                                           overlap state before frame 0
+struct SynthArgs {
+    const float *freq;
+    const unsigned char *transient;
+    float *pcm;
+    float *tails;
+    long nstreams, nframes;
+    int channels;
+};
+
+// Four consecutive LONG frames of one (stream, channel): group gi = sc * ceil(nframes/4) + q.
+// Row g chains to row g-1 in registers/LDS when both are long; group-first rows and rows after a
+// transient frame are mirrored against zeros here and receive their carry in synth_fixup.
+template <int N2R>
+struct FrameLongRows {
+    static constexpr bool STRIDED = false;
+    static constexpr bool CHAINS = true;
+    static constexpr int N = Geo<N2R>::NIN;
+    const float *in0;   // frame f0, this channel
+    float *fin0;        // pcm of frame f0
+    float *tail0;       // tails slot f0+1
+    long in_step;       // channels * N
+    unsigned longmask;  // bit g+1 set <=> frame f0+g exists and is long (g = -1..4)
+    NYQ_HD FrameLongRows(const SynthArgs &A, long gi) {
+        const long gq = (A.nframes + kGroup - 1) / kGroup;
+        const long sc = gi / gq, q = gi - sc * gq;
+        const long s = sc / A.channels, c = sc - s * A.channels;
+        const long f0 = q * kGroup;
+        in_step = (long)A.channels * N;
+        in0 = A.freq + ((s * A.nframes + f0) * A.channels + c) * (long)N;
+        fin0 = A.pcm + (sc * A.nframes + f0) * (long)N;
+        tail0 = A.tails + (sc * (A.nframes + 1) + f0 + 1) * (long)kHalfOv;
+        longmask = 0;
+        const unsigned char *t = A.transient + s * A.nframes;
+#pragma unroll
+        for (int g = -1; g <= kGroup; g++) {
+            const long f = f0 + g;
+            if (f >= 0 && f < A.nframes && !(A.transient && t[f])) longmask |= 1u << (g + 1);
+        }
+    }
+    NYQ_HD bool is_long(int g) const { return (longmask >> (g + 1)) & 1u; }
+    NYQ_HD bool valid(int g) const { return is_long(g); }
+    NYQ_HD const float *in(int g) const { return in0 + g * in_step; }
+    NYQ_HD int stride() const { return 1; }
+    NYQ_HD float *fin(int g) const { return fin0 + g * (long)N; }
+    NYQ_HD bool chain(int g) const { return g > 0 && is_long(g - 1); }
+    NYQ_HD const float *carry(int) const { return nullptr; }
+    // the next frame's head is chained in-wave only if it is long and inside this group
+    NYQ_HD float *tail(int g) const {
+        return (g == kGroup - 1 || !is_long(g + 1)) ? tail0 + g * (long)kHalfOv : nullptr;
+    }
+};
+
+// The B short blocks of ONE transient frame of one (stream, channel), four at a time
+// (h = 0 .. ceil(B/4)-1, same wave, chained through the tail ring).  Always N2R = 4.
+struct FrameShortRows {
+    static constexpr bool STRIDED = true;
+    static constexpr bool CHAINS = true;
+    const float *in0;   // freq of this frame and channel
+    float *fin0;        // pcm of this frame
+    float *tail_slot;   // tails slot f+1
+    int B, b0;          // blocks in the frame, first block of this group
+    NYQ_HD FrameShortRows(const SynthArgs &A, long sc, long f, int B_, int h) {
+        const long s = sc / A.channels, c = sc - s * A.channels;
+        const long N = 120L * B_;
+        B = B_;
+        b0 = h * kGroup;
+        in0 = A.freq + ((s * A.nframes + f) * A.channels + c) * N;
+        fin0 = A.pcm + (sc * A.nframes + f) * N;
+        tail_slot = A.tails + (sc * (A.nframes + 1) + f + 1) * (long)kHalfOv;
+    }
+    NYQ_HD bool valid(int g) const { return b0 + g < B; }
+    NYQ_HD const float *in(int g) const { return in0 + (b0 + g); }
+    NYQ_HD int stride() const { return B; }
+    NYQ_HD float *fin(int g) const { return fin0 + 120L * (b0 + g); }
+    NYQ_HD bool chain(int g) const { return b0 + g > 0; }
+    NYQ_HD const float *carry(int) const { return nullptr; }
+    NYQ_HD float *tail(int g) const { return (b0 + g == B - 1) ? tail_slot : nullptr; }
+};
+
+// Is the head of frame f (its first 120 samples) already mirrored against the true carry?
+// Only long frames that chained in-wave are; every other head gets its carry in synth_fixup.
+NYQ_HD bool head_done_in_wave(const unsigned char *t, long f) {
+    return f > 0 && (f % kGroup) != 0 && !(t && (t[f] || t[f - 1]));
+}
+
 // ---- phase A -----------------------------------------------------------
 template <int N2R>
 struct StageRegs {
     f4 a[Geo<N2R>::SUBS], b[Geo<N2R>::SUBS];
 };
 
-// issue every global load of the group (rows row0 .. row0+3, clipped to nrows)
-template <int N2R, int NT = 0>
-NYQ_HD void stage_in_load(StageRegs<N2R> &R, int lane, const float *in, long row0, long nrows) {
+// issue every global load of the group
+template <int N2R, int NT, class Rows>
+NYQ_HD void stage_in_load(StageRegs<N2R> &R, int lane, const Rows &rows) {
     using Gm = Geo<N2R>;
 #pragma unroll
     for (int sub = 0; sub < Gm::SUBS; sub++) {
         int g, j;
         bool on;
         stage_slot<N2R>(sub, lane, g, j, on);
-        if (on && row0 + g < nrows) {
-            const float *row = in + (row0 + g) * (long)Gm::NIN;
-            R.a[sub] = ld_f4<NT>(row + 4 * j);
-            R.b[sub] = ld_f4<NT>(row + Gm::NIN - 4 - 4 * j);
+        if (on && rows.valid(g)) {
+            const float *row = rows.in(g);
+            if constexpr (Rows::STRIDED) {
+                const long st = rows.stride();
+                const float *pa = row + (long)(4 * j) * st;
+                const float *pb = row + (long)(Gm::NIN - 4 - 4 * j) * st;
+                R.a[sub] = f4{pa[0], pa[st], pa[2 * st], pa[3 * st]};
+                R.b[sub] = f4{pb[0], pb[st], pb[2 * st], pb[3 * st]};
+            } else {
+                R.a[sub] = ld_f4<NT>(row + 4 * j);
+                R.b[sub] = ld_f4<NT>(row + Gm::NIN - 4 - 4 * j);
+            }
         } else {
             R.a[sub] = f4{0, 0, 0, 0};
             R.b[sub] = f4{0, 0, 0, 0};
@@ -253,19 +387,47 @@ NYQ_HD void pass2_store(int g, int n2, cpx *lds, cpx (&v)[15]) {
 }
 
 // ---- phase D -----------------------------------------------------------------
-// carry: [nrows][60] or nullptr (zeros).  fin: [nrows][NIN].  tail: [nrows][60] or nullptr.
-template <int N2R, int NT = 0>
-NYQ_HD void stage_out(const LaneConst<N2R> &K, int lane, const cpx *lds, const float *carry,
-                      float *fin, float *tail, long row0, long nrows) {
+// Sub-iterations whose lanes can own a TDAC head (task j < 15): only the first 64-lane slice of
+// each row slot.
+template <int N2R>
+NYQ_HD constexpr bool sub_has_heads(int sub) {
+    return Geo<N2R>::SLOT <= kWave || (sub % Geo<N2R>::JSETS) == 0;
+}
+
+// The TDAC mirror of one head task (mdct.c:362-377): i = 59-4j-e, x1 = raw[59-i] = F[e],
+// x2 = carry[i] = C[3-e];  out[i] = w[119-i] x2 - w[i] x1,  out[119-i] = w[i] x2 + w[119-i] x1.
+template <int N2R>
+NYQ_HD void tdac_mix(const LaneConst<N2R> &K, f4 F, f4 C, f4 &hi, f4 &lo) {
+    hi.x = K.wlo[3] * C.w + K.whi[0] * F.x;   // out[60+4j+0]
+    hi.y = K.wlo[2] * C.z + K.whi[1] * F.y;
+    hi.z = K.wlo[1] * C.y + K.whi[2] * F.z;
+    hi.w = K.wlo[0] * C.x + K.whi[3] * F.w;
+    lo.w = K.whi[0] * C.w - K.wlo[3] * F.x;   // out[59-4j-0]
+    lo.z = K.whi[1] * C.z - K.wlo[2] * F.y;
+    lo.y = K.whi[2] * C.y - K.wlo[1] * F.z;
+    lo.x = K.whi[3] * C.x - K.wlo[0] * F.w;
+}
+
+// Heads kept in registers between the two halves of phase D when rows chain.
+template <int N2R>
+struct HeadRegs {
+    f4 F[Geo<N2R>::SUBS], Bk[Geo<N2R>::SUBS];
+};
+
+// Part 1: post-rotation, body stores; head lanes (j < 15) either finish at once (no chaining)
+// or park F/Bk and publish their raw tail in the wave's LDS tail ring: ring[g+1] = tail of row g
+// (ring[0] = tail left by the previous group).  ring: 5 x 60 floats.
+template <int N2R, int NT, class Rows>
+NYQ_HD void stage_out(const LaneConst<N2R> &K, int lane, const cpx *lds, float *ring, const Rows &rows,
+                      HeadRegs<N2R> &H) {
     using Gm = Geo<N2R>;
 #pragma unroll
     for (int sub = 0; sub < Gm::SUBS; sub++) {
         int g, j;
         bool on;
         stage_slot<N2R>(sub, lane, g, j, on);
-        if (!(on && row0 + g < nrows)) continue;
+        if (!(on && rows.valid(g))) continue;
         const int s = sub % Gm::JSETS;
-        const long r = row0 + g;
         const cpx *row = lds + g * Gm::S;
         cpx q0 = postrot(row[2 * j], K.tr[s][0], K.tr[s][5], Gm::SINE);
         cpx q1 = postrot(row[2 * j + 1], K.tr[s][1], K.tr[s][4], Gm::SINE);
@@ -274,27 +436,65 @@ NYQ_HD void stage_out(const LaneConst<N2R> &K, int lane, const cpx *lds, const f
         // raw[4j..4j+3] and raw[NIN-4-4j..NIN-1-4j]
         f4 F = {q0.re, q3.im, q1.re, q2.im};
         f4 Bk = {q2.re, q1.im, q3.re, q0.im};
-        float *orow = fin + r * (long)Gm::NIN;
-        if (j < 15) {
-            // TDAC mirror, mdct.c:362-377: i = 59-4j-e, x1 = raw[59-i] = F[e], x2 = carry[i]
-            f4 C = {0, 0, 0, 0};
-            if (carry) C = *reinterpret_cast<const f4 *>(carry + r * kHalfOv + 56 - 4 * j);
-            f4 hi, lo;
-            hi.x = K.wlo[3] * C.w + K.whi[0] * F.x;   // out[60+4j+0]
-            hi.y = K.wlo[2] * C.z + K.whi[1] * F.y;
-            hi.z = K.wlo[1] * C.y + K.whi[2] * F.z;
-            hi.w = K.wlo[0] * C.x + K.whi[3] * F.w;
-            lo.w = K.whi[0] * C.w - K.wlo[3] * F.x;   // out[59-4j-0]
-            lo.z = K.whi[1] * C.z - K.wlo[2] * F.y;
-            lo.y = K.whi[2] * C.y - K.wlo[1] * F.z;
-            lo.x = K.whi[3] * C.x - K.wlo[0] * F.w;
-            st_f4<NT>(orow + 60 + 4 * j, hi);
-            st_f4<NT>(orow + 56 - 4 * j, lo);
-            if (tail) st_f4<NT>(tail + r * kHalfOv + 56 - 4 * j, Bk);
+        float *orow = rows.fin(g);
+        if (sub_has_heads<N2R>(sub) && j < 15) {
+            if constexpr (Rows::CHAINS) {
+                H.F[sub] = F;
+                H.Bk[sub] = Bk;
+                *reinterpret_cast<f4 *>(ring + (g + 1) * kHalfOv + 56 - 4 * j) = Bk;
+            } else {
+                f4 C = {0, 0, 0, 0};
+                const float *cy = rows.carry(g);
+                if (cy) C = *reinterpret_cast<const f4 *>(cy + 56 - 4 * j);
+                f4 hi, lo;
+                tdac_mix<N2R>(K, F, C, hi, lo);
+                st_f4<NT>(orow + 60 + 4 * j, hi);
+                st_f4<NT>(orow + 56 - 4 * j, lo);
+                float *tl = rows.tail(g);
+                if (tl) st_f4<NT>(tl + 56 - 4 * j, Bk);
+            }
         } else {
             st_f4<NT>(orow + 60 + 4 * j, F);
             st_f4<NT>(orow + Gm::NIN + 56 - 4 * j, Bk);
         }
+    }
+}
+
+// Part 2 (CHAINS only; all lanes must have finished part 1): heads take their carry from the
+// tail ring (chained rows) or from memory / zeros, mix, store, and emit tails where asked.
+template <int N2R, int NT, class Rows>
+NYQ_HD void stage_out_heads(const LaneConst<N2R> &K, int lane, const float *ring, const Rows &rows,
+                            const HeadRegs<N2R> &H) {
+    using Gm = Geo<N2R>;
+#pragma unroll
+    for (int sub = 0; sub < Gm::SUBS; sub++) {
+        if (!sub_has_heads<N2R>(sub)) continue;
+        int g, j;
+        bool on;
+        stage_slot<N2R>(sub, lane, g, j, on);
+        if (!(on && rows.valid(g) && j < 15)) continue;
+        f4 C = {0, 0, 0, 0};
+        if (rows.chain(g)) {
+            C = *reinterpret_cast<const f4 *>(ring + g * kHalfOv + 56 - 4 * j);
+        } else {
+            const float *cy = rows.carry(g);
+            if (cy) C = *reinterpret_cast<const f4 *>(cy + 56 - 4 * j);
+        }
+        f4 hi, lo;
+        tdac_mix<N2R>(K, H.F[sub], C, hi, lo);
+        float *orow = rows.fin(g);
+        st_f4<NT>(orow + 60 + 4 * j, hi);
+        st_f4<NT>(orow + 56 - 4 * j, lo);
+        float *tl = rows.tail(g);
+        if (tl) st_f4<NT>(tl + 56 - 4 * j, H.Bk[sub]);
+    }
+}
+
+// Part 3 (CHAINS only, after part 2): hand the last row's tail to the next group of this wave.
+NYQ_HD void ring_rotate(int lane, float *ring) {
+    if (lane < 15) {
+        f4 v = *reinterpret_cast<const f4 *>(ring + kGroup * kHalfOv + 4 * lane);
+        *reinterpret_cast<f4 *>(ring + 4 * lane) = v;
     }
 }
 

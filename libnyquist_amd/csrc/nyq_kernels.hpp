@@ -66,16 +66,42 @@ __device__ __forceinline__ void fft_passes(int lane, cpx *lds) {
     NYQ_WAVE_SYNC();
 }
 
+// One group through phases A..D.  `R` holds the group's input registers (already loaded).
+template <int N2R, typename Cfg, class Rows>
+__device__ __forceinline__ void run_group(const LaneConst<N2R> &K, int lane, cpx *lds, float *ring,
+                                          const Rows &rows, StageRegs<N2R> &R) {
+    NYQ_WAVE_SYNC();
+    stage_in_store<N2R>(R, K, lane, lds);
+    NYQ_WAVE_SYNC();
+    fft_passes<N2R>(lane, lds);
+    HeadRegs<N2R> H;
+    stage_out<N2R, Cfg::NT_ST>(K, lane, lds, ring, rows, H);
+    if constexpr (Rows::CHAINS) {
+        NYQ_WAVE_SYNC();
+        stage_out_heads<N2R, Cfg::NT_ST>(K, lane, ring, rows, H);
+    }
+}
+
+// per-wave LDS carve: rows slice, then (chained kernels only) the 5 x 60-float tail ring
+template <int N2R, int WPB, bool RING>
+struct WaveLds {
+    static constexpr int ROW_FLOATS = 2 * Geo<N2R>::LDS_CPX;
+    static constexpr int PER_WAVE = ROW_FLOATS + (RING ? Geo<N2R>::RING_FLOATS + 4 : 0);   // keep 16-B multiples
+    static constexpr int TOTAL = WPB * PER_WAVE;
+    static_assert(PER_WAVE % 4 == 0, "LDS slices must stay 16-byte aligned");
+};
+
 template <int N2R, typename Cfg>
 __global__ __launch_bounds__(kWave *Cfg::WPB) void imdct_rows_kernel(
     const float *__restrict__ in, const float *__restrict__ carry, float *__restrict__ fin,
     float *__restrict__ tail, long nrows, const float *__restrict__ trig,
     const float *__restrict__ window) {
     using Gm = Geo<N2R>;
-    __shared__ cpx lds_all[Cfg::WPB * Gm::LDS_CPX];
+    using WL = WaveLds<N2R, Cfg::WPB, false>;
+    __shared__ __attribute__((aligned(16))) float smem[WL::TOTAL];
     const int lane = threadIdx.x & (kWave - 1);
     const int wv = threadIdx.x >> 6;
-    cpx *lds = lds_all + wv * Gm::LDS_CPX;
+    cpx *lds = reinterpret_cast<cpx *>(smem + wv * WL::PER_WAVE);
 
     LaneConst<N2R> K;
     lane_init<N2R>(K, lane, trig, window);
@@ -91,21 +117,106 @@ __global__ __launch_bounds__(kWave *Cfg::WPB) void imdct_rows_kernel(
     StageRegs<N2R> R;
     if constexpr (Cfg::PREFETCH) {
         // Software pipeline over this wave's groups: the float4 loads of group g+1 are issued
-        // as soon as group g's registers have been pre-rotated into LDS, and stay in flight
-        // under both FFT passes and the stores of group g.
-        if (gi < ngroups) stage_in_load<N2R, Cfg::NT_LD>(R, lane, in, gi * kGroup, nrows);
+        // as soon as group g's registers have been pre-rotated into LDS.  (Measured: no gain.)
+        if (gi < ngroups) {
+            IndepRows<N2R> rows{in, carry, fin, tail, gi * kGroup, nrows};
+            stage_in_load<N2R, Cfg::NT_LD>(R, lane, rows);
+        }
     }
     for (; gi < ngroups; gi += nwaves) {
-        const long row0 = gi * kGroup;
-        if constexpr (!Cfg::PREFETCH) stage_in_load<N2R, Cfg::NT_LD>(R, lane, in, row0, nrows);
-        NYQ_WAVE_SYNC();
-        stage_in_store<N2R>(R, K, lane, lds);
-        if constexpr (Cfg::PREFETCH) {
-            if (gi + nwaves < ngroups) stage_in_load<N2R, Cfg::NT_LD>(R, lane, in, (gi + nwaves) * kGroup, nrows);
+        IndepRows<N2R> rows{in, carry, fin, tail, gi * kGroup, nrows};
+        if constexpr (!Cfg::PREFETCH) {
+            stage_in_load<N2R, Cfg::NT_LD>(R, lane, rows);
+            run_group<N2R, Cfg>(K, lane, lds, nullptr, rows, R);
+        } else {
+            NYQ_WAVE_SYNC();
+            stage_in_store<N2R>(R, K, lane, lds);
+            if (gi + nwaves < ngroups) {
+                IndepRows<N2R> nxt{in, carry, fin, tail, (gi + nwaves) * kGroup, nrows};
+                stage_in_load<N2R, Cfg::NT_LD>(R, lane, nxt);
+            }
+            NYQ_WAVE_SYNC();
+            fft_passes<N2R>(lane, lds);
+            HeadRegs<N2R> H;
+            stage_out<N2R, Cfg::NT_ST>(K, lane, lds, nullptr, rows, H);
         }
-        NYQ_WAVE_SYNC();
-        fft_passes<N2R>(lane, lds);
-        stage_out<N2R, Cfg::NT_ST>(K, lane, lds, carry, fin, tail, row0, nrows);
+    }
+}
+
+// ---- frame sequences: the compute_inv_mdcts replacement (celt_decoder_clean.c:264-312) ----
+// Long frames: one group = four consecutive frames of one (stream, channel), chained in-wave.
+template <int N2R, typename Cfg>
+__global__ __launch_bounds__(kWave *Cfg::WPB) void synth_long_kernel(SynthArgs A, const float *__restrict__ trig,
+                                                                      const float *__restrict__ window) {
+    using WL = WaveLds<N2R, Cfg::WPB, true>;
+    __shared__ __attribute__((aligned(16))) float smem[WL::TOTAL];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wv = threadIdx.x >> 6;
+    cpx *lds = reinterpret_cast<cpx *>(smem + wv * WL::PER_WAVE);
+    float *ring = smem + wv * WL::PER_WAVE + WL::ROW_FLOATS;
+
+    LaneConst<N2R> K;
+    lane_init<N2R>(K, lane, trig, window);
+
+    const long ngroups = A.nstreams * A.channels * ((A.nframes + kGroup - 1) / kGroup);
+    const long nwaves = (long)gridDim.x * Cfg::WPB;
+    for (long gi = (long)blockIdx.x * Cfg::WPB + wv; gi < ngroups; gi += nwaves) {
+        FrameLongRows<N2R> rows(A, gi);
+        if ((rows.longmask & 0x1Eu) == 0) continue;   // four transient frames: nothing to do here
+        StageRegs<N2R> R;
+        stage_in_load<N2R, Cfg::NT_LD>(R, lane, rows);
+        run_group<N2R, Cfg>(K, lane, lds, ring, rows, R);
+    }
+}
+
+// Transient frames: a wave takes one (stream, channel, frame) and walks its B short blocks four
+// at a time; blocks chain through the tail ring, the last block publishes the frame's tail.
+template <typename Cfg>
+__global__ __launch_bounds__(kWave *Cfg::WPB) void synth_short_kernel(SynthArgs A, int B,
+                                                                       const float *__restrict__ trig,
+                                                                       const float *__restrict__ window) {
+    using WL = WaveLds<4, Cfg::WPB, true>;
+    __shared__ __attribute__((aligned(16))) float smem[WL::TOTAL];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wv = threadIdx.x >> 6;
+    cpx *lds = reinterpret_cast<cpx *>(smem + wv * WL::PER_WAVE);
+    float *ring = smem + wv * WL::PER_WAVE + WL::ROW_FLOATS;
+
+    LaneConst<4> K;
+    lane_init<4>(K, lane, trig, window);
+
+    const long units = A.nstreams * A.channels * A.nframes;
+    const long nwaves = (long)gridDim.x * Cfg::WPB;
+    for (long u = (long)blockIdx.x * Cfg::WPB + wv; u < units; u += nwaves) {
+        const long sc = u / A.nframes, f = u - sc * A.nframes;
+        const long s = sc / A.channels;
+        if (!A.transient[s * A.nframes + f]) continue;
+        for (int h = 0; h * kGroup < B; h++) {
+            FrameShortRows rows(A, sc, f, B, h);
+            StageRegs<4> R;
+            stage_in_load<4, 0>(R, lane, rows);
+            run_group<4, Cfg>(K, lane, lds, ring, rows, R);
+            NYQ_WAVE_SYNC();
+            ring_rotate(lane, ring);
+        }
+    }
+}
+
+// Heads that were mirrored against zeros receive their carry: slot f of the tails buffer holds
+// the raw tail that precedes frame f (slot 0: the state handed in).  mdct.c:371-372 is linear in
+// the carry, so  out[i] += w[119-i] c[i];  out[119-i] += w[i] c[i]  completes the mirror exactly.
+__global__ __launch_bounds__(64) void synth_fixup_kernel(SynthArgs A, int N, const float *__restrict__ window) {
+    const int i = threadIdx.x;
+    if (i >= kHalfOv) return;
+    const long units = A.nstreams * A.channels * A.nframes;
+    for (long u = blockIdx.x; u < units; u += gridDim.x) {
+        const long sc = u / A.nframes, f = u - sc * A.nframes;
+        const long s = sc / A.channels;
+        if (head_done_in_wave(A.transient ? A.transient + s * A.nframes : nullptr, f)) continue;
+        const float cv = A.tails[(sc * (A.nframes + 1) + f) * (long)kHalfOv + i];
+        float *o = A.pcm + (sc * A.nframes + f) * (long)N;
+        o[i] += window[kOverlap - 1 - i] * cv;
+        o[kOverlap - 1 - i] += window[i] * cv;
     }
 }
 

@@ -15,6 +15,8 @@ Writes DATA only (inputs + expected outputs):
   ref_ifft_shared.npz                 opus_ifft through the mode's shared plans, all 4 sizes
   ref_chain.npz                       consecutive blocks of one channel, long/short mixed,
                                       emulating the decode_mem shift of celt_decoder_clean.c:625,641
+  ref_synth.npz                       compute_inv_mdcts over 2 stereo streams x 11 frames with
+                                      transient frames, through the reference's B1_C2 fast paths
 Everything is seeded; re-running reproduces the files bit for bit.
 """
 import os
@@ -135,6 +137,27 @@ def main():
     np.savez(f"{OUT}/ref_chain.npz", kinds=np.array(list(kinds)), freq=freq,
              carry_in=carry_in, pcm=mem[: 960 * len(kinds)].copy(),
              tail=mem[960 * len(kinds):].copy())
+    # compute_inv_mdcts over frame sequences (celt_decoder_clean.c:264-312): 2 stereo streams,
+    # 11 frames, LM = 3, long frames through B1_C2 stride 1, transient frames through 8 x B1_C2
+    # stride 8 -- exactly the reference's two fast paths -- into one decode_mem-like buffer.
+    ns, nf, ch = 2, 11, 2
+    freq = decoder_like(rng, ns * nf * ch, 960).reshape(ns, nf, ch, 960)
+    transient = np.array([[0, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0],
+                          [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]], np.uint8)
+    state = (rng.standard_normal((ns * ch, HALF_OV)) * 30).astype(np.float32)
+    mem = np.zeros((ns, ch, nf * 960 + HALF_OV), np.float32)
+    mem[:, :, :HALF_OV] = state.reshape(ns, ch, HALF_OV)
+    for s_ in range(ns):
+        for f in range(nf):
+            X = np.ascontiguousarray(freq[s_, f])
+            if transient[s_, f]:
+                for b in range(8):
+                    ref.imdct_c2(X[0, b:], X[1, b:], mem[s_, 0, f * 960 + 120 * b: f * 960 + 120 * b + 180],
+                                 mem[s_, 1, f * 960 + 120 * b: f * 960 + 120 * b + 180], 3, 8)
+            else:
+                ref.imdct_c2(X[0], X[1], mem[s_, 0, f * 960: f * 960 + 1020], mem[s_, 1, f * 960: f * 960 + 1020], 0, 1)
+    np.savez(f"{OUT}/ref_synth.npz", freq=freq, transient=transient, state_in=state,
+             pcm=mem[:, :, : nf * 960].copy(), state_out=mem[:, :, nf * 960:].reshape(ns * ch, HALF_OV).copy())
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"wrote {len(os.listdir(OUT))} files, {total/1024:.0f} KiB -> {OUT}")
 

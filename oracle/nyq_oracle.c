@@ -511,6 +511,53 @@ int nyq_oracle_imdct_chain(int shift, const float *in, const float *carry0,
     return 0;
 }
 
+/* compute_inv_mdcts (celt_decoder_clean.c:264-312) over whole frame sequences, with the
+ * decode_mem carry of celt_decoder_clean.c:622-656 emulated by one contiguous per-channel
+ * buffer (frame f's out_syn = mem + f*N; the 60 floats past a block are left in place and are
+ * the next block's carry).  All frames have size N = 120 << LM.
+ *   freq      [nstreams][nframes][channels][N]
+ *   transient [nstreams][nframes] (NULL = none): B = 2^LM interleaved short blocks, shift 3,
+ *             stride B (:292-300, :301-311); otherwise one block, shift 3-LM, stride 1
+ *   pcm       [nstreams][channels][nframes*N]
+ *   state     [nstreams*channels][60] in/out (NULL = zeros in, discarded out)
+ * The B==1&&C==2 / B==8&&C==2 fast paths of the reference are clt_mdct_backward per channel
+ * (mdct.c:258-265), so one generic loop restates all three branches. */
+int nyq_oracle_celt_synth(int LM, const float *freq, const unsigned char *transient, float *pcm,
+                          float *state, long nstreams, long nframes, int channels, int nthreads)
+{
+    long sc;
+    const long N = 120L << LM;
+    const int B = 1 << LM;
+    if (LM < 0 || LM > 3 || channels < 1) return -1;
+    nq_need_init();
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
+#endif
+    for (sc = 0; sc < nstreams * channels; sc++) {
+        const long s = sc / channels, c = sc % channels;
+        long f;
+        int b;
+        float *mem = (float *)malloc(sizeof(float) * (size_t)(nframes * N + NQ_HALF_OV));
+        if (!mem) continue;
+        if (state) memcpy(mem, state + sc * NQ_HALF_OV, sizeof(float) * NQ_HALF_OV);
+        else memset(mem, 0, sizeof(float) * NQ_HALF_OV);
+        for (f = 0; f < nframes; f++) {
+            const float *X = freq + ((s * nframes + f) * channels + c) * N;
+            float *out = mem + f * N;
+            if (transient && transient[s * nframes + f]) {
+                for (b = 0; b < B; b++) nyq_oracle_imdct(X + b, out + 120 * b, 3, B);
+            } else {
+                nyq_oracle_imdct(X, out, 3 - LM, 1);
+            }
+        }
+        memcpy(pcm + sc * nframes * N, mem, sizeof(float) * (size_t)(nframes * N));
+        if (state) memcpy(state + sc * NQ_HALF_OV, mem + nframes * N, sizeof(float) * NQ_HALF_OV);
+        free(mem);
+    }
+    return 0;
+}
+
 int nyq_oracle_max_threads(void)
 {
 #ifdef _OPENMP

@@ -53,6 +53,8 @@ class Oracle:
         L.nyq_oracle_imdct.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int]
         L.nyq_oracle_imdct_batch.argtypes = [C.c_int, _f32p, C.c_void_p, _f32p, C.c_void_p, C.c_long, C.c_int]
         L.nyq_oracle_imdct_chain.argtypes = [C.c_int, _f32p, C.c_void_p, _f32p, C.c_void_p, C.c_long]
+        L.nyq_oracle_celt_synth.argtypes = [C.c_int, _f32p, C.c_void_p, _f32p, C.c_void_p, C.c_long, C.c_long,
+                                            C.c_int, C.c_int]
         if tables is None:
             L.nyq_oracle_init_default()
         else:
@@ -129,6 +131,20 @@ class Oracle:
         rc = self.lib.nyq_oracle_imdct_chain(shift, x.reshape(-1), _opt(carry0), pcm.reshape(-1), _opt(tail), b)
         assert rc == 0
         return pcm, tail
+
+
+    def celt_synth(self, lm, freq, transient=None, state=None, nthreads=1):
+        """freq [ns][nf][ch][120<<lm] -> (pcm [ns][ch][nf*N], state_out or None); see nyq_oracle_celt_synth."""
+        n = 120 << lm
+        freq = np.ascontiguousarray(freq, np.float32)
+        ns, nf, ch, nn = freq.shape
+        assert nn == n
+        tr = None if transient is None else np.ascontiguousarray(transient, np.uint8).reshape(ns, nf)
+        st = None if state is None else np.ascontiguousarray(state, np.float32).reshape(ns * ch, HALF_OV).copy()
+        pcm = np.empty((ns, ch, nf * n), np.float32)
+        rc = self.lib.nyq_oracle_celt_synth(lm, freq.reshape(-1), _opt(tr), pcm.reshape(-1), _opt(st), ns, nf, ch, nthreads)
+        assert rc == 0
+        return pcm, st
 
 
 def ref_available():

@@ -1,10 +1,12 @@
-// tests/emu/lane_emu.cpp -- CPU replay of the HIP kernel's lane program.  TEST ONLY.
+// tests/emu/lane_emu.cpp -- CPU replay of the HIP kernels' lane program.  TEST ONLY.
 //
 // Includes the same __host__ __device__ headers the gfx950 kernels are built from
 // (libnyquist_amd/csrc/nyq_imdct_lanes.hpp) and executes them lane by lane, phase by
-// phase, with a plain array standing in for the wave's LDS slice.  It exists so the
-// index maps (prime-factor slots, stage tasks, TDAC placement) can be checked against
-// the oracle in the CPU-only test tier; it is not reachable from the product API.
+// phase, with plain arrays standing in for the wave's LDS slice and tail ring.  The phase
+// order mirrors nyq_kernels.hpp (run_group, synth_long_kernel, synth_short_kernel,
+// synth_fixup_kernel).  It exists so the index maps (prime-factor slots, stage tasks, TDAC
+// placement, in-wave chaining) can be checked against the oracle in the CPU-only test tier;
+// it is not reachable from the product API.
 #include <cstring>
 #include <vector>
 
@@ -13,16 +15,16 @@
 using namespace nyq;
 
 template <int N2R>
-static void emu_imdct(const float *in, const float *carry, float *fin, float *tail, long nrows,
-                      const float *trig, const float *window) {
+struct WaveEmu {
     using Gm = Geo<N2R>;
-    std::vector<cpx> lds(Gm::LDS_CPX, cpx{0, 0});
-    std::vector<LaneConst<N2R>> K(kWave);
-    for (int l = 0; l < kWave; l++) lane_init<N2R>(K[l], l, trig, window);
-    std::vector<StageRegs<N2R>> R(kWave);
-    for (long row0 = 0; row0 < nrows; row0 += kGroup) {
-        for (int l = 0; l < kWave; l++) stage_in_load<N2R>(R[l], l, in, row0, nrows);
-        for (int l = 0; l < kWave; l++) stage_in_store<N2R>(R[l], K[l], l, lds.data());
+    std::vector<cpx> lds;
+    std::vector<float> ring;
+    std::vector<LaneConst<N2R>> K;
+    WaveEmu(const float *trig, const float *window)
+        : lds(Gm::LDS_CPX, cpx{0, 0}), ring(Gm::RING_FLOATS + 4, 0.f), K(kWave) {
+        for (int l = 0; l < kWave; l++) lane_init<N2R>(K[l], l, trig, window);
+    }
+    void fft() {
         for (int l = 0; l < kWave; l++) pass1<N2R>(l, lds.data());
         for (int it = 0; it < Gm::P2_ITERS; it++) {
             cpx v[kWave][15];
@@ -32,26 +34,83 @@ static void emu_imdct(const float *in, const float *carry, float *fin, float *ta
             for (int l = 0; l < kWave; l++)
                 if (ok[l]) pass2_store<N2R>(g[l], n2[l], lds.data(), v[l]);
         }
-        for (int l = 0; l < kWave; l++) stage_out<N2R>(K[l], l, lds.data(), carry, fin, tail, row0, nrows);
+    }
+    // nyq_kernels.hpp: stage_in_load + run_group
+    template <class Rows>
+    void group(const Rows &rows) {
+        std::vector<StageRegs<N2R>> R(kWave);
+        std::vector<HeadRegs<N2R>> H(kWave);
+        for (int l = 0; l < kWave; l++) stage_in_load<N2R, 0>(R[l], l, rows);
+        for (int l = 0; l < kWave; l++) stage_in_store<N2R>(R[l], K[l], l, lds.data());
+        fft();
+        for (int l = 0; l < kWave; l++) stage_out<N2R, 0>(K[l], l, lds.data(), ring.data(), rows, H[l]);
+        if (Rows::CHAINS)
+            for (int l = 0; l < kWave; l++) stage_out_heads<N2R, 0>(K[l], l, ring.data(), rows, H[l]);
+    }
+    void rotate() {
+        for (int l = 0; l < kWave; l++) ring_rotate(l, ring.data());
+    }
+};
+
+template <int N2R>
+static void emu_imdct(const float *in, const float *carry, float *fin, float *tail, long nrows,
+                      const float *trig, const float *window) {
+    WaveEmu<N2R> W(trig, window);
+    for (long row0 = 0; row0 < nrows; row0 += kGroup) {
+        IndepRows<N2R> rows{in, carry, fin, tail, row0, nrows};
+        W.group(rows);
     }
 }
 
 template <int N2R>
 static void emu_ifft(const float *in, float *out, long nrows) {
     using Gm = Geo<N2R>;
-    std::vector<cpx> lds(Gm::LDS_CPX, cpx{0, 0});
+    std::vector<float> dummy_t(481, 1.f), dummy_w(120, 1.f);
+    WaveEmu<N2R> W(dummy_t.data(), dummy_w.data());
     for (long row0 = 0; row0 < nrows; row0 += kGroup) {
-        for (int l = 0; l < kWave; l++) ifft_stage_in<N2R>(l, in, lds.data(), row0, nrows);
-        for (int l = 0; l < kWave; l++) pass1<N2R>(l, lds.data());
-        for (int it = 0; it < Gm::P2_ITERS; it++) {
-            cpx v[kWave][15];
-            int g[kWave], n2[kWave];
-            bool ok[kWave];
-            for (int l = 0; l < kWave; l++) ok[l] = pass2_load<N2R>(l, it, lds.data(), v[l], g[l], n2[l]);
-            for (int l = 0; l < kWave; l++)
-                if (ok[l]) pass2_store<N2R>(g[l], n2[l], lds.data(), v[l]);
+        for (int l = 0; l < kWave; l++) ifft_stage_in<N2R>(l, in, W.lds.data(), row0, nrows);
+        W.fft();
+        for (int l = 0; l < kWave; l++) ifft_stage_out<N2R>(l, W.lds.data(), out, row0, nrows);
+    }
+    (void)sizeof(Gm);
+}
+
+template <int N2R>
+static void emu_synth_long(const SynthArgs &A, const float *trig, const float *window) {
+    WaveEmu<N2R> W(trig, window);
+    const long ngroups = A.nstreams * A.channels * ((A.nframes + kGroup - 1) / kGroup);
+    for (long gi = 0; gi < ngroups; gi++) {
+        FrameLongRows<N2R> rows(A, gi);
+        if ((rows.longmask & 0x1Eu) == 0) continue;
+        W.group(rows);
+    }
+}
+
+static void emu_synth_short(const SynthArgs &A, int B, const float *trig, const float *window) {
+    WaveEmu<4> W(trig, window);
+    const long units = A.nstreams * A.channels * A.nframes;
+    for (long u = 0; u < units; u++) {
+        const long sc = u / A.nframes, f = u - sc * A.nframes, s = sc / A.channels;
+        if (!A.transient[s * A.nframes + f]) continue;
+        for (int h = 0; h * kGroup < B; h++) {
+            FrameShortRows rows(A, sc, f, B, h);
+            W.group(rows);
+            W.rotate();
         }
-        for (int l = 0; l < kWave; l++) ifft_stage_out<N2R>(l, lds.data(), out, row0, nrows);
+    }
+}
+
+static void emu_synth_fixup(const SynthArgs &A, int N, const float *window) {
+    const long units = A.nstreams * A.channels * A.nframes;
+    for (long u = 0; u < units; u++) {
+        const long sc = u / A.nframes, f = u - sc * A.nframes, s = sc / A.channels;
+        if (head_done_in_wave(A.transient ? A.transient + s * A.nframes : nullptr, f)) continue;
+        for (int i = 0; i < kHalfOv; i++) {
+            const float cv = A.tails[(sc * (A.nframes + 1) + f) * (long)kHalfOv + i];
+            float *o = A.pcm + (sc * A.nframes + f) * (long)N;
+            o[i] += window[kOverlap - 1 - i] * cv;
+            o[kOverlap - 1 - i] += window[i] * cv;
+        }
     }
 }
 
@@ -74,6 +133,31 @@ extern "C" int emu_ifft_batch(int nfft, const float *in, float *out, long nrows)
     case 60: emu_ifft<4>(in, out, nrows); return 0;
     }
     return -1;
+}
+
+// mirrors nyq_celt_synth_dev (nyq_imdct.hip): slot-0 seeding, long, short, fix-up, state out
+extern "C" int emu_celt_synth(int LM, const float *freq, const unsigned char *transient, float *pcm, float *state,
+                              long nstreams, long nframes, int channels, const float *trig, const float *window) {
+    if (LM < 0 || LM > 3) return -1;
+    const long nsc = nstreams * channels;
+    std::vector<float> tails((size_t)nsc * (nframes + 1) * kHalfOv, 0.f);
+    for (long sc = 0; sc < nsc; sc++)
+        for (int i = 0; i < kHalfOv; i++)
+            tails[(size_t)sc * (nframes + 1) * kHalfOv + i] = state ? state[sc * kHalfOv + i] : 0.f;
+    SynthArgs A{freq, LM > 0 ? transient : nullptr, pcm, tails.data(), nstreams, nframes, channels};
+    switch (LM) {
+    case 3: emu_synth_long<32>(A, trig, window); break;
+    case 2: emu_synth_long<16>(A, trig, window); break;
+    case 1: emu_synth_long<8>(A, trig, window); break;
+    default: emu_synth_long<4>(A, trig, window); break;
+    }
+    if (A.transient) emu_synth_short(A, 1 << LM, trig, window);
+    emu_synth_fixup(A, 120 << LM, window);
+    if (state)
+        for (long sc = 0; sc < nsc; sc++)
+            for (int i = 0; i < kHalfOv; i++)
+                state[sc * kHalfOv + i] = tails[((size_t)sc * (nframes + 1) + nframes) * kHalfOv + i];
+    return 0;
 }
 
 // single in-register DFT, for unit-testing nyq_fft_core.hpp

@@ -12,7 +12,7 @@ from conftest import ROOT
 def _declared_functions():
     text = open(os.path.join(ROOT, "include", "nyq_imdct.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = re.findall(r"^\s*(?:const\s+)?(?:int|void|char)\s*\*?\s*(\w+)\s*\(", text, flags=re.M)
+    names = re.findall(r"^\s*(?:const\s+)?(?:int|void|char|size_t)\s*\*?\s*(\w+)\s*\(", text, flags=re.M)
     return sorted(set(names))
 
 

@@ -253,3 +253,56 @@ def test_chain_dev_matches_host_chain(ctx, oracle):
     wp, wt = oracle.imdct_chain(0, x[-length:], None)
     assert rel_rms(d_pcm[-length:].cpu().numpy(), wp) <= 1e-6
     assert rel_rms(d_tail[-1].cpu().numpy(), wt) <= 1e-6
+
+
+# ---- frame sequences: the compute_inv_mdcts replacement ---------------------------------------
+def test_frame_synth_vs_reference_fixture(ctx_ref_tables):
+    z = np.load(os.path.join(GOLDEN, "ref_synth.npz"))
+    pcm, st = ctx_ref_tables.celt_synth(3, z["freq"], z["transient"], z["state_in"], channels=2)
+    assert rel_rms(pcm, z["pcm"]) <= TOL and rel_rms(pcm, z["pcm"]) <= 1e-6
+    assert rel_rms(st, z["state_out"]) <= 1e-6
+    c = np.load(os.path.join(GOLDEN, "ref_chain.npz"))
+    tr = np.array([[k == "S" for k in "".join(c["kinds"])]], np.uint8)
+    pcm, st = ctx_ref_tables.celt_synth(3, c["freq"][None, :, None, :], tr, c["carry_in"][None, :], channels=1)
+    assert rel_rms(pcm.reshape(-1), c["pcm"]) <= 1e-6 and rel_rms(st[0], c["tail"]) <= 1e-6
+
+
+@pytest.mark.parametrize("lm", [3, 2, 1, 0])
+def test_frame_synth_vs_oracle(ctx, oracle, lm):
+    ctx.set_tables(*oracle.tables()[:2])
+    rng = np.random.default_rng(40 + lm)
+    n = 120 << lm
+    for ns, nf, ch, ptr in ((1, 1, 1, 0.0), (3, 50, 2, 0.1), (2, 33, 8, 0.5), (5, 4, 2, 1.0), (64, 21, 2, 0.03), (2, 7, 1, 0.0)):
+        freq = (rng.standard_normal((ns, nf, ch, n)) * 30).astype(np.float32)
+        tr = (rng.uniform(size=(ns, nf)) < ptr).astype(np.uint8)
+        st = (rng.standard_normal((ns * ch, 60)) * 30).astype(np.float32)
+        pcm, so = ctx.celt_synth(lm, freq, tr, st, channels=ch)
+        wp, ws = oracle.celt_synth(lm, freq, tr, st, nthreads=4)
+        assert rel_rms(pcm, wp) <= 1e-6, (ns, nf, ch, ptr)
+        assert rel_rms(so, ws) <= 1e-6
+        pcm0, none = ctx.celt_synth(lm, freq, None, None, channels=ch)      # no transients, zero state
+        wp0, _ = oracle.celt_synth(lm, freq, None, None, nthreads=4)
+        assert none is None and rel_rms(pcm0, wp0) <= 1e-6
+
+
+def test_frame_synth_matches_sb_reverie_mix_at_scale(ctx, oracle):
+    """config C4 shape: many stereo streams with the measured sb-reverie.opus frame mix (2.8 %
+    transient), device resident; checked on sampled streams + against the chain operator."""
+    import torch
+    dev = torch.device("cuda", 0)
+    ctx.set_tables(*oracle.tables()[:2])
+    ns, nf, ch = 256, 200, 2
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    freq = torch.randn((ns, nf, ch, 960), generator=g, device=dev) * 30
+    tr = (torch.rand((ns, nf), generator=g, device=dev) < 0.028).to(torch.uint8)
+    pcm = torch.empty((ns, ch, nf * 960), device=dev)
+    state = torch.zeros((ns * ch, 60), device=dev)
+    work = torch.empty(ctx.celt_synth_work_floats(ns, nf, ch), device=dev)
+    torch.cuda.synchronize(dev)
+    ctx.celt_synth_dev(3, freq.data_ptr(), tr.data_ptr(), pcm.data_ptr(), state.data_ptr(), work.data_ptr(), ns, nf, ch)
+    ctx.synchronize()
+    for s in (0, 17, 255):
+        wp, ws = oracle.celt_synth(3, freq[s:s + 1].cpu().numpy(), tr[s:s + 1].cpu().numpy(), np.zeros((ch, 60), np.float32), nthreads=2)
+        assert rel_rms(pcm[s].cpu().numpy(), wp[0]) <= 1e-6
+        assert rel_rms(state[s * ch:(s + 1) * ch].cpu().numpy(), ws) <= 1e-6

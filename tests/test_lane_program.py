@@ -75,3 +75,41 @@ def test_lane_program_bundled_ifft_vectors(emu, nfft):
     for r in range(6):
         assert np.sqrt(np.mean((ys[r].astype(np.float64) - want) ** 2)) <= 1e-5   # north_star tolerance
         assert np.sqrt(np.mean((ys[r].astype(np.float64) - want) ** 2)) <= 2e-7
+
+
+@pytest.mark.parametrize("lm", [3, 2, 1, 0])
+def test_frame_synth_lane_program_vs_oracle(emu, oracle, lm):
+    """In-wave chaining of long frames, tail-ring chaining of short blocks, fix-up of the rest."""
+    emu.emu_celt_synth.argtypes = [C.c_int, _f32p, C.c_void_p, _f32p, C.c_void_p, C.c_long, C.c_long, C.c_int,
+                                   _f32p, _f32p]
+    trig, win, _ = oracle.tables()
+    rng = np.random.default_rng(lm)
+    n = 120 << lm
+    for ns, nf, ch, ptr in ((1, 1, 1, 0.0), (2, 9, 2, 0.3), (1, 13, 3, 0.6), (3, 4, 2, 1.0), (2, 7, 1, 0.0)):
+        freq = (rng.standard_normal((ns, nf, ch, n)) * 30).astype(np.float32)
+        tr = (rng.uniform(size=(ns, nf)) < ptr).astype(np.uint8)
+        st = (rng.standard_normal((ns * ch, 60)) * 30).astype(np.float32)
+        for use_state in (True, False):
+            pcm = np.zeros((ns, ch, nf * n), np.float32)
+            st2 = st.copy()
+            rc = emu.emu_celt_synth(lm, freq.reshape(-1), tr.ctypes.data_as(C.c_void_p), pcm.reshape(-1),
+                                    st2.ctypes.data_as(C.c_void_p) if use_state else None, ns, nf, ch, trig, win)
+            assert rc == 0
+            wp, ws = oracle.celt_synth(lm, freq, tr, st if use_state else None)
+            assert rel_rms(pcm, wp) <= 1e-6
+            if use_state:
+                assert rel_rms(st2, ws) <= 1e-6
+
+
+def test_frame_synth_lane_program_vs_reference_fixture(emu, ref_tables):
+    emu.emu_celt_synth.argtypes = [C.c_int, _f32p, C.c_void_p, _f32p, C.c_void_p, C.c_long, C.c_long, C.c_int,
+                                   _f32p, _f32p]
+    z = np.load(os.path.join(GOLDEN, "ref_synth.npz"))
+    freq, tr = np.ascontiguousarray(z["freq"]), np.ascontiguousarray(z["transient"])
+    ns, nf, ch, n = freq.shape
+    pcm = np.zeros((ns, ch, nf * n), np.float32)
+    st = z["state_in"].copy()
+    emu.emu_celt_synth(3, freq.reshape(-1), tr.ctypes.data_as(C.c_void_p), pcm.reshape(-1),
+                       st.ctypes.data_as(C.c_void_p), ns, nf, ch, ref_tables["trig"], ref_tables["window"])
+    assert rel_rms(pcm, z["pcm"]) <= 1e-6
+    assert rel_rms(st, z["state_out"]) <= 1e-6

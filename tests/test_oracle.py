@@ -171,3 +171,15 @@ def test_linearity_and_edge_cases(oracle):
     assert not z.any() and not zt.any()
     e, et = oracle.imdct_batch(0, np.zeros((0, 960), np.float32))  # empty batch
     assert e.shape == (0, 960) and et.shape == (0, 60)
+
+
+def test_frame_synth_bit_exact_vs_reference(oracle):
+    """compute_inv_mdcts over frame sequences (celt_decoder_clean.c:264-312) incl. transient frames."""
+    z = np.load(os.path.join(GOLDEN, "ref_synth.npz"))
+    pcm, st = oracle.celt_synth(3, z["freq"], z["transient"], z["state_in"], nthreads=2)
+    assert np.array_equal(pcm, z["pcm"])
+    assert np.array_equal(st, z["state_out"])
+    c = np.load(os.path.join(GOLDEN, "ref_chain.npz"))
+    tr = np.array([[k == "S" for k in "".join(c["kinds"])]], np.uint8)
+    pcm, st = oracle.celt_synth(3, c["freq"][None, :, None, :], tr, c["carry_in"][None, :])
+    assert np.array_equal(pcm.reshape(-1), c["pcm"]) and np.array_equal(st[0], c["tail"])
