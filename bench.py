@@ -201,6 +201,36 @@ def main():
         step()                                  # restore fin for the parity check below
         torch.cuda.synchronize(dev)
 
+    # secondary figure (not the headline metric): Opus 20 ms stereo frames/s through the frame-sequence
+    # operator nyq_celt_synth_dev on the measured sb-reverie.opus frame mix (2.8 % transient frames,
+    # BASELINE.md section 2), 1024 concurrent streams x 256 frames, device resident.
+    synth = None
+    if rank == 0:
+        ns, nf, ch = 1024, 256, 2
+        gs = torch.Generator(device=dev)
+        gs.manual_seed(4)
+        sfreq = torch.randn((ns, nf, ch, N2), generator=gs, device=dev) * 30.0
+        strans = (torch.rand((ns, nf), generator=gs, device=dev) < 0.028).to(torch.uint8)
+        spcm = torch.empty((ns, ch, nf * N2), device=dev)
+        sstate = torch.zeros((ns * ch, HALF_OV), device=dev)
+        swork = torch.empty(ctx.celt_synth_work_floats(ns, nf, ch), device=dev)
+
+        def sstep():
+            ctx.celt_synth_dev(3, sfreq.data_ptr(), strans.data_ptr(), spcm.data_ptr(), sstate.data_ptr(),
+                               swork.data_ptr(), ns, nf, ch)
+        sstep()
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record(stream)
+        for _ in range(10):
+            sstep()
+        s1.record(stream)
+        torch.cuda.synchronize(dev)
+        sms = s0.elapsed_time(s1) / 10
+        synth = {"stereo_frames_per_sec": ns * nf / (sms * 1e-3), "channel_frames_per_sec": ns * nf * ch / (sms * 1e-3),
+                 "ms_per_call": sms, "algorithmic_GBps": ns * nf * ch * ALG_BYTES_PER_IMDCT / (sms * 1e-3) / 1e9,
+                 "config": f"{ns} streams x {nf} frames x {ch} ch, LM 3, 2.8 % transient frames, chained carry"}
+        del sfreq, spcm, swork
+
     if world > 1:
         t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -254,6 +284,7 @@ def main():
                        "device": devname, "compute_units": cus},
             "opus_stereo_20ms_frames_per_sec": value / 2.0,
             "parity_rel_rms_vs_oracle": parity,
+            "opus_frame_synthesis": synth,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "nyq::imdct_rows_kernel<32, KCfg<1,false,0>>", "kernel_avg_ms": kern_avg_ms,

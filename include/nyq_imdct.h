@@ -86,7 +86,8 @@ int nyq_imdct_batch_dev(nyq_ctx *ctx, int shift, const float *d_in, const float 
  * c*len .. c*len+len-1): block r's carry is block r-1's tail, as the decoder's buffer
  * shift arranges (celt_decoder_clean.c:625,641).  d_carry0 [nchains][60] or NULL seeds
  * row 0 of each chain; d_pcm [nchains*len][N2]; d_tail_out [nchains][60] or NULL gets
- * each chain's final tail; d_work [nchains*len][60] is caller-provided scratch. */
+ * each chain's final tail; d_work [nchains][len+1][60] is caller-provided scratch.
+ * (Same machinery as nyq_celt_synth_dev with one channel and no transient frames.) */
 int nyq_imdct_chain_dev(nyq_ctx *ctx, int shift, const float *d_in, const float *d_carry0,
                         float *d_pcm, float *d_tail_out, float *d_work,
                         size_t nchains, size_t len);

@@ -250,24 +250,6 @@ extern "C" int nyq_ifft_batch_dev(nyq_ctx *ctx, int nfft, const float *d_in, flo
     }
 }
 
-extern "C" int nyq_imdct_chain_dev(nyq_ctx *ctx, int shift, const float *d_in, const float *d_carry0, float *d_pcm,
-                                   float *d_tail_out, float *d_work, size_t nchains, size_t len) {
-    if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_imdct_chain_dev: ctx is NULL");
-    if (shift < 0 || shift > 3) return fail(ctx, NYQ_ERR_INVALID, "nyq_imdct_chain_dev: shift must be 0..3");
-    const size_t rows = nchains * len;
-    if (rows == 0) return NYQ_OK;
-    if (!d_in || !d_pcm || !d_work) return fail(ctx, NYQ_ERR_INVALID, "nyq_imdct_chain_dev: NULL in/pcm/work");
-    // 1. every raw IMDCT in parallel, heads mirrored against a zero carry, tails to d_work
-    int rc = nyq_imdct_batch_dev(ctx, shift, d_in, nullptr, d_pcm, d_work, rows);
-    if (rc != NYQ_OK) return rc;
-    // 2. one hop: add each predecessor's tail into the mirrored head
-    size_t blocks = rows < (size_t)ctx->cus * 32 ? rows : (size_t)ctx->cus * 32;
-    hipLaunchKernelGGL(chain_fixup_kernel, dim3((unsigned)blocks), dim3(64), 0, ctx->stream, d_pcm, d_work, d_carry0,
-                       d_tail_out, NYQ_MDCT_N >> (shift + 1), (long)len, (long)rows, ctx->d_window);
-    NYQ_HIP(ctx, hipGetLastError());
-    return NYQ_OK;
-}
-
 // ---- frame sequences ----------------------------------------------------------------
 extern "C" size_t nyq_celt_synth_work_floats(size_t nstreams, size_t nframes, int channels) {
     return nstreams * (size_t)(channels > 0 ? channels : 0) * (nframes + 1) * NYQ_HALF_OV;
@@ -275,9 +257,9 @@ extern "C" size_t nyq_celt_synth_work_floats(size_t nstreams, size_t nframes, in
 
 template <int N2R>
 static int launch_synth_long(nyq_ctx *ctx, const SynthArgs &A) {
-    const size_t ngroups = (size_t)A.nstreams * A.channels * ((A.nframes + kGroup - 1) / kGroup);
+    const size_t nchunks = (size_t)A.nstreams * A.channels * FrameLongRows<N2R>::chunks_per_channel(A.nframes);
     const int res = resident_blocks(ctx, synth_long_kernel<N2R, Cfg>, &ctx->res_synth_long[Geo<N2R>::SHIFT]);
-    const size_t need = (ngroups + kWavesPerBlock - 1) / kWavesPerBlock;
+    const size_t need = (nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
     const unsigned grid = (unsigned)(need < (size_t)res ? need : (size_t)res);
     hipLaunchKernelGGL((synth_long_kernel<N2R, Cfg>), dim3(grid), dim3(kWave * kWavesPerBlock), 0, ctx->stream, A,
                        ctx->d_trig, ctx->d_window);
@@ -285,21 +267,16 @@ static int launch_synth_long(nyq_ctx *ctx, const SynthArgs &A) {
     return NYQ_OK;
 }
 
-extern "C" int nyq_celt_synth_dev(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned char *d_transient,
-                                  float *d_pcm, float *d_state, float *d_work, size_t nstreams, size_t nframes,
-                                  int channels) {
-    if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_celt_synth_dev: ctx is NULL");
-    if (LM < 0 || LM > 3) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_synth_dev: LM must be 0..3");
-    if (channels < 1 || channels > 255) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_synth_dev: channels must be 1..255");
-    if (nstreams == 0 || nframes == 0) return NYQ_OK;
-    if (!d_freq || !d_pcm || !d_work) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_synth_dev: NULL freq/pcm/work");
-    if (!aligned16(d_freq) || !aligned16(d_pcm) || !aligned16(d_work) || !aligned16(d_state))
-        return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_synth_dev: device pointers must be 16-byte aligned");
+// shared by nyq_celt_synth_dev and nyq_imdct_chain_dev (a chain is a 1-channel stream without
+// transient frames); arguments already validated
+static int synth_core(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned char *d_transient, float *d_pcm,
+                      const float *d_state_in, float *d_state_out, float *d_work, size_t nstreams, size_t nframes,
+                      int channels) {
     const size_t nsc = nstreams * (size_t)channels;
     const size_t pitch = (nframes + 1) * NYQ_HALF_OV * sizeof(float), slot = NYQ_HALF_OV * sizeof(float);
     // tails slot 0 of every (stream, channel) = the state handed in
-    if (d_state)
-        NYQ_HIP(ctx, hipMemcpy2DAsync(d_work, pitch, d_state, slot, slot, nsc, hipMemcpyDeviceToDevice, ctx->stream));
+    if (d_state_in)
+        NYQ_HIP(ctx, hipMemcpy2DAsync(d_work, pitch, d_state_in, slot, slot, nsc, hipMemcpyDeviceToDevice, ctx->stream));
     else
         NYQ_HIP(ctx, hipMemset2DAsync(d_work, pitch, 0, slot, nsc, ctx->stream));
     SynthArgs A;
@@ -321,19 +298,45 @@ extern "C" int nyq_celt_synth_dev(nyq_ctx *ctx, int LM, const float *d_freq, con
     const size_t units = nsc * nframes;
     if (A.transient) {
         const int res = resident_blocks(ctx, synth_short_kernel<Cfg>, &ctx->res_synth_short);
-        const size_t need = (units + kWavesPerBlock - 1) / kWavesPerBlock;
+        const size_t need = (units + kWave * kWavesPerBlock - 1) / (kWave * kWavesPerBlock);
         const unsigned grid = (unsigned)(need < (size_t)res ? need : (size_t)res);
         hipLaunchKernelGGL((synth_short_kernel<Cfg>), dim3(grid), dim3(kWave * kWavesPerBlock), 0, ctx->stream, A, 1 << LM,
                            ctx->d_trig, ctx->d_window);
         NYQ_HIP(ctx, hipGetLastError());
     }
-    const size_t fb = units < (size_t)ctx->cus * 32 ? units : (size_t)ctx->cus * 32;
-    hipLaunchKernelGGL(synth_fixup_kernel, dim3((unsigned)fb), dim3(64), 0, ctx->stream, A, 120 << LM, ctx->d_window);
+    const size_t per_block = (size_t)kWave * kFixupWaves;
+    hipLaunchKernelGGL(synth_fixup_kernel, dim3((unsigned)((units + per_block - 1) / per_block)),
+                       dim3(kWave * kFixupWaves), 0, ctx->stream, A, 120 << LM, ctx->d_window);
     NYQ_HIP(ctx, hipGetLastError());
-    if (d_state)
-        NYQ_HIP(ctx, hipMemcpy2DAsync(d_state, slot, d_work + nframes * NYQ_HALF_OV, pitch, slot, nsc,
+    if (d_state_out)
+        NYQ_HIP(ctx, hipMemcpy2DAsync(d_state_out, slot, d_work + nframes * NYQ_HALF_OV, pitch, slot, nsc,
                                       hipMemcpyDeviceToDevice, ctx->stream));
     return NYQ_OK;
+}
+
+extern "C" int nyq_celt_synth_dev(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned char *d_transient,
+                                  float *d_pcm, float *d_state, float *d_work, size_t nstreams, size_t nframes,
+                                  int channels) {
+    if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_celt_synth_dev: ctx is NULL");
+    if (LM < 0 || LM > 3) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_synth_dev: LM must be 0..3");
+    if (channels < 1 || channels > 255) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_synth_dev: channels must be 1..255");
+    if (nstreams == 0 || nframes == 0) return NYQ_OK;
+    if (!d_freq || !d_pcm || !d_work) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_synth_dev: NULL freq/pcm/work");
+    if (!aligned16(d_freq) || !aligned16(d_pcm) || !aligned16(d_work) || !aligned16(d_state))
+        return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_synth_dev: device pointers must be 16-byte aligned");
+    return synth_core(ctx, LM, d_freq, d_transient, d_pcm, d_state, d_state, d_work, nstreams, nframes, channels);
+}
+
+extern "C" int nyq_imdct_chain_dev(nyq_ctx *ctx, int shift, const float *d_in, const float *d_carry0, float *d_pcm,
+                                   float *d_tail_out, float *d_work, size_t nchains, size_t len) {
+    if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_imdct_chain_dev: ctx is NULL");
+    if (shift < 0 || shift > 3) return fail(ctx, NYQ_ERR_INVALID, "nyq_imdct_chain_dev: shift must be 0..3");
+    if (nchains * len == 0) return NYQ_OK;
+    if (!d_in || !d_pcm || !d_work) return fail(ctx, NYQ_ERR_INVALID, "nyq_imdct_chain_dev: NULL in/pcm/work");
+    if (!aligned16(d_in) || !aligned16(d_pcm) || !aligned16(d_work) || !aligned16(d_carry0) || !aligned16(d_tail_out))
+        return fail(ctx, NYQ_ERR_INVALID, "nyq_imdct_chain_dev: device pointers must be 16-byte aligned");
+    // a chain is a one-channel stream of `len` long frames of size N2 = 120 << (3 - shift)
+    return synth_core(ctx, 3 - shift, d_in, nullptr, d_pcm, d_carry0, d_tail_out, d_work, nchains, len, 1);
 }
 
 // ---- host-buffer variants ---------------------------------------------------------
@@ -379,7 +382,7 @@ static int imdct_host(nyq_ctx *ctx, int shift, const float *in, const float *car
     const size_t n2 = (size_t)(NYQ_MDCT_N >> (shift + 1));
     NYQ_HIP(ctx, hipSetDevice(ctx->device));
     const size_t n_in = round16f(rows * n2), n_c = round16f(carry_rows * NYQ_HALF_OV),
-                 n_t = round16f(rows * NYQ_HALF_OV), n_to = round16f(tail_rows * NYQ_HALF_OV);
+                 n_t = round16f((rows + nchains) * NYQ_HALF_OV), n_to = round16f(tail_rows * NYQ_HALF_OV);
     int rc = need_scratch(ctx, (2 * n_in + n_c + n_t + n_to) * sizeof(float));
     if (rc != NYQ_OK) return rc;
     float *d_in = ctx->d_scratch, *d_fin = d_in + n_in, *d_c = d_fin + n_in, *d_t = d_c + n_c, *d_to = d_t + n_t;

@@ -211,9 +211,14 @@ struct SynthArgs {
     int channels;
 };
 
-// Four consecutive LONG frames of one (stream, channel): group gi = sc * ceil(nframes/4) + q.
-// Row g chains to row g-1 in registers/LDS when both are long; group-first rows and rows after a
-// transient frame are mirrored against zeros here and receive their carry in synth_fixup.
+// Long frames.  A wave visits CHUNKS of kChainGroups groups = 16 consecutive frames of one
+// (stream, channel); inside a chunk every long frame that follows a long frame takes its carry
+// in-wave (LDS tail ring, handed from group to group by ring_rotate).  Chunk-first frames and
+// frames after a transient frame are mirrored against zeros here and receive their carry in
+// synth_fixup; their predecessors publish a tail to the tails buffer.
+constexpr int kChainGroups = 4;
+constexpr int kChainFrames = kChainGroups * kGroup;
+
 template <int N2R>
 struct FrameLongRows {
     static constexpr bool STRIDED = false;
@@ -224,11 +229,15 @@ struct FrameLongRows {
     float *tail0;       // tails slot f0+1
     long in_step;       // channels * N
     unsigned longmask;  // bit g+1 set <=> frame f0+g exists and is long (g = -1..4)
-    NYQ_HD FrameLongRows(const SynthArgs &A, long gi) {
-        const long gq = (A.nframes + kGroup - 1) / kGroup;
-        const long sc = gi / gq, q = gi - sc * gq;
+    int qq;             // group inside the chunk
+    // chunk ci = sc * chunks_per_channel + k covers frames 16k .. 16k+15 of channel sc
+    NYQ_HD static long chunks_per_channel(long nframes) { return (nframes + kChainFrames - 1) / kChainFrames; }
+    NYQ_HD FrameLongRows(const SynthArgs &A, long ci, int qq_) {
+        const long cpc = chunks_per_channel(A.nframes);
+        const long sc = ci / cpc, k = ci - sc * cpc;
         const long s = sc / A.channels, c = sc - s * A.channels;
-        const long f0 = q * kGroup;
+        const long f0 = k * kChainFrames + (long)qq_ * kGroup;
+        qq = qq_;
         in_step = (long)A.channels * N;
         in0 = A.freq + ((s * A.nframes + f0) * A.channels + c) * (long)N;
         fin0 = A.pcm + (sc * A.nframes + f0) * (long)N;
@@ -241,16 +250,19 @@ struct FrameLongRows {
             if (f >= 0 && f < A.nframes && !(A.transient && t[f])) longmask |= 1u << (g + 1);
         }
     }
+    NYQ_HD bool any() const { return (longmask & 0x1Eu) != 0; }
     NYQ_HD bool is_long(int g) const { return (longmask >> (g + 1)) & 1u; }
     NYQ_HD bool valid(int g) const { return is_long(g); }
     NYQ_HD const float *in(int g) const { return in0 + g * in_step; }
     NYQ_HD int stride() const { return 1; }
     NYQ_HD float *fin(int g) const { return fin0 + g * (long)N; }
-    NYQ_HD bool chain(int g) const { return g > 0 && is_long(g - 1); }
+    // row 0 of a later group of the chunk chains to the ring slot the previous group left
+    NYQ_HD bool chain(int g) const { return (g > 0 || qq > 0) && is_long(g - 1); }
     NYQ_HD const float *carry(int) const { return nullptr; }
-    // the next frame's head is chained in-wave only if it is long and inside this group
+    // publish the tail unless the next frame's head is completed in-wave
     NYQ_HD float *tail(int g) const {
-        return (g == kGroup - 1 || !is_long(g + 1)) ? tail0 + g * (long)kHalfOv : nullptr;
+        const bool next_in_wave = is_long(g + 1) && (g < kGroup - 1 || qq < kChainGroups - 1);
+        return next_in_wave ? nullptr : tail0 + g * (long)kHalfOv;
     }
 };
 
@@ -284,7 +296,7 @@ struct FrameShortRows {
 // Is the head of frame f (its first 120 samples) already mirrored against the true carry?
 // Only long frames that chained in-wave are; every other head gets its carry in synth_fixup.
 NYQ_HD bool head_done_in_wave(const unsigned char *t, long f) {
-    return f > 0 && (f % kGroup) != 0 && !(t && (t[f] || t[f - 1]));
+    return (f % kChainFrames) != 0 && !(t && (t[f] || t[f - 1]));
 }
 
 // ---- phase A -----------------------------------------------------------

@@ -5,8 +5,11 @@
 // Kernels (all wave-autonomous: 64 lanes own 4 rows, meet only in their LDS slice):
 //   imdct_rows_kernel<N2R,Cfg>  clt_mdct_backward  (mdct.c:267-379)  on independent rows
 //   ifft_rows_kernel<N2R,WPB>   opus_ifft          (kiss_fft.c:696-747)
-//   chain_fixup_kernel          adds the carry terms of the TDAC mirror (mdct.c:362-377)
-//                               for rows chained to their predecessor's tail
+//   synth_long_kernel<N2R,Cfg>  compute_inv_mdcts (celt_decoder_clean.c:264-312), long frames,
+//                               16-frame chunks chained in-wave
+//   synth_short_kernel<Cfg>     the same for the interleaved short blocks of transient frames
+//   synth_fixup_kernel          adds the carry terms of the TDAC mirror (mdct.c:371-372) to the
+//                               few heads that could not be chained in-wave
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(kWave *Cfg::WPB) void imdct_rows_kernel(
 }
 
 // ---- frame sequences: the compute_inv_mdcts replacement (celt_decoder_clean.c:264-312) ----
-// Long frames: one group = four consecutive frames of one (stream, channel), chained in-wave.
+// Long frames: chunks of 16 consecutive frames of one (stream, channel), chained in-wave.
 template <int N2R, typename Cfg>
 __global__ __launch_bounds__(kWave *Cfg::WPB) void synth_long_kernel(SynthArgs A, const float *__restrict__ trig,
                                                                       const float *__restrict__ window) {
@@ -158,14 +161,19 @@ __global__ __launch_bounds__(kWave *Cfg::WPB) void synth_long_kernel(SynthArgs A
     LaneConst<N2R> K;
     lane_init<N2R>(K, lane, trig, window);
 
-    const long ngroups = A.nstreams * A.channels * ((A.nframes + kGroup - 1) / kGroup);
+    const long nchunks = A.nstreams * A.channels * FrameLongRows<N2R>::chunks_per_channel(A.nframes);
     const long nwaves = (long)gridDim.x * Cfg::WPB;
-    for (long gi = (long)blockIdx.x * Cfg::WPB + wv; gi < ngroups; gi += nwaves) {
-        FrameLongRows<N2R> rows(A, gi);
-        if ((rows.longmask & 0x1Eu) == 0) continue;   // four transient frames: nothing to do here
-        StageRegs<N2R> R;
-        stage_in_load<N2R, Cfg::NT_LD>(R, lane, rows);
-        run_group<N2R, Cfg>(K, lane, lds, ring, rows, R);
+    for (long ci = (long)blockIdx.x * Cfg::WPB + wv; ci < nchunks; ci += nwaves) {
+#pragma unroll 1
+        for (int qq = 0; qq < kChainGroups; qq++) {
+            FrameLongRows<N2R> rows(A, ci, qq);
+            if (!rows.any()) continue;   // four transient (or out-of-range) frames: nothing to do here
+            StageRegs<N2R> R;
+            stage_in_load<N2R, Cfg::NT_LD>(R, lane, rows);
+            run_group<N2R, Cfg>(K, lane, lds, ring, rows, R);
+            NYQ_WAVE_SYNC();
+            ring_rotate(lane, ring);
+        }
     }
 }
 
@@ -185,19 +193,32 @@ __global__ __launch_bounds__(kWave *Cfg::WPB) void synth_short_kernel(SynthArgs 
     LaneConst<4> K;
     lane_init<4>(K, lane, trig, window);
 
+    // Transient frames are rare (a few per cent), so the scan is vectorised: the wave looks at 64
+    // consecutive (stream*channel, frame) units at once -- one flag byte per lane, one ballot --
+    // and then walks only the set bits.
     const long units = A.nstreams * A.channels * A.nframes;
     const long nwaves = (long)gridDim.x * Cfg::WPB;
-    for (long u = (long)blockIdx.x * Cfg::WPB + wv; u < units; u += nwaves) {
-        const long sc = u / A.nframes, f = u - sc * A.nframes;
-        const long s = sc / A.channels;
-        if (!A.transient[s * A.nframes + f]) continue;
-        for (int h = 0; h * kGroup < B; h++) {
-            FrameShortRows rows(A, sc, f, B, h);
-            StageRegs<4> R;
-            stage_in_load<4, 0>(R, lane, rows);
-            run_group<4, Cfg>(K, lane, lds, ring, rows, R);
-            NYQ_WAVE_SYNC();
-            ring_rotate(lane, ring);
+    for (long base = ((long)blockIdx.x * Cfg::WPB + wv) * kWave; base < units; base += nwaves * kWave) {
+        const long mine = base + lane;
+        bool hit = false;
+        if (mine < units) {
+            const long sc = mine / A.nframes, f = mine - sc * A.nframes;
+            hit = A.transient[(sc / A.channels) * A.nframes + f] != 0;
+        }
+        unsigned long long todo = __ballot(hit);
+        while (todo) {
+            const int bit = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const long u = base + bit;
+            const long sc = u / A.nframes, f = u - sc * A.nframes;
+            for (int h = 0; h * kGroup < B; h++) {
+                FrameShortRows rows(A, sc, f, B, h);
+                StageRegs<4> R;
+                stage_in_load<4, 0>(R, lane, rows);
+                run_group<4, Cfg>(K, lane, lds, ring, rows, R);
+                NYQ_WAVE_SYNC();
+                ring_rotate(lane, ring);
+            }
         }
     }
 }
@@ -205,18 +226,34 @@ __global__ __launch_bounds__(kWave *Cfg::WPB) void synth_short_kernel(SynthArgs 
 // Heads that were mirrored against zeros receive their carry: slot f of the tails buffer holds
 // the raw tail that precedes frame f (slot 0: the state handed in).  mdct.c:371-372 is linear in
 // the carry, so  out[i] += w[119-i] c[i];  out[119-i] += w[i] c[i]  completes the mirror exactly.
-__global__ __launch_bounds__(64) void synth_fixup_kernel(SynthArgs A, int N, const float *__restrict__ window) {
-    const int i = threadIdx.x;
-    if (i >= kHalfOv) return;
+constexpr int kFixupWaves = 4;   // waves per block; each wave scans 64 (stream*channel, frame) units
+__global__ __launch_bounds__(kWave *kFixupWaves) void synth_fixup_kernel(SynthArgs A, int N,
+                                                                          const float *__restrict__ window) {
+    // Few heads need work (one in 16 plus the neighbours of transient frames), so scan 64 units per
+    // wave with one flag test per lane and a ballot, then let lanes 0..59 patch each hit.
+    const int lane = threadIdx.x & (kWave - 1);
+    const long base = ((long)blockIdx.x * kFixupWaves + (threadIdx.x >> 6)) * kWave;
     const long units = A.nstreams * A.channels * A.nframes;
-    for (long u = blockIdx.x; u < units; u += gridDim.x) {
+    const long mine = base + lane;
+    bool need = false;
+    if (mine < units) {
+        const long sc = mine / A.nframes, f = mine - sc * A.nframes;
+        need = !head_done_in_wave(A.transient ? A.transient + (sc / A.channels) * A.nframes : nullptr, f);
+    }
+    unsigned long long todo = __ballot(need);
+    const float wa = lane < kHalfOv ? window[kOverlap - 1 - lane] : 0.f;
+    const float wb = lane < kHalfOv ? window[lane] : 0.f;
+    while (todo) {
+        const int bit = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const long u = base + bit;
         const long sc = u / A.nframes, f = u - sc * A.nframes;
-        const long s = sc / A.channels;
-        if (head_done_in_wave(A.transient ? A.transient + s * A.nframes : nullptr, f)) continue;
-        const float cv = A.tails[(sc * (A.nframes + 1) + f) * (long)kHalfOv + i];
-        float *o = A.pcm + (sc * A.nframes + f) * (long)N;
-        o[i] += window[kOverlap - 1 - i] * cv;
-        o[kOverlap - 1 - i] += window[i] * cv;
+        if (lane < kHalfOv) {
+            const float cv = A.tails[(sc * (A.nframes + 1) + f) * (long)kHalfOv + lane];
+            float *o = A.pcm + (sc * A.nframes + f) * (long)N;
+            o[lane] += wa * cv;
+            o[kOverlap - 1 - lane] += wb * cv;
+        }
     }
 }
 
@@ -237,29 +274,6 @@ __global__ __launch_bounds__(kWave *WPB) void ifft_rows_kernel(const float *__re
         NYQ_WAVE_SYNC();
         fft_passes<N2R>(lane, lds);
         ifft_stage_out<N2R>(lane, lds, out, row0, nrows);
-    }
-}
-
-// One 64-thread block per row: lanes 0..59 add the carry terms of mdct.c:371-372 to a
-// head that was produced with zero carry:  out[i] += w[119-i]*c[i];  out[119-i] += w[i]*c[i].
-// Row r of chain c takes c[] from tails[row-1] (r > 0) or carry0[c] (r == 0, may be NULL).
-__global__ __launch_bounds__(64) void chain_fixup_kernel(float *__restrict__ pcm,
-                                                          const float *__restrict__ tails,
-                                                          const float *__restrict__ carry0,
-                                                          float *__restrict__ tail_out, int n2,
-                                                          long len, long nrows,
-                                                          const float *__restrict__ window) {
-    const int i = threadIdx.x;
-    if (i >= kHalfOv) return;
-    for (long row = blockIdx.x; row < nrows; row += gridDim.x) {
-        const long c = row / len, r = row - c * len;
-        float cv = 0.f;
-        if (r > 0) cv = tails[(row - 1) * kHalfOv + i];
-        else if (carry0) cv = carry0[c * kHalfOv + i];
-        float *o = pcm + row * (long)n2;
-        o[i] += window[kOverlap - 1 - i] * cv;
-        o[kOverlap - 1 - i] += window[i] * cv;
-        if (tail_out && r == len - 1) tail_out[c * kHalfOv + i] = tails[row * kHalfOv + i];
     }
 }
 

@@ -78,12 +78,14 @@ static void emu_ifft(const float *in, float *out, long nrows) {
 template <int N2R>
 static void emu_synth_long(const SynthArgs &A, const float *trig, const float *window) {
     WaveEmu<N2R> W(trig, window);
-    const long ngroups = A.nstreams * A.channels * ((A.nframes + kGroup - 1) / kGroup);
-    for (long gi = 0; gi < ngroups; gi++) {
-        FrameLongRows<N2R> rows(A, gi);
-        if ((rows.longmask & 0x1Eu) == 0) continue;
-        W.group(rows);
-    }
+    const long nchunks = A.nstreams * A.channels * FrameLongRows<N2R>::chunks_per_channel(A.nframes);
+    for (long ci = 0; ci < nchunks; ci++)
+        for (int qq = 0; qq < kChainGroups; qq++) {
+            FrameLongRows<N2R> rows(A, ci, qq);
+            if (!rows.any()) continue;
+            W.group(rows);
+            W.rotate();
+        }
 }
 
 static void emu_synth_short(const SynthArgs &A, int B, const float *trig, const float *window) {

@@ -244,7 +244,7 @@ def test_chain_dev_matches_host_chain(ctx, oracle):
     d_x = torch.from_numpy(x).to(dev)
     d_pcm = torch.empty_like(d_x)
     d_tail = torch.empty((nchains, 60), device=dev)
-    d_work = torch.empty((nchains * length, 60), device=dev)
+    d_work = torch.empty((nchains, length + 1, 60), device=dev)
     torch.cuda.synchronize(dev)      # ctx runs on its own stream here: order it after torch's copies
     ctx.imdct_chain_dev(0, d_x.data_ptr(), 0, d_pcm.data_ptr(), d_tail.data_ptr(), d_work.data_ptr(), nchains, length)
     ctx.synchronize()

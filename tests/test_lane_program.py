@@ -85,7 +85,7 @@ def test_frame_synth_lane_program_vs_oracle(emu, oracle, lm):
     trig, win, _ = oracle.tables()
     rng = np.random.default_rng(lm)
     n = 120 << lm
-    for ns, nf, ch, ptr in ((1, 1, 1, 0.0), (2, 9, 2, 0.3), (1, 13, 3, 0.6), (3, 4, 2, 1.0), (2, 7, 1, 0.0)):
+    for ns, nf, ch, ptr in ((1, 1, 1, 0.0), (2, 9, 2, 0.3), (1, 37, 3, 0.2), (3, 4, 2, 1.0), (2, 33, 1, 0.0), (1, 16, 2, 0.1)):
         freq = (rng.standard_normal((ns, nf, ch, n)) * 30).astype(np.float32)
         tr = (rng.uniform(size=(ns, nf)) < ptr).astype(np.uint8)
         st = (rng.standard_normal((ns * ch, 60)) * 30).astype(np.float32)
