@@ -17,6 +17,11 @@ Writes DATA only (inputs + expected outputs):
                                       emulating the decode_mem shift of celt_decoder_clean.c:625,641
   ref_synth.npz                       compute_inv_mdcts over 2 stereo streams x 11 frames with
                                       transient frames, through the reference's B1_C2 fast paths
+  real_opus_frames.npz                REAL data: freq[] / isTransient / out_syn of frames 64..127 of
+                                      test_data/short.opus as the reference decoder itself computed
+                                      them (NyquistIO::Load with the recording tap), the transient
+                                      maps of short.opus and sb-reverie.opus, and the end-to-end
+                                      sample counts / checksums (examples/src/Main.cpp:137-154)
 Everything is seeded; re-running reproduces the files bit for bit.
 """
 import os
@@ -158,6 +163,40 @@ def main():
                 ref.imdct_c2(X[0], X[1], mem[s_, 0, f * 960: f * 960 + 1020], mem[s_, 1, f * 960: f * 960 + 1020], 0, 1)
     np.savez(f"{OUT}/ref_synth.npz", freq=freq, transient=transient, state_in=state,
              pcm=mem[:, :, : nf * 960].copy(), state_out=mem[:, :, nf * 960:].reshape(ns * ch, HALF_OV).copy())
+    # REAL decoder data: the reference decoder itself (oracle/_ref/ref_capture = NyquistIO::Load built
+    # from the reference's sources with the recording tap) run on the bundled test files.
+    import struct
+    import subprocess
+    import tempfile
+
+    def capture(name, max_frames):
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "cap.bin")
+            subprocess.run([os.path.join(ROOT, "oracle", "_ref", "ref_capture"), f"{REFDATA}/{name}", out,
+                            str(max_frames)], check=True, stdout=subprocess.DEVNULL)
+            b = open(out, "rb").read()
+        _, ch, frames, ncalls = struct.unpack("<4i", b[:16])
+        (fsum,) = struct.unpack("<f", b[16:20])
+        (nsamp,) = struct.unpack("<q", b[20:28])
+        flags = np.frombuffer(b[28:28 + frames], np.uint8).copy()
+        pay = np.frombuffer(b[28 + frames:], np.float32).reshape(frames, ch, 1980)
+        return dict(channels=ch, flags=flags, freq=pay[:, :, :960].copy(), out=pay[:, :, 960:].copy(),
+                    sum=fsum, samples=nsamp, calls=ncalls)
+
+    sh_ = capture("short.opus", 100000)
+    lo, hi = 64, 128                                  # 64 frames incl. transient frames 73, 97, 123, 124
+    rv = capture("sb-reverie.opus", 100000)
+    np.savez_compressed(
+        f"{OUT}/real_opus_frames.npz",
+        freq=sh_["freq"][lo:hi][None], transient=sh_["flags"][lo:hi][None],
+        state_in=sh_["out"][lo - 1, :, 960:].copy(),              # raw tail of frame lo-1 = carry of frame lo
+        pcm=sh_["out"][lo:hi, :, :960].transpose(1, 0, 2).reshape(1, 2, -1).copy(),
+        state_out=sh_["out"][hi - 1, :, 960:].copy(),
+        short_opus=np.array([sh_["samples"], sh_["calls"], len(sh_["flags"]), int(sh_["flags"].sum())], np.int64),
+        short_opus_sum=np.float32(sh_["sum"]), short_opus_transient=sh_["flags"],
+        sb_reverie=np.array([rv["samples"], rv["calls"], len(rv["flags"]), int(rv["flags"].sum())], np.int64),
+        sb_reverie_sum=np.float32(rv["sum"]), sb_reverie_transient=rv["flags"],
+        window=np.array([lo, hi]))
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"wrote {len(os.listdir(OUT))} files, {total/1024:.0f} KiB -> {OUT}")
 

@@ -306,3 +306,44 @@ def test_frame_synth_matches_sb_reverie_mix_at_scale(ctx, oracle):
         wp, ws = oracle.celt_synth(3, freq[s:s + 1].cpu().numpy(), tr[s:s + 1].cpu().numpy(), np.zeros((ch, 60), np.float32), nthreads=2)
         assert rel_rms(pcm[s].cpu().numpy(), wp[0]) <= 1e-6
         assert rel_rms(state[s * ch:(s + 1) * ch].cpu().numpy(), ws) <= 1e-6
+
+
+def test_frame_synth_on_real_decoder_frames(ctx_ref_tables):
+    """Real freq[] of test_data/short.opus frames 64..127 (captured from the reference decoder):
+    the GPU path must reproduce the decoder's own out_syn."""
+    z = np.load(os.path.join(GOLDEN, "real_opus_frames.npz"))
+    pcm, st = ctx_ref_tables.celt_synth(3, z["freq"], z["transient"], z["state_in"], channels=2)
+    assert rel_rms(pcm, z["pcm"]) <= TOL and rel_rms(pcm, z["pcm"]) <= 1e-6
+    assert rel_rms(st, z["state_out"]) <= 1e-6
+    # per-frame check, transient frames included
+    want = z["pcm"].reshape(2, -1, 960)
+    got = pcm.reshape(2, -1, 960)
+    for f in range(want.shape[1]):
+        assert rel_rms(got[:, f], want[:, f]) <= TOL, f
+
+
+def test_config4_thousand_streams_sb_reverie_pattern(ctx, oracle):
+    """BASELINE config 4 shape: 1000 concurrent stereo streams following the REAL transient map of
+    test_data/sb-reverie.opus (first 64 frames of the map per stream, streams start at different
+    offsets), synthetic decoder-scale freq[]; sampled streams checked against the oracle."""
+    import torch
+    dev = torch.device("cuda", 0)
+    ctx.set_tables(*oracle.tables()[:2])
+    z = np.load(os.path.join(GOLDEN, "real_opus_frames.npz"))
+    tmap = z["sb_reverie_transient"]
+    ns, nf, ch = 1000, 64, 2
+    offs = (np.arange(ns) * 11) % (len(tmap) - nf)
+    tr_np = np.stack([tmap[o:o + nf] for o in offs]).astype(np.uint8)
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    freq = torch.randn((ns, nf, ch, 960), generator=g, device=dev) * 30
+    tr = torch.from_numpy(tr_np).to(dev)
+    pcm = torch.empty((ns, ch, nf * 960), device=dev)
+    work = torch.empty(ctx.celt_synth_work_floats(ns, nf, ch), device=dev)
+    torch.cuda.synchronize(dev)
+    ctx.celt_synth_dev(3, freq.data_ptr(), tr.data_ptr(), pcm.data_ptr(), 0, work.data_ptr(), ns, nf, ch)
+    ctx.synchronize()
+    hit = [int(i) for i in np.nonzero(tr_np.sum(1))[0][:3]] + [0, ns - 1]
+    for s in hit:
+        wp, _ = oracle.celt_synth(3, freq[s:s + 1].cpu().numpy(), tr_np[s:s + 1], None, nthreads=2)
+        assert rel_rms(pcm[s].cpu().numpy(), wp[0]) <= 1e-6, s

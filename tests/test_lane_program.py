@@ -113,3 +113,17 @@ def test_frame_synth_lane_program_vs_reference_fixture(emu, ref_tables):
                        st.ctypes.data_as(C.c_void_p), ns, nf, ch, ref_tables["trig"], ref_tables["window"])
     assert rel_rms(pcm, z["pcm"]) <= 1e-6
     assert rel_rms(st, z["state_out"]) <= 1e-6
+
+
+def test_frame_synth_lane_program_on_real_decoder_frames(emu, ref_tables):
+    emu.emu_celt_synth.argtypes = [C.c_int, _f32p, C.c_void_p, _f32p, C.c_void_p, C.c_long, C.c_long, C.c_int,
+                                   _f32p, _f32p]
+    z = np.load(os.path.join(GOLDEN, "real_opus_frames.npz"))
+    freq, tr = np.ascontiguousarray(z["freq"]), np.ascontiguousarray(z["transient"])
+    ns, nf, ch, n = freq.shape
+    pcm = np.zeros((ns, ch, nf * n), np.float32)
+    st = z["state_in"].copy()
+    emu.emu_celt_synth(3, freq.reshape(-1), tr.ctypes.data_as(C.c_void_p), pcm.reshape(-1),
+                       st.ctypes.data_as(C.c_void_p), ns, nf, ch, ref_tables["trig"], ref_tables["window"])
+    assert rel_rms(pcm, z["pcm"]) <= 1e-6
+    assert rel_rms(st, z["state_out"]) <= 1e-6

@@ -183,3 +183,18 @@ def test_frame_synth_bit_exact_vs_reference(oracle):
     tr = np.array([[k == "S" for k in "".join(c["kinds"])]], np.uint8)
     pcm, st = oracle.celt_synth(3, c["freq"][None, :, None, :], tr, c["carry_in"][None, :])
     assert np.array_equal(pcm.reshape(-1), c["pcm"]) and np.array_equal(st[0], c["tail"])
+
+
+def test_real_decoder_frames_bit_exact(oracle):
+    """freq[] and out_syn captured from the reference decoder itself on test_data/short.opus
+    (frames 64..127, four of them transient): the oracle's frame synthesis is bit-exact, and the
+    captured run reproduces the reference's documented end-to-end numbers."""
+    z = np.load(os.path.join(GOLDEN, "real_opus_frames.npz"))
+    pcm, st = oracle.celt_synth(3, z["freq"], z["transient"], z["state_in"])
+    assert z["transient"].sum() == 4
+    assert np.array_equal(pcm, z["pcm"])
+    assert np.array_equal(st, z["state_out"])
+    # examples/src/Main.cpp:146 pair for sb-reverie.opus: (int)sum == 403, size == 21472602
+    assert int(z["sb_reverie"][0]) == 21472602 and int(float(z["sb_reverie_sum"])) == 403
+    assert list(z["sb_reverie"][1:]) == [26764, 11184, 314]       # BASELINE.md section 2 call mix
+    assert list(z["short_opus"]) == [421930, 554, 220, 8]
