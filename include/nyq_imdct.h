@@ -113,6 +113,24 @@ int nyq_celt_synth_dev(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned
                        float *d_pcm, float *d_state, float *d_work,
                        size_t nstreams, size_t nframes, int channels);
 
+/* What celt_decode_with_ec does after the IMDCT (celt_decoder_clean.c:658-683, 723): the pitch
+ * post-filter (comb_filter, celt.c:114-172) and deemphasis() (:192-256) with its 1/32768 scaling
+ * and channel interleave -- i.e. from out_syn to the interleaved [-1,1) float samples that end up
+ * in nqr::AudioData::samples.  Recursive along time: one wavefront per (stream, channel).
+ *   d_pcm        [nstreams*channels][nframes*N]  output of nyq_celt_synth_dev (read only)
+ *   d_pf_pitch, d_pf_gain, d_pf_tapset [nstreams][nframes]  post-filter parameters decoded from each
+ *                frame (postfilter_pitch, postfilter_gain, postfilter_tapset; gain 0 = filter off)
+ *   d_pf_state_in / d_pf_state_out [nstreams][6] or NULL  {period_old, period, gain_old, gain,
+ *                tapset_old, tapset} before / after; must not alias each other
+ *   d_hist       [nstreams*channels][1088] or NULL  filtered history before frame 0, in/out
+ *   d_deemph     [nstreams*channels] or NULL        preemph_memD, in/out
+ *   d_out        [nstreams][nframes*N][channels]    interleaved float PCM
+ * NULL state pointers mean a freshly reset decoder (zeros) and discard the final state. */
+int nyq_celt_post_dev(nyq_ctx *ctx, int LM, const float *d_pcm, const int *d_pf_pitch,
+                      const float *d_pf_gain, const int *d_pf_tapset, const float *d_pf_state_in,
+                      float *d_pf_state_out, float *d_hist, float *d_deemph, float *d_out,
+                      size_t nstreams, size_t nframes, int channels);
+
 /* ---- host-buffer variants (synchronous: H2D, kernel, D2H through context scratch) ---- */
 int nyq_ifft_batch(nyq_ctx *ctx, int nfft, const float *in, float *out, size_t batch);
 int nyq_imdct_batch(nyq_ctx *ctx, int shift, const float *in, const float *carry,

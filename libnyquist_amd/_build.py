@@ -3,6 +3,7 @@
 hipcc cross-compiles without a GPU; the built .so travels to the GPU box with the
 repository snapshot (it is git-ignored, not gpurun-ignored).
 """
+import glob
 import os
 import shutil
 import subprocess
@@ -12,9 +13,8 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libnyq_imdct.so")
 SOURCES = [os.path.join(CSRC, "nyq_imdct.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, "nyq_kernels.hpp"), os.path.join(CSRC, "nyq_imdct_lanes.hpp"),
-                  os.path.join(CSRC, "nyq_fft_core.hpp"),
-                  os.path.join(ROOT, "include", "nyq_imdct.h")]
+DEPS = sorted(set(SOURCES + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.hip"))
+                  + [os.path.join(ROOT, "include", "nyq_imdct.h")]))
 
 
 def hipcc():

@@ -21,7 +21,7 @@ EXPORTS = [
     "nyq_ctx_create", "nyq_ctx_destroy", "nyq_last_error", "nyq_ctx_set_stream", "nyq_ctx_reset_stream", "nyq_ctx_get_stream",
     "nyq_ctx_synchronize", "nyq_ctx_set_tables", "nyq_ctx_get_tables", "nyq_ctx_device_info",
     "nyq_ifft_batch_dev", "nyq_imdct_batch_dev", "nyq_imdct_chain_dev",
-    "nyq_celt_synth_work_floats", "nyq_celt_synth_dev", "nyq_celt_synth",
+    "nyq_celt_synth_work_floats", "nyq_celt_synth_dev", "nyq_celt_synth", "nyq_celt_post_dev",
     "nyq_ifft_batch", "nyq_imdct_batch", "nyq_imdct_chain",
     "processMDCTCuda", "processMDCTCudaB1C2", "cleanupCudaBuffers", "printCudaVersion",
 ]
@@ -41,6 +41,14 @@ def load(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
+    # One process must use ONE HIP runtime.  PyTorch-ROCm bundles its own libamdhip64; if it is going
+    # to be used beside this library (device buffers, streams), it has to be loaded first so that our
+    # DT_NEEDED libamdhip64.so resolves to the same, already loaded runtime.  Harmless when absent.
+    if os.environ.get("NYQ_NO_TORCH") is None:
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     p = path or _build.LIB
     if path is None:
         try:
@@ -72,6 +80,7 @@ def load(path=None):
     L.nyq_celt_synth_work_floats.restype = sz
     L.nyq_celt_synth_dev.argtypes = [vp, i, fp, fp, fp, fp, fp, sz, sz, i]
     L.nyq_celt_synth.argtypes = [vp, i, fp, fp, fp, fp, sz, sz, i]
+    L.nyq_celt_post_dev.argtypes = [vp, i, fp, fp, fp, fp, fp, fp, fp, fp, fp, sz, sz, i]
     L.nyq_ifft_batch.argtypes = [vp, i, fp, fp, sz]
     L.nyq_imdct_batch.argtypes = [vp, i, fp, fp, fp, fp, sz]
     L.nyq_imdct_chain.argtypes = [vp, i, fp, fp, fp, fp, sz, sz]
@@ -203,6 +212,13 @@ class Context:
         self._ck(self.lib.nyq_celt_synth_dev(self.h, lm, C.c_void_p(d_freq), C.c_void_p(d_transient or 0),
                                              C.c_void_p(d_pcm), C.c_void_p(d_state or 0), C.c_void_p(d_work),
                                              nstreams, nframes, channels))
+
+    def celt_post_dev(self, lm, d_pcm, d_pf_pitch, d_pf_gain, d_pf_tapset, d_pf_state_in, d_pf_state_out, d_hist,
+                      d_deemph, d_out, nstreams, nframes, channels):
+        V = lambda p: C.c_void_p(p or 0)
+        self._ck(self.lib.nyq_celt_post_dev(self.h, lm, V(d_pcm), V(d_pf_pitch), V(d_pf_gain), V(d_pf_tapset),
+                                            V(d_pf_state_in), V(d_pf_state_out), V(d_hist), V(d_deemph), V(d_out),
+                                            nstreams, nframes, channels))
 
     # -- device-resident operators (raw pointers)
     def ifft_batch_dev(self, nfft, d_in, d_out, batch):

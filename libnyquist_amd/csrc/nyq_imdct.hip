@@ -16,6 +16,7 @@
 #include "../../include/nyq_imdct.h"
 
 #include "nyq_kernels.hpp"
+#include "nyq_post_kernels.hpp"
 
 using namespace nyq;
 
@@ -41,6 +42,7 @@ struct nyq_ctx {
     int res_ifft[4] = {0, 0, 0, 0};
     int res_synth_long[4] = {0, 0, 0, 0};
     int res_synth_short = 0;
+    int res_post = 0;
     std::string err;
     char devname[256];
 };
@@ -337,6 +339,50 @@ extern "C" int nyq_imdct_chain_dev(nyq_ctx *ctx, int shift, const float *d_in, c
         return fail(ctx, NYQ_ERR_INVALID, "nyq_imdct_chain_dev: device pointers must be 16-byte aligned");
     // a chain is a one-channel stream of `len` long frames of size N2 = 120 << (3 - shift)
     return synth_core(ctx, 3 - shift, d_in, nullptr, d_pcm, d_carry0, d_tail_out, d_work, nchains, len, 1);
+}
+
+// ---- post-filter + de-emphasis + interleave ---------------------------------------------
+constexpr int kPostWavesPerBlock = 4;
+
+extern "C" int nyq_celt_post_dev(nyq_ctx *ctx, int LM, const float *d_pcm, const int *d_pf_pitch, const float *d_pf_gain,
+                                 const int *d_pf_tapset, const float *d_pf_state_in, float *d_pf_state_out,
+                                 float *d_hist, float *d_deemph, float *d_out, size_t nstreams, size_t nframes,
+                                 int channels) {
+    if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_celt_post_dev: ctx is NULL");
+    if (LM < 0 || LM > 3) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_post_dev: LM must be 0..3");
+    if (channels < 1 || channels > 255) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_post_dev: channels must be 1..255");
+    if (nstreams == 0 || nframes == 0) return NYQ_OK;
+    if (!d_pcm || !d_pf_pitch || !d_pf_gain || !d_pf_tapset || !d_out)
+        return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_post_dev: NULL pcm/parameters/out");
+    if (d_pf_state_in && d_pf_state_in == d_pf_state_out)
+        return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_post_dev: pf_state_in and pf_state_out must not alias");
+    PostArgs A;
+    A.pcm = d_pcm;
+    A.pf_pitch = d_pf_pitch;
+    A.pf_gain = d_pf_gain;
+    A.pf_tapset = d_pf_tapset;
+    A.pf_state = d_pf_state_in;
+    A.pf_state_out = d_pf_state_out;
+    A.hist = d_hist;
+    A.deemph = d_deemph;
+    A.out = d_out;
+    A.nstreams = (long)nstreams;
+    A.nframes = (long)nframes;
+    A.channels = channels;
+    const size_t nsc = nstreams * (size_t)channels;
+    if (ctx->res_post == 0) {
+        int per_cu = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, celt_post_kernel<kPostWavesPerBlock>,
+                                                                    kWave * kPostWavesPerBlock, 0);
+        if (e != hipSuccess || per_cu < 1) per_cu = 1;
+        ctx->res_post = per_cu * ctx->cus;
+    }
+    const size_t need = (nsc + kPostWavesPerBlock - 1) / kPostWavesPerBlock;
+    const unsigned grid = (unsigned)(need < (size_t)ctx->res_post ? need : (size_t)ctx->res_post);
+    hipLaunchKernelGGL((celt_post_kernel<kPostWavesPerBlock>), dim3(grid), dim3(kWave * kPostWavesPerBlock), 0,
+                       ctx->stream, A, LM, ctx->d_window);
+    NYQ_HIP(ctx, hipGetLastError());
+    return NYQ_OK;
 }
 
 // ---- host-buffer variants ---------------------------------------------------------

@@ -20,8 +20,11 @@ Writes DATA only (inputs + expected outputs):
   real_opus_frames.npz                REAL data: freq[] / isTransient / out_syn of frames 64..127 of
                                       test_data/short.opus as the reference decoder itself computed
                                       them (NyquistIO::Load with the recording tap), the transient
-                                      maps of short.opus and sb-reverie.opus, and the end-to-end
-                                      sample counts / checksums (examples/src/Main.cpp:137-154)
+                                      maps of short.opus and sb-reverie.opus, the end-to-end sample
+                                      counts / checksums (examples/src/Main.cpp:137-154); and for the
+                                      same frames the post-filter parameters and state, the filtered
+                                      history, the de-emphasis memory and the FINAL decoded PCM
+                                      (AudioData::samples) -- the whole freq[] -> PCM chain
 Everything is seeded; re-running reproduces the files bit for bit.
 """
 import os
@@ -175,19 +178,60 @@ def main():
             subprocess.run([os.path.join(ROOT, "oracle", "_ref", "ref_capture"), f"{REFDATA}/{name}", out,
                             str(max_frames)], check=True, stdout=subprocess.DEVNULL)
             b = open(out, "rb").read()
+            p = open(out + ".post", "rb").read()
         _, ch, frames, ncalls = struct.unpack("<4i", b[:16])
         (fsum,) = struct.unpack("<f", b[16:20])
         (nsamp,) = struct.unpack("<q", b[20:28])
         flags = np.frombuffer(b[28:28 + frames], np.uint8).copy()
         pay = np.frombuffer(b[28 + frames:], np.float32).reshape(frames, ch, 1980)
+        # post-filter calls: per LM=3 frame and channel one N=120 call and one N=840 call
+        ncomb, _ = struct.unpack("<2i", p[:8])
+        off, comb = 8, []
+        for _k in range(ncomb):
+            iv = struct.unpack("<5i", p[off:off + 20])
+            fv = struct.unpack("<2f", p[off + 20:off + 28])
+            (hh,) = struct.unpack("<i", p[off + 28:off + 32])
+            off += 32
+            hist = None
+            if hh:
+                hist = np.frombuffer(p[off:off + 1088 * 4], np.float32).copy()
+                off += 1088 * 4
+            comb.append(dict(T0=iv[0], T1=iv[1], N=iv[2], ts0=iv[3], ts1=iv[4], g0=fv[0], g1=fv[1], hist=hist))
+        (npcm,) = struct.unpack("<q", p[off:off + 8])
+        final = np.frombuffer(p[off + 8:], np.float32).reshape(-1, ch).copy()
+        raw = open(f"{REFDATA}/{name}", "rb").read()
+        h = raw.find(b"OpusHead")
+        _v, _c, preskip, _r, gain, _fam = struct.unpack("<BBHIhB", raw[h + 8:h + 19])
+        assert gain == 0
         return dict(channels=ch, flags=flags, freq=pay[:, :, :960].copy(), out=pay[:, :, 960:].copy(),
-                    sum=fsum, samples=nsamp, calls=ncalls)
+                    sum=fsum, samples=nsamp, calls=ncalls, comb=comb, final=final, preskip=preskip)
 
     sh_ = capture("short.opus", 100000)
     lo, hi = 64, 128                                  # 64 frames incl. transient frames 73, 97, 123, 124
     rv = capture("sb-reverie.opus", 100000)
+    # post-filter parameters of frame f = second call (N=840) of channel 0: (T1, g1, tapset1); the state
+    # before frame lo = the arguments of its first call; filtered history and de-emphasis memory before
+    # frame lo; final PCM = AudioData::samples (pre-skip removed by opusfile).
+    cb, ch_ = sh_["comb"], sh_["channels"]
+    first = lambda f, c: cb[(f * ch_ + c) * 2]
+    second = lambda f, c: cb[(f * ch_ + c) * 2 + 1]
+    pf_pitch = np.array([second(f, 0)["T1"] for f in range(lo, hi)], np.int32)
+    pf_gain = np.array([second(f, 0)["g1"] for f in range(lo, hi)], np.float32)
+    pf_tapset = np.array([second(f, 0)["ts1"] for f in range(lo, hi)], np.int32)
+    a = first(lo, 0)
+    z_ = first(hi, 0)
+    pf_state_in = np.array([a["T0"], a["T1"], a["g0"], a["g1"], a["ts0"], a["ts1"]], np.float32)
+    pf_state_out = np.array([z_["T0"], z_["T1"], z_["g0"], z_["g1"], z_["ts0"], z_["ts1"]], np.float32)
+    hist_in = np.stack([first(lo, c)["hist"] for c in range(ch_)])
+    ps = sh_["preskip"]
+    final = sh_["final"][lo * 960 - ps: hi * 960 - ps].copy()           # [64*960][2]
+    deemph_in = (np.float32(0.85000610) * (sh_["final"][lo * 960 - ps - 1] * np.float32(32768.0))).astype(np.float32)
+    deemph_out = (np.float32(0.85000610) * (sh_["final"][hi * 960 - ps - 1] * np.float32(32768.0))).astype(np.float32)
     np.savez_compressed(
         f"{OUT}/real_opus_frames.npz",
+        pf_pitch=pf_pitch[None], pf_gain=pf_gain[None], pf_tapset=pf_tapset[None], pf_state_in=pf_state_in[None],
+        pf_state_out=pf_state_out[None], hist_in=hist_in[None], deemph_in=deemph_in, deemph_out=deemph_out,
+        final=final[None], preskip=np.int64(ps),
         freq=sh_["freq"][lo:hi][None], transient=sh_["flags"][lo:hi][None],
         state_in=sh_["out"][lo - 1, :, 960:].copy(),              # raw tail of frame lo-1 = carry of frame lo
         pcm=sh_["out"][lo:hi, :, :960].transpose(1, 0, 2).reshape(1, 2, -1).copy(),

@@ -558,6 +558,144 @@ int nyq_oracle_celt_synth(int LM, const float *freq, const unsigned char *transi
     return 0;
 }
 
+/* ---- post-filter and de-emphasis (the steps right after the IMDCT) ---------------------- */
+
+/* comb_filter_const (float build: MULT16_32_Q15(a,b) = a*b).  Two variants exist in the
+ * reference: the portable one, celt.c:87-110, sums left to right; on x86 (any gcc build there
+ * defines __SSE__, pitch.h:40-41) celt/x86/pitch_sse.h:104-150 overrides it and adds the two
+ * outer tap pairs as a partial sum first.  The reference build this oracle is pinned against
+ * (oracle/_ref, x86-64) runs the SSE variant, so that association is the default here;
+ * nyq_oracle_set_comb_portable(1) selects the portable order.  They differ by <= 1 ulp. */
+static int g_comb_portable = 0;
+void nyq_oracle_set_comb_portable(int on) { g_comb_portable = on; }
+
+static void nq_comb_const(float *y, const float *x, int T, int N, float g10, float g11, float g12)
+{
+    float x0, x1, x2, x3, x4;
+    int i;
+    x4 = x[-T - 2];
+    x3 = x[-T - 1];
+    x2 = x[-T];
+    x1 = x[-T + 1];
+    for (i = 0; i < N; i++) {
+        x0 = x[i - T + 2];
+        if (g_comb_portable) {
+            y[i] = x[i] + g10 * x2 + g11 * (x1 + x3) + g12 * (x0 + x4);
+        } else {
+            float part = g11 * (x3 + x1) + g12 * (x4 + x0);
+            y[i] = (x[i] + g10 * x2) + part;
+        }
+        x4 = x3; x3 = x2; x2 = x1; x1 = x0;
+    }
+}
+
+/* comb_filter, celt.c:114-172: cross-fade from (T0,g0,tapset0) to (T1,g1,tapset1) over the
+ * first `overlap` samples with the squared window, then the constant filter.  x == y in the
+ * decoder (in place on out_syn), so x[i-T] are already-filtered samples. */
+void nyq_oracle_comb_filter(float *y, float *x, int T0, int T1, int N, float g0, float g1,
+                            int tapset0, int tapset1, int overlap)
+{
+    static const float gains[3][3] = {
+        {0.3066406250f, 0.2170410156f, 0.1296386719f},
+        {0.4638671875f, 0.2680664062f, 0.f},
+        {0.7998046875f, 0.1000976562f, 0.f}};
+    float g00, g01, g02, g10, g11, g12, x0, x1, x2, x3, x4;
+    const float *window;
+    int i;
+    nq_need_init();
+    window = g_window;
+    if (g0 == 0 && g1 == 0) {
+        if (x != y) memmove(y, x, sizeof(float) * (size_t)N);
+        return;
+    }
+    g00 = g0 * gains[tapset0][0];
+    g01 = g0 * gains[tapset0][1];
+    g02 = g0 * gains[tapset0][2];
+    g10 = g1 * gains[tapset1][0];
+    g11 = g1 * gains[tapset1][1];
+    g12 = g1 * gains[tapset1][2];
+    x1 = x[-T1 + 1];
+    x2 = x[-T1];
+    x3 = x[-T1 - 1];
+    x4 = x[-T1 - 2];
+    for (i = 0; i < overlap; i++) {
+        float f;
+        x0 = x[i - T1 + 2];
+        f = window[i] * window[i];
+        y[i] = x[i]
+             + ((1.0f - f) * g00) * x[i - T0]
+             + ((1.0f - f) * g01) * (x[i - T0 + 1] + x[i - T0 - 1])
+             + ((1.0f - f) * g02) * (x[i - T0 + 2] + x[i - T0 - 2])
+             + (f * g10) * x2
+             + (f * g11) * (x1 + x3)
+             + (f * g12) * (x0 + x4);
+        x4 = x3; x3 = x2; x2 = x1; x1 = x0;
+    }
+    if (g1 == 0) {
+        if (x != y) memmove(y + overlap, x + overlap, sizeof(float) * (size_t)(N - overlap));
+        return;
+    }
+    nq_comb_const(y + i, x + i, T1, N - i, g10, g11, g12);
+}
+
+/* The post-filter and de-emphasis of celt_decode_with_ec (celt_decoder_clean.c:658-680, 723;
+ * deemphasis :192-256, float build, downsample 1) over frame sequences.
+ *   pcm     [nstreams*channels] rows of `pitch` floats; each row = `pre` floats of filtered
+ *           history (>= 1026) followed by nframes*N IMDCT output samples; filtered in place
+ *   pf_pitch/pf_gain/pf_tapset [nstreams][nframes]: the post-filter parameters decoded from
+ *           each frame's bitstream (postfilter_pitch, postfilter_gain, postfilter_tapset)
+ *   pf_state [nstreams][6] in/out: period_old, period, tapset_old, tapset (as floats), gain_old, gain
+ *           -> layout {period_old, period, gain_old, gain, tapset_old, tapset}
+ *   deemph_mem [nstreams*channels] in/out: preemph_memD
+ *   out     [nstreams][nframes*N][channels] interleaved float PCM in [-1,1) (AudioData layout)
+ */
+int nyq_oracle_celt_post(int LM, float *pcm, long pitch, long pre, const int *pf_pitch, const float *pf_gain,
+                         const int *pf_tapset, float *pf_state, float *deemph_mem, float *out,
+                         long nstreams, long nframes, int channels)
+{
+    const long N = 120L << LM;
+    const float coef0 = 0.85000610f;      /* mode->preemph[0], static_modes_float.h:582 */
+    long s;
+    if (LM < 0 || LM > 3 || pre < 1026) return -1;
+    nq_need_init();
+    for (s = 0; s < nstreams; s++) {
+        int T_old = (int)pf_state[6 * s + 0], T_cur = (int)pf_state[6 * s + 1];
+        float g_old = pf_state[6 * s + 2], g_cur = pf_state[6 * s + 3];
+        int ts_old = (int)pf_state[6 * s + 4], ts_cur = (int)pf_state[6 * s + 5];
+        long f;
+        int c;
+        for (f = 0; f < nframes; f++) {
+            const int T_new = pf_pitch[s * nframes + f];
+            const float g_new = pf_gain[s * nframes + f];
+            const int ts_new = pf_tapset[s * nframes + f];
+            if (T_cur < 15) T_cur = 15;            /* IMAX(.., COMBFILTER_MINPERIOD), :661-662 */
+            if (T_old < 15) T_old = 15;
+            for (c = 0; c < channels; c++) {
+                float *syn = pcm + (s * channels + c) * pitch + pre + f * N;
+                long j;
+                float m = deemph_mem[s * channels + c];
+                nyq_oracle_comb_filter(syn, syn, T_old, T_cur, 120, g_old, g_cur, ts_old, ts_cur, NQ_OVERLAP);
+                if (LM != 0)
+                    nyq_oracle_comb_filter(syn + 120, syn + 120, T_cur, T_new, (int)N - 120, g_cur, g_new, ts_cur,
+                                           ts_new, NQ_OVERLAP);
+                for (j = 0; j < N; j++) {              /* deemphasis :243-248 */
+                    float tmp = syn[j] + m + 1e-30f;
+                    m = coef0 * tmp;
+                    out[((s * nframes + f) * N + j) * channels + c] = tmp * (1 / 32768.f);
+                }
+                deemph_mem[s * channels + c] = m;
+            }
+            T_old = T_cur; g_old = g_cur; ts_old = ts_cur;      /* :672-677 */
+            T_cur = T_new; g_cur = g_new; ts_cur = ts_new;
+            if (LM != 0) { T_old = T_cur; g_old = g_cur; ts_old = ts_cur; }   /* :678-683 */
+        }
+        pf_state[6 * s + 0] = (float)T_old; pf_state[6 * s + 1] = (float)T_cur;
+        pf_state[6 * s + 2] = g_old;        pf_state[6 * s + 3] = g_cur;
+        pf_state[6 * s + 4] = (float)ts_old; pf_state[6 * s + 5] = (float)ts_cur;
+    }
+    return 0;
+}
+
 int nyq_oracle_max_threads(void)
 {
 #ifdef _OPENMP

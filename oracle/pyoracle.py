@@ -55,6 +55,8 @@ class Oracle:
         L.nyq_oracle_imdct_chain.argtypes = [C.c_int, _f32p, C.c_void_p, _f32p, C.c_void_p, C.c_long]
         L.nyq_oracle_celt_synth.argtypes = [C.c_int, _f32p, C.c_void_p, _f32p, C.c_void_p, C.c_long, C.c_long,
                                             C.c_int, C.c_int]
+        L.nyq_oracle_celt_post.argtypes = [C.c_int, _f32p, C.c_long, C.c_long, _i32p, _f32p, _i32p, _f32p, _f32p,
+                                           _f32p, C.c_long, C.c_long, C.c_int]
         if tables is None:
             L.nyq_oracle_init_default()
         else:
@@ -145,6 +147,26 @@ class Oracle:
         rc = self.lib.nyq_oracle_celt_synth(lm, freq.reshape(-1), _opt(tr), pcm.reshape(-1), _opt(st), ns, nf, ch, nthreads)
         assert rc == 0
         return pcm, st
+
+
+    def celt_post(self, lm, pcm, pre, pf_pitch, pf_gain, pf_tapset, pf_state=None, deemph=None):
+        """Post-filter + de-emphasis over frame sequences (nyq_oracle_celt_post).
+        pcm [ns][ch][pre + nf*N] (history then IMDCT output); returns
+        (out [ns][nf*N][ch], pcm_filtered, pf_state_out [ns][6], deemph_out [ns*ch])."""
+        n = 120 << lm
+        pcm = np.ascontiguousarray(pcm, np.float32).copy()
+        ns, ch, pitch = pcm.shape
+        nf = (pitch - pre) // n
+        pp = np.ascontiguousarray(pf_pitch, np.int32).reshape(ns, nf)
+        pg = np.ascontiguousarray(pf_gain, np.float32).reshape(ns, nf)
+        pt = np.ascontiguousarray(pf_tapset, np.int32).reshape(ns, nf)
+        st = np.zeros((ns, 6), np.float32) if pf_state is None else np.ascontiguousarray(pf_state, np.float32).reshape(ns, 6).copy()
+        dm = np.zeros(ns * ch, np.float32) if deemph is None else np.ascontiguousarray(deemph, np.float32).reshape(ns * ch).copy()
+        out = np.empty((ns, nf * n, ch), np.float32)
+        rc = self.lib.nyq_oracle_celt_post(lm, pcm.reshape(-1), pitch, pre, pp.reshape(-1), pg.reshape(-1), pt.reshape(-1),
+                                           st.reshape(-1), dm, out.reshape(-1), ns, nf, ch)
+        assert rc == 0
+        return out, pcm, st, dm
 
 
 def ref_available():

@@ -30,12 +30,22 @@ typedef struct {
 void nyq_tap_start(long max_calls);
 long nyq_tap_count(void);
 const nyq_tap_call *nyq_tap_get(long i);
+typedef struct {
+    float *y;
+    int T0, T1, N, tapset0, tapset1;
+    float g0, g1;
+    float *hist;
+} nyq_comb_call;
+void nyq_comb_tap_start(long max_calls);
+long nyq_comb_tap_count(void);
+const nyq_comb_call *nyq_comb_tap_get(long i);
 }
 
 int main(int argc, char **argv) {
     if (argc < 3) { std::fprintf(stderr, "usage: ref_capture file.opus out.bin [max_frames]\n"); return 2; }
     const long max_frames = argc > 3 ? std::atol(argv[3]) : 64;
     nyq_tap_start(max_frames * 16 + 64);
+    nyq_comb_tap_start(max_frames * 4 + 64);
     nqr::NyquistIO loader;
     nqr::AudioData data;
     loader.Load(&data, std::string(argv[1]));
@@ -90,6 +100,30 @@ int main(int argc, char **argv) {
     std::fwrite(flags.data(), 1, flags.size(), f);
     std::fwrite(payload.data(), sizeof(float), payload.size(), f);
     std::fclose(f);
+    // <out>.post: post-filter calls (2 per channel per LM=3 frame: N=120 then N=840) and the decoded PCM
+    //   int32 ncomb, channels; per call: int32 T0,T1,N,tapset0,tapset1; float g0,g1; int32 has_hist; [1088 floats]
+    //   then int64 nsamples and the interleaved float PCM of AudioData::samples
+    {
+        std::string pp = std::string(argv[2]) + ".post";
+        FILE *g = std::fopen(pp.c_str(), "wb");
+        if (!g) return 4;
+        int32_t n = (int32_t)nyq_comb_tap_count(), cc = ch;
+        std::fwrite(&n, 4, 1, g);
+        std::fwrite(&cc, 4, 1, g);
+        for (long k = 0; k < n; k++) {
+            const nyq_comb_call *q = nyq_comb_tap_get(k);
+            int32_t iv[5] = {q->T0, q->T1, q->N, q->tapset0, q->tapset1};
+            float fv[2] = {q->g0, q->g1};
+            int32_t hh = q->hist ? 1 : 0;
+            std::fwrite(iv, sizeof iv, 1, g);
+            std::fwrite(fv, sizeof fv, 1, g);
+            std::fwrite(&hh, 4, 1, g);
+            if (hh) std::fwrite(q->hist, sizeof(float), 1088, g);
+        }
+        std::fwrite(&nsamp, sizeof nsamp, 1, g);
+        std::fwrite(data.samples.data(), sizeof(float), data.samples.size(), g);
+        std::fclose(g);
+    }
     std::printf("%s: channels %d, decoded samples %lld, sum %f, imdct calls recorded %ld, frames written %ld\n", argv[1], ch,
                 (long long)nsamp, sum, ncalls, frames);
     return 0;

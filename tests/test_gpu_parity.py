@@ -347,3 +347,62 @@ def test_config4_thousand_streams_sb_reverie_pattern(ctx, oracle):
     for s in hit:
         wp, _ = oracle.celt_synth(3, freq[s:s + 1].cpu().numpy(), tr_np[s:s + 1], None, nthreads=2)
         assert rel_rms(pcm[s].cpu().numpy(), wp[0]) <= 1e-6, s
+
+
+# ---- post-filter + de-emphasis + interleave (out_syn -> AudioData samples) ----------------------
+def _post_on_gpu(ctx, lm, pcm, pf_pitch, pf_gain, pf_tapset, pf_state, hist, deemph, channels):
+    import torch
+    dev = torch.device("cuda", 0)
+    T = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dt)).to(dev)
+    ns = pf_pitch.shape[0]
+    nf = pf_pitch.shape[1]
+    n = 120 << lm
+    d_pcm = T(pcm, np.float32)
+    d_pp, d_pg, d_pt = T(pf_pitch, np.int32), T(pf_gain, np.float32), T(pf_tapset, np.int32)
+    d_si = T(pf_state, np.float32)
+    d_so = torch.zeros_like(d_si)
+    d_h, d_m = T(hist, np.float32), T(deemph, np.float32)
+    d_out = torch.empty((ns, nf * n, channels), device=dev)
+    torch.cuda.synchronize(dev)
+    ctx.celt_post_dev(lm, d_pcm.data_ptr(), d_pp.data_ptr(), d_pg.data_ptr(), d_pt.data_ptr(), d_si.data_ptr(),
+                      d_so.data_ptr(), d_h.data_ptr(), d_m.data_ptr(), d_out.data_ptr(), ns, nf, channels)
+    ctx.synchronize()
+    return d_out.cpu().numpy(), d_so.cpu().numpy(), d_h.cpu().numpy(), d_m.cpu().numpy()
+
+
+def test_post_chain_on_real_decoder_frames(ctx_ref_tables):
+    """freq[] -> nyq_celt_synth -> nyq_celt_post_dev must give the reference decoder's FINAL PCM
+    (AudioData::samples) for frames 64..127 of test_data/short.opus."""
+    z = np.load(os.path.join(GOLDEN, "real_opus_frames.npz"))
+    pcm, _ = ctx_ref_tables.celt_synth(3, z["freq"], z["transient"], z["state_in"], channels=2)
+    out, pst, hist, dm = _post_on_gpu(ctx_ref_tables, 3, pcm, z["pf_pitch"], z["pf_gain"], z["pf_tapset"],
+                                      z["pf_state_in"], z["hist_in"], z["deemph_in"], 2)
+    assert rel_rms(out, z["final"]) <= TOL
+    assert rel_rms(out, z["final"]) <= 2e-6          # measured level
+    assert np.abs(out - z["final"]).max() <= 2e-6     # samples are in [-1, 1)
+    assert np.array_equal(pst, z["pf_state_out"])
+    assert rel_rms(dm, z["deemph_out"]) <= 1e-5
+
+
+@pytest.mark.parametrize("lm", [3, 2, 1, 0])
+def test_post_vs_oracle_random_parameters(ctx, oracle, lm):
+    ctx.set_tables(*oracle.tables()[:2])
+    rng = np.random.default_rng(70 + lm)
+    n = 120 << lm
+    for ns, nf, ch in ((1, 3, 1), (3, 17, 2), (2, 9, 6)):
+        pcm = (rng.standard_normal((ns, ch, nf * n)) * 300).astype(np.float32)
+        hist = (rng.standard_normal((ns, ch, 1088)) * 300).astype(np.float32)
+        pitch = rng.integers(15, 1023, (ns, nf)).astype(np.int32)
+        pitch[:, ::5] = rng.integers(15, 24, pitch[:, ::5].shape)          # short periods: narrow wave steps
+        gain = (rng.integers(0, 9, (ns, nf)) * 0.09375).astype(np.float32)  # (qg+1)*3/32 or 0 = off
+        gain[:, 1::4] = 0
+        taps = rng.integers(0, 3, (ns, nf)).astype(np.int32)
+        st = np.stack([[rng.integers(15, 1023), rng.integers(15, 1023), 0.28125, 0.375, 1, 2] for _ in range(ns)]).astype(np.float32)
+        dm = (rng.standard_normal(ns * ch) * 100).astype(np.float32)
+        buf = np.concatenate([hist, pcm], axis=2)
+        want, filt, wst, wdm = oracle.celt_post(lm, buf, 1088, pitch, gain, taps, st, dm)
+        out, pst, gh, gdm = _post_on_gpu(ctx, lm, pcm, pitch, gain, taps, st, hist.reshape(ns * ch, 1088), dm, ch)
+        assert rel_rms(out, want) <= 1e-5, (ns, nf, ch)
+        assert np.array_equal(pst, wst)
+        assert rel_rms(gh, filt[:, :, -1088:].reshape(ns * ch, 1088)) <= 1e-5
+        assert rel_rms(gdm, wdm) <= 1e-5

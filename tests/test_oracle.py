@@ -198,3 +198,19 @@ def test_real_decoder_frames_bit_exact(oracle):
     assert int(z["sb_reverie"][0]) == 21472602 and int(float(z["sb_reverie_sum"])) == 403
     assert list(z["sb_reverie"][1:]) == [26764, 11184, 314]       # BASELINE.md section 2 call mix
     assert list(z["short_opus"]) == [421930, 554, 220, 8]
+
+
+def test_real_decoder_post_chain_bit_exact(oracle):
+    """freq[] -> IMDCT -> comb filter -> de-emphasis -> interleaved PCM: the oracle reproduces the
+    reference decoder's final AudioData::samples for frames 64..127 of short.opus bit for bit
+    (comb_filter celt.c:114-172 incl. the x86 association of comb_filter_const, deemphasis
+    celt_decoder_clean.c:192-256, state handling :658-683)."""
+    z = np.load(os.path.join(GOLDEN, "real_opus_frames.npz"))
+    pcm, _ = oracle.celt_synth(3, z["freq"], z["transient"], z["state_in"])
+    buf = np.concatenate([z["hist_in"], pcm], axis=2)
+    out, filt, pst, dm = oracle.celt_post(3, buf, 1088, z["pf_pitch"], z["pf_gain"], z["pf_tapset"],
+                                          z["pf_state_in"], z["deemph_in"])
+    assert np.array_equal(out, z["final"])
+    assert np.array_equal(pst, z["pf_state_out"])
+    assert np.array_equal(dm, z["deemph_out"])
+    assert (z["pf_gain"] > 0).sum() > 30 and (z["pf_gain"] == 0).sum() > 0     # filter on and off both occur
