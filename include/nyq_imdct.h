@@ -139,6 +139,17 @@ int nyq_imdct_chain(nyq_ctx *ctx, int shift, const float *in, const float *carry
                     float *pcm, float *tail_out, size_t nchains, size_t len);
 int nyq_celt_synth(nyq_ctx *ctx, int LM, const float *freq, const unsigned char *transient,
                    float *pcm, float *state, size_t nstreams, size_t nframes, int channels);
+/* freq[] -> interleaved PCM in one call: nyq_celt_synth_dev followed by nyq_celt_post_dev:
+ * everything celt_decode_with_ec does after denormalise_bands (celt_decoder_clean.c:620-723).
+ * Host buffers; layouts as in the two _dev functions; out [nstreams][nframes*N][channels].
+ * `state` (host, in/out, nyq_celt_state_floats() floats) carries the decoders from one call to the
+ * next, e.g. across a change of frame size: [nsc][60] overlap carry, [nsc][1088] filtered history,
+ * [nsc] de-emphasis memory, [nstreams][6] post-filter state (nsc = nstreams*channels).  NULL means
+ * freshly reset decoders and discards the final state. */
+size_t nyq_celt_state_floats(size_t nstreams, int channels);
+int nyq_celt_frames_to_pcm(nyq_ctx *ctx, int LM, const float *freq, const unsigned char *transient,
+                           const int *pf_pitch, const float *pf_gain, const int *pf_tapset,
+                           float *out, float *state, size_t nstreams, size_t nframes, int channels);
 
 /* ---- the reference's operator boundary, kept verbatim ------------------- */
 /* cuda/mdct_cuda.hpp:89-91 (impl mdct_cuda.cu:314-392).  Host pointers, caller-owned.

@@ -22,6 +22,7 @@ EXPORTS = [
     "nyq_ctx_synchronize", "nyq_ctx_set_tables", "nyq_ctx_get_tables", "nyq_ctx_device_info",
     "nyq_ifft_batch_dev", "nyq_imdct_batch_dev", "nyq_imdct_chain_dev",
     "nyq_celt_synth_work_floats", "nyq_celt_synth_dev", "nyq_celt_synth", "nyq_celt_post_dev",
+    "nyq_celt_frames_to_pcm", "nyq_celt_state_floats",
     "nyq_ifft_batch", "nyq_imdct_batch", "nyq_imdct_chain",
     "processMDCTCuda", "processMDCTCudaB1C2", "cleanupCudaBuffers", "printCudaVersion",
 ]
@@ -81,6 +82,9 @@ def load(path=None):
     L.nyq_celt_synth_dev.argtypes = [vp, i, fp, fp, fp, fp, fp, sz, sz, i]
     L.nyq_celt_synth.argtypes = [vp, i, fp, fp, fp, fp, sz, sz, i]
     L.nyq_celt_post_dev.argtypes = [vp, i, fp, fp, fp, fp, fp, fp, fp, fp, fp, sz, sz, i]
+    L.nyq_celt_frames_to_pcm.argtypes = [vp, i, fp, fp, fp, fp, fp, fp, fp, sz, sz, i]
+    L.nyq_celt_state_floats.argtypes = [sz, i]
+    L.nyq_celt_state_floats.restype = sz
     L.nyq_ifft_batch.argtypes = [vp, i, fp, fp, sz]
     L.nyq_imdct_batch.argtypes = [vp, i, fp, fp, fp, fp, sz]
     L.nyq_imdct_chain.argtypes = [vp, i, fp, fp, fp, fp, sz, sz]
@@ -204,6 +208,21 @@ class Context:
         pcm = np.empty((ns, channels, nf * n), np.float32)
         self._ck(self.lib.nyq_celt_synth(self.h, lm, _np(freq), _np(tr), _np(pcm), _np(st), ns, nf, channels))
         return pcm, st
+
+    def celt_frames_to_pcm(self, lm, freq, transient, pf_pitch, pf_gain, pf_tapset, channels, state=None):
+        """freq [ns][nf][ch][N] (+ per-frame flags/parameters [ns][nf]) -> interleaved PCM [ns][nf*N][ch].
+        `state`: float32 array of nyq_celt_state_floats(ns, ch) floats, updated in place (None = fresh)."""
+        n = 120 << lm
+        freq = _f32(freq)
+        ns, nf = freq.shape[0], freq.shape[1]
+        tr = None if transient is None else np.ascontiguousarray(transient, dtype=np.uint8).reshape(ns, nf)
+        pp = np.ascontiguousarray(pf_pitch, dtype=np.int32).reshape(ns, nf)
+        pg = np.ascontiguousarray(pf_gain, dtype=np.float32).reshape(ns, nf)
+        pt = np.ascontiguousarray(pf_tapset, dtype=np.int32).reshape(ns, nf)
+        out = np.empty((ns, nf * n, channels), np.float32)
+        self._ck(self.lib.nyq_celt_frames_to_pcm(self.h, lm, _np(freq), _np(tr), _np(pp), _np(pg), _np(pt), _np(out),
+                                                 _np(state), ns, nf, channels))
+        return out
 
     def celt_synth_work_floats(self, nstreams, nframes, channels):
         return int(self.lib.nyq_celt_synth_work_floats(nstreams, nframes, channels))

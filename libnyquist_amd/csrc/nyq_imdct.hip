@@ -492,6 +492,64 @@ extern "C" int nyq_celt_synth(nyq_ctx *ctx, int LM, const float *freq, const uns
     return NYQ_OK;
 }
 
+extern "C" size_t nyq_celt_state_floats(size_t nstreams, int channels) {
+    const size_t nsc = nstreams * (size_t)(channels > 0 ? channels : 0);
+    return nsc * (NYQ_HALF_OV + kPostHist + 1) + nstreams * 6;
+}
+
+extern "C" int nyq_celt_frames_to_pcm(nyq_ctx *ctx, int LM, const float *freq, const unsigned char *transient,
+                                      const int *pf_pitch, const float *pf_gain, const int *pf_tapset, float *out,
+                                      float *state, size_t nstreams, size_t nframes, int channels) {
+    if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm: ctx is NULL");
+    if (LM < 0 || LM > 3) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm: LM must be 0..3");
+    if (channels < 1 || channels > 255) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm: channels must be 1..255");
+    if (nstreams == 0 || nframes == 0) return NYQ_OK;
+    if (!freq || !pf_pitch || !pf_gain || !pf_tapset || !out)
+        return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm: NULL buffer");
+    NYQ_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t N = (size_t)120 << LM, nsc = nstreams * (size_t)channels, nfr = nstreams * nframes;
+    const size_t n_x = round16f(nsc * nframes * N), n_w = round16f(nyq_celt_synth_work_floats(nstreams, nframes, channels)),
+                 n_p = round16f(nfr), n_t = round16f((nfr + 3) / 4);
+    // state on the device: overlap, hist, deemph, pf in, pf out (each 16-byte aligned)
+    const size_t n_ov = round16f(nsc * NYQ_HALF_OV), n_hi = round16f(nsc * kPostHist), n_de = round16f(nsc),
+                 n_pf = round16f(nstreams * 6);
+    int rc = need_scratch(ctx, (3 * n_x + n_w + 3 * n_p + n_t + n_ov + n_hi + n_de + 2 * n_pf) * sizeof(float));
+    if (rc != NYQ_OK) return rc;
+    float *d_x = ctx->d_scratch, *d_pcm = d_x + n_x, *d_out = d_pcm + n_x, *d_w = d_out + n_x, *d_pg = d_w + n_w;
+    int *d_pp = reinterpret_cast<int *>(d_pg + n_p), *d_pt = d_pp + n_p;
+    unsigned char *d_t = reinterpret_cast<unsigned char *>(d_pt + n_p);
+    float *d_ov = reinterpret_cast<float *>(d_pt + n_p) + n_t, *d_hi = d_ov + n_ov, *d_de = d_hi + n_hi,
+          *d_pfi = d_de + n_de, *d_pfo = d_pfi + n_pf;
+    NYQ_HIP(ctx, hipMemcpyAsync(d_x, freq, nsc * nframes * N * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (transient) NYQ_HIP(ctx, hipMemcpyAsync(d_t, transient, nfr, hipMemcpyHostToDevice, ctx->stream));
+    NYQ_HIP(ctx, hipMemcpyAsync(d_pg, pf_gain, nfr * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    NYQ_HIP(ctx, hipMemcpyAsync(d_pp, pf_pitch, nfr * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    NYQ_HIP(ctx, hipMemcpyAsync(d_pt, pf_tapset, nfr * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    float *h_ov = state, *h_hi = state ? h_ov + nsc * NYQ_HALF_OV : nullptr, *h_de = state ? h_hi + nsc * kPostHist : nullptr,
+          *h_pf = state ? h_de + nsc : nullptr;
+    if (state) {
+        NYQ_HIP(ctx, hipMemcpyAsync(d_ov, h_ov, nsc * NYQ_HALF_OV * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        NYQ_HIP(ctx, hipMemcpyAsync(d_hi, h_hi, nsc * kPostHist * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        NYQ_HIP(ctx, hipMemcpyAsync(d_de, h_de, nsc * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        NYQ_HIP(ctx, hipMemcpyAsync(d_pfi, h_pf, nstreams * 6 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    }
+    rc = nyq_celt_synth_dev(ctx, LM, d_x, transient ? d_t : nullptr, d_pcm, state ? d_ov : nullptr, d_w, nstreams, nframes,
+                            channels);
+    if (rc != NYQ_OK) return rc;
+    rc = nyq_celt_post_dev(ctx, LM, d_pcm, d_pp, d_pg, d_pt, state ? d_pfi : nullptr, state ? d_pfo : nullptr,
+                           state ? d_hi : nullptr, state ? d_de : nullptr, d_out, nstreams, nframes, channels);
+    if (rc != NYQ_OK) return rc;
+    NYQ_HIP(ctx, hipMemcpyAsync(out, d_out, nsc * nframes * N * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (state) {
+        NYQ_HIP(ctx, hipMemcpyAsync(h_ov, d_ov, nsc * NYQ_HALF_OV * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        NYQ_HIP(ctx, hipMemcpyAsync(h_hi, d_hi, nsc * kPostHist * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        NYQ_HIP(ctx, hipMemcpyAsync(h_de, d_de, nsc * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        NYQ_HIP(ctx, hipMemcpyAsync(h_pf, d_pfo, nstreams * 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    NYQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NYQ_OK;
+}
+
 // ---- the reference's operator names (cuda/mdct_cuda.hpp:79-103) --------------------
 static nyq_ctx *g_shim_ctx = nullptr;
 static const float *g_shim_trig = nullptr, *g_shim_window = nullptr;

@@ -1,0 +1,52 @@
+// celt_decoder.hpp -- the bit-serial half of a CELT frame: range decoding, band energies, bit
+// allocation, PVQ shape decoding, folding/anti-collapse and denormalisation -- everything
+// celt_decode_with_ec (third_party/opus/celt/celt_decoder_clean.c:353-731) does BEFORE
+// compute_inv_mdcts.  The output is the frame's freq[] plus the few scalars the GPU stages need
+// (transient flag, post-filter parameters); the IMDCT, post-filter and de-emphasis then run batched
+// on the MI355X through libnyq_imdct.so.  One CeltDecoder per Opus stream (it carries the inter-frame
+// energy prediction state).
+#pragma once
+#include <cstdint>
+
+#include "celt_mode.hpp"
+#include "range_decoder.hpp"
+
+namespace nyq_host {
+
+struct CeltFrame {
+    int LM = 3;                 // frame size = 120 << LM samples
+    int channels = 2;           // CC: channels of the decoder / of freq[]
+    bool transient = false;     // isTransient: 2^LM interleaved short blocks in freq[]
+    bool silence = false;
+    int pfPitch = 0;            // postfilter_pitch   (celt_decoder_clean.c:492-509)
+    float pfGain = 0.f;         // postfilter_gain
+    int pfTapset = 0;           // postfilter_tapset
+    uint32_t rangeFinal = 0;    // dec->rng after the frame (st->rng), the spec's conformance hook
+    // freq[channels][120 << LM] is written to the caller's buffer by CeltDecoder::decode()
+};
+
+class CeltDecoder {
+public:
+    explicit CeltDecoder(int channels);
+    void reset();                                   // OPUS_RESET_STATE, celt_decoder_clean.c:846-859
+    void setEndBand(int end) { end_ = end; }        // CELT_SET_END_BAND (bandwidth from the TOC)
+    void setStreamChannels(int c) { streamChannels_ = c; }   // CELT_SET_CHANNELS (stereo flag of the TOC)
+    // Decode one CELT frame of `frameSize` samples per channel from data[0..len).
+    // freq: channels() * frameSize floats, channel-major (celt_decoder_clean.c:620-652).
+    // Returns 0, or a negative OPUS_* style code (-1 bad arg, -3 internal, -4 corrupt).
+    int decode(const uint8_t *data, int len, int frameSize, float *freq, CeltFrame &info);
+    int channels() const { return channels_; }
+
+private:
+    const CeltMode &m_;
+    int channels_;            // CC
+    int streamChannels_;      // C
+    int start_ = 0, end_ = kBands;
+    uint32_t rng_ = 0;
+    float oldBandE_[2 * kBands];
+    float oldLogE_[2 * kBands];
+    float oldLogE2_[2 * kBands];
+    float backgroundLogE_[2 * kBands];
+};
+
+}  // namespace nyq_host

@@ -1,0 +1,150 @@
+// nqr_surface.cpp -- NyquistIO / OpusDecoder of the plugin surface (reference: src/Common.cpp:33-219,
+// src/OpusDecoder.cpp:39-183), backed by the batched MI355X decode path.
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+
+#include "batch_decoder.hpp"
+#include "libnyquist/Decoders.h"
+
+using namespace nqr;
+
+namespace {
+const int OPUS_SAMPLE_RATE = 48000;               // src/OpusDecoder.cpp:37
+
+void fill(AudioData *d, nyq_host::DecodedStream &s) {
+    if (!s.error.empty()) throw std::runtime_error(s.error);
+    d->sampleRate = OPUS_SAMPLE_RATE;              // src/OpusDecoder.cpp:75-79
+    d->channelCount = s.channels;
+    d->sourceFormat = MakeFormatForBits(32, true, false);
+    d->lengthSeconds = double(uint64_t(s.totalSamples / OPUS_SAMPLE_RATE));   // integer division, :160
+    d->frameSize = (size_t)s.channels * GetFormatBitsPerSample(d->sourceFormat);
+    d->samples = std::move(s.pcm);                 // samples.size() == op_pcm_total * channels
+    if (d->samples.empty()) throw std::runtime_error("could not read any data");
+}
+
+int deviceFromEnv() {
+    const char *e = std::getenv("NYQ_DEVICE");
+    return e ? std::atoi(e) : 0;
+}
+}  // namespace
+
+int nqr::GetFormatBitsPerSample(PCMFormat f) {
+    switch (f) {
+    case PCM_U8: case PCM_S8: return 8;
+    case PCM_16: return 16;
+    case PCM_24: return 24;
+    case PCM_32: case PCM_FLT: return 32;
+    case PCM_64: case PCM_DBL: return 64;
+    default: return 0;
+    }
+}
+
+PCMFormat nqr::MakeFormatForBits(int bits, bool floatingPt, bool isSigned) {
+    switch (bits) {
+    case 8: return isSigned ? PCM_S8 : PCM_U8;
+    case 16: return PCM_16;
+    case 24: return PCM_24;
+    case 32: return floatingPt ? PCM_FLT : PCM_32;
+    case 64: return floatingPt ? PCM_DBL : PCM_64;
+    default: return PCM_END;
+    }
+}
+
+NyquistFileBuffer nqr::ReadFile(const std::string &pathToFile) {
+    FILE *f = std::fopen(pathToFile.c_str(), "rb");
+    if (!f) throw std::runtime_error("file not found");
+    std::fseek(f, 0, SEEK_END);
+    const long len = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    NyquistFileBuffer b;
+    b.buffer.resize(len > 0 ? (size_t)len : 0);
+    const size_t got = b.buffer.empty() ? 0 : std::fread(b.buffer.data(), 1, b.buffer.size(), f);
+    std::fclose(f);
+    if (got != b.buffer.size()) throw std::runtime_error("error reading file or file too small");
+    b.size = got;
+    return b;
+}
+
+void nqr::OpusDecoder::LoadFromPath(AudioData *data, const std::string &path) {
+    auto fileBuffer = nqr::ReadFile(path);
+    LoadFromBuffer(data, fileBuffer.buffer);
+}
+
+void nqr::OpusDecoder::LoadFromBuffer(AudioData *data, const std::vector<uint8_t> &memory) {
+    nyq_host::BatchOpusDecoder dec(deviceFromEnv());
+    std::vector<nyq_host::DecodedStream> out;
+    dec.decode({&memory}, out, nullptr, 1);
+    fill(data, out[0]);
+}
+
+std::vector<std::string> nqr::OpusDecoder::GetSupportedFileExtensions() { return {"opus"}; }
+
+void nqr::BatchLoad(std::vector<AudioData> &out, const std::vector<std::vector<uint8_t>> &buffers, int device) {
+    nyq_host::BatchOpusDecoder dec(device);
+    std::vector<const std::vector<uint8_t> *> files;
+    for (const auto &b : buffers) files.push_back(&b);
+    std::vector<nyq_host::DecodedStream> dec_out;
+    dec.decode(files, dec_out);
+    out.resize(buffers.size());
+    for (size_t i = 0; i < buffers.size(); i++) fill(&out[i], dec_out[i]);
+}
+
+NyquistIO::NyquistIO() { BuildDecoderTable(); }
+NyquistIO::~NyquistIO() {}
+
+void NyquistIO::Load(AudioData *data, const std::string &path) {
+    if (!IsFileSupported(path)) throw UnsupportedExtensionEx();
+    if (!decoderTable.size()) throw std::runtime_error("No available decoders.");
+    auto decoder = GetDecoderForExtension(ParsePathForExtension(path));
+    try {
+        decoder->LoadFromPath(data, path);
+    } catch (const std::exception &e) {
+        std::cerr << "NyquistIO::Load(" << path << ") caught internal exception: " << e.what() << std::endl;
+        throw;
+    }
+}
+
+void NyquistIO::Load(AudioData *data, const std::vector<uint8_t> &buffer) {
+    // magic sniffing (src/Common.cpp:66-141): of the formats the reference recognises only Ogg Opus is served here
+    if (buffer.size() >= 36 && std::memcmp(buffer.data(), "OggS", 4) == 0) {
+        const size_t lim = std::min<size_t>(buffer.size(), 4096);
+        for (size_t i = 0; i + 8 <= lim; i++)
+            if (std::memcmp(buffer.data() + i, "OpusHead", 8) == 0) return Load(data, "opus", buffer);
+    }
+    throw UnsupportedExtensionEx();
+}
+
+void NyquistIO::Load(AudioData *data, const std::string &extension, const std::vector<uint8_t> &buffer) {
+    if (decoderTable.find(extension) == decoderTable.end()) throw UnsupportedExtensionEx();
+    auto decoder = GetDecoderForExtension(extension);
+    try {
+        decoder->LoadFromBuffer(data, buffer);
+    } catch (const std::exception &e) {
+        std::cerr << "caught internal loading exception: " << e.what() << std::endl;
+        throw;
+    }
+}
+
+bool NyquistIO::IsFileSupported(const std::string &path) const {
+    return decoderTable.find(ParsePathForExtension(path)) != decoderTable.end();
+}
+
+std::string NyquistIO::ParsePathForExtension(const std::string &path) const {
+    const size_t dot = path.find_last_of(".");
+    return dot != std::string::npos ? path.substr(dot + 1) : std::string("");
+}
+
+std::shared_ptr<BaseDecoder> NyquistIO::GetDecoderForExtension(const std::string &ext) {
+    if (!decoderTable.size()) throw std::runtime_error("No available decoders.");
+    return decoderTable[ext];
+}
+
+void NyquistIO::AddDecoderToTable(std::shared_ptr<nqr::BaseDecoder> decoder) {
+    for (const auto &ext : decoder->GetSupportedFileExtensions()) {
+        if (decoderTable.count(ext) >= 1) throw std::runtime_error("decoder already exists for extension");
+        decoderTable.insert(DecoderPair(ext, decoder));
+    }
+}
+
+void NyquistIO::BuildDecoderTable() { AddDecoderToTable(std::make_shared<OpusDecoder>()); }

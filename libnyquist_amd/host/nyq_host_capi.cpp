@@ -1,0 +1,126 @@
+// nyq_host_capi.cpp -- plain-C entry points of libnyquist_host.so used by the tests (ctypes) and
+// by tools: the CPU entropy stage on its own, and the mode tables for cross-checking.
+#include <cstring>
+#include <vector>
+
+#include "batch_decoder.hpp"
+#include "celt_decoder.hpp"
+#include "libnyquist/Decoders.h"
+#include "opus_stream.hpp"
+
+using namespace nyq_host;
+
+extern "C" {
+
+// cache tables of the 48 kHz mode as this library computed them (tests compare them with the
+// reference's static tables): returns sizes through the out parameters
+int nyqh_mode_tables(short *logN21, short *cacheIndex105, unsigned char *cacheBits, int *cacheBitsLen,
+                     unsigned char *cacheCaps168) {
+    const CeltMode &m = mode48k();
+    std::memcpy(logN21, m.logN, sizeof m.logN);
+    if ((int)m.cacheIndex.size() != 105 || (int)m.cacheCaps.size() != 168) return -1;
+    std::memcpy(cacheIndex105, m.cacheIndex.data(), 105 * sizeof(short));
+    *cacheBitsLen = (int)m.cacheBits.size();
+    std::memcpy(cacheBits, m.cacheBits.data(), m.cacheBits.size());
+    std::memcpy(cacheCaps168, m.cacheCaps.data(), 168);
+    return 0;
+}
+
+// Entropy-decode an Ogg Opus file held in memory up to freq[] (no GPU involved).
+// Outputs for at most max_frames frames: freq [frames][channels][frame_size] (all frames must share
+// one frame size), flags [frames][4] = {transient, pf_pitch, pf_tapset, LM}, pf_gain [frames],
+// range [frames] (final range coder state per frame).  info[0..5] = channels, pre_skip, frames,
+// frame_size, last_granule (low 32 bits), packets.
+// Returns 0, or <0: -10 malformed container, -11 unsupported packet (not CELT-only / mapping family),
+// -12 mixed frame sizes, otherwise the CELT decoder's error.
+int nyqh_decode_to_freq(const unsigned char *file, long size, long max_frames, float *freq, int *flags, float *pf_gain,
+                        unsigned *range, long *info) {
+    OggOpusFile f;
+    try {
+        f = parseOggOpus(file, (size_t)size);
+    } catch (const std::exception &) {
+        return -10;
+    }
+    if (f.head.mappingFamily != 0 || f.head.channels < 1 || f.head.channels > 2) return -11;
+    const int CC = f.head.channels;
+    CeltDecoder dec(CC);
+    long nframes = 0;
+    int frameSize = 0;
+    for (const auto &pkt : f.packets) {
+        PacketFrames pf;
+        if (!parseOpusPacket(pkt.data(), (int)pkt.size(), pf)) return -10;
+        if (pf.config < 16) return -11;
+        dec.setEndBand(pf.bandwidthEnd);
+        dec.setStreamChannels(pf.stereo ? 2 : 1);
+        for (const auto &fr : pf.frames) {
+            if (nframes >= max_frames) goto done;
+            if (frameSize == 0) frameSize = pf.frameSize;
+            if (pf.frameSize != frameSize) goto done;   // a different frame size ends this fixed-shape dump
+            CeltFrame info1;
+            const int rc = dec.decode(fr.first, fr.second, pf.frameSize, freq + (size_t)nframes * CC * frameSize, info1);
+            if (rc < 0) return rc;
+            flags[4 * nframes + 0] = info1.transient;
+            flags[4 * nframes + 1] = info1.pfPitch;
+            flags[4 * nframes + 2] = info1.pfTapset;
+            flags[4 * nframes + 3] = info1.LM;
+            pf_gain[nframes] = info1.pfGain;
+            range[nframes] = info1.rangeFinal;
+            nframes++;
+        }
+    }
+done:
+    info[0] = CC;
+    info[1] = f.head.preSkip;
+    info[2] = nframes;
+    info[3] = frameSize;
+    info[4] = (long)f.lastGranule;
+    info[5] = (long)f.packets.size();
+    return 0;
+}
+
+// NyquistIO::Load through the plugin surface (what examples/src/Main.cpp:86-154 does): returns the number
+// of float samples (channels * frames) or <0 on exception; info = {channelCount, sampleRate, frameSize,
+// lengthSeconds}.  Call twice: first with samples == NULL to learn the size.
+long nyqh_nyquistio_load(const char *path, float *samples, long capacity, long *info) {
+    try {
+        nqr::NyquistIO loader;
+        nqr::AudioData data;
+        loader.Load(&data, std::string(path));
+        info[0] = data.channelCount;
+        info[1] = data.sampleRate;
+        info[2] = (long)data.frameSize;
+        info[3] = (long)data.lengthSeconds;
+        if (samples && capacity >= (long)data.samples.size())
+            std::memcpy(samples, data.samples.data(), data.samples.size() * sizeof(float));
+        return (long)data.samples.size();
+    } catch (const nqr::UnsupportedExtensionEx &) {
+        return -2;
+    } catch (const std::exception &) {
+        return -1;
+    }
+}
+
+// `count` copies of one file decoded as ONE batch (config 4 shape: many concurrent streams).
+// Copies the first and the last decoded stream out for checking; stats = {cpu_s, gpu_s, frames, threads}.
+long nyqh_batch_decode(const unsigned char *file, long size, long count, int threads, float *first, float *last,
+                       long capacity, double *stats) {
+    try {
+        std::vector<uint8_t> buf(file, file + size);
+        std::vector<const std::vector<uint8_t> *> files((size_t)count, &buf);
+        nyq_host::BatchOpusDecoder dec(0);
+        std::vector<nyq_host::DecodedStream> out;
+        nyq_host::BatchStats st;
+        dec.decode(files, out, &st, threads);
+        for (auto &o : out)
+            if (!o.error.empty()) return -1;
+        stats[0] = st.cpuSeconds; stats[1] = st.gpuSeconds; stats[2] = (double)st.frames; stats[3] = st.threads;
+        const long nsamp = (long)out[0].pcm.size();
+        if (first && capacity >= nsamp) std::memcpy(first, out[0].pcm.data(), nsamp * sizeof(float));
+        if (last && capacity >= nsamp) std::memcpy(last, out.back().pcm.data(), nsamp * sizeof(float));
+        return nsamp;
+    } catch (const std::exception &) {
+        return -1;
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,161 @@
+// opus_stream.cpp -- see opus_stream.hpp.
+#include "opus_stream.hpp"
+
+#include <cstring>
+
+namespace nyq_host {
+
+namespace {
+uint32_t rd32(const uint8_t *p) { return p[0] | p[1] << 8 | p[2] << 16 | (uint32_t)p[3] << 24; }
+int64_t rd64(const uint8_t *p) { return (int64_t)((uint64_t)rd32(p) | (uint64_t)rd32(p + 4) << 32); }
+}  // namespace
+
+OggOpusFile parseOggOpus(const uint8_t *data, size_t size) {
+    OggOpusFile f;
+    std::vector<uint8_t> pending;     // packet continued across pages
+    bool havePending = false;
+    int packetIndex = 0;
+    size_t pos = 0;
+    uint32_t serial = 0;
+    bool haveSerial = false;
+    while (pos + 27 <= size) {
+        if (std::memcmp(data + pos, "OggS", 4) != 0) {   // resynchronise on garbage
+            pos++;
+            continue;
+        }
+        const uint8_t *h = data + pos;
+        const int headerType = h[5];
+        const int64_t granule = rd64(h + 6);
+        const uint32_t ser = rd32(h + 14);
+        const int nsegs = h[26];
+        if (pos + 27 + nsegs > size) break;
+        size_t bodyLen = 0;
+        for (int i = 0; i < nsegs; i++) bodyLen += h[27 + i];
+        const uint8_t *body = h + 27 + nsegs;
+        if (body + bodyLen > data + size) break;
+        if (!haveSerial) { serial = ser; haveSerial = true; }
+        if (ser == serial) {                               // first logical stream only
+            if (!(headerType & 1) && havePending) {        // a fresh packet starts: drop the dangling one
+                pending.clear();
+                havePending = false;
+            }
+            size_t off = 0;
+            for (int i = 0; i < nsegs; i++) {
+                const int seg = h[27 + i];
+                pending.insert(pending.end(), body + off, body + off + seg);
+                havePending = true;
+                off += seg;
+                if (seg < 255) {                           // packet complete
+                    if (packetIndex == 0) {
+                        if (pending.size() < 19 || std::memcmp(pending.data(), "OpusHead", 8) != 0)
+                            throw std::runtime_error("not an Ogg Opus stream (OpusHead missing)");
+                        f.head.version = pending[8];
+                        f.head.channels = pending[9];
+                        f.head.preSkip = pending[10] | pending[11] << 8;
+                        f.head.inputRate = rd32(&pending[12]);
+                        f.head.outputGainQ8 = (int16_t)(pending[16] | pending[17] << 8);
+                        f.head.mappingFamily = pending[18];
+                    } else if (packetIndex == 1) {
+                        if (pending.size() < 8 || std::memcmp(pending.data(), "OpusTags", 8) != 0)
+                            throw std::runtime_error("OpusTags packet missing");
+                    } else {
+                        f.packets.push_back(pending);
+                    }
+                    packetIndex++;
+                    pending.clear();
+                    havePending = false;
+                }
+            }
+            if (granule >= 0) f.lastGranule = granule;
+        }
+        pos += 27 + nsegs + bodyLen;
+    }
+    if (packetIndex < 2) throw std::runtime_error("truncated Ogg Opus stream");
+    return f;
+}
+
+bool parseOpusPacket(const uint8_t *data, int len, PacketFrames &out) {
+    out.frames.clear();
+    if (len < 1) return false;
+    const int toc = data[0];
+    out.config = toc >> 3;
+    out.stereo = (toc >> 2) & 1;
+    // RFC 6716 table 2: 16-19 CELT NB, 20-23 WB, 24-27 SWB, 28-31 FB; 2.5/5/10/20 ms
+    if (out.config >= 16) {
+        out.frameSize = 120 << (out.config & 3);
+        static const int endBand[4] = {13, 17, 19, 21};    // opus_decoder_clean.c:463-483 (CELT_SET_END_BAND)
+        out.bandwidthEnd = endBand[(out.config - 16) >> 2];
+    } else if (out.config >= 12) {
+        out.frameSize = (out.config & 1) ? 960 : 480;      // hybrid 10 / 20 ms
+    } else {
+        static const int silkSize[4] = {480, 960, 1920, 2880};
+        out.frameSize = silkSize[out.config & 3];
+    }
+    const uint8_t *p = data + 1;
+    int rem = len - 1;
+    auto readLen = [&](int &val) -> bool {                 // 1- or 2-byte frame length
+        if (rem < 1) return false;
+        if (p[0] < 252) { val = p[0]; p += 1; rem -= 1; return true; }
+        if (rem < 2) return false;
+        val = 4 * p[1] + p[0];
+        p += 2; rem -= 2;
+        return true;
+    };
+    switch (toc & 3) {
+    case 0:
+        out.frames.push_back({p, rem});
+        return true;
+    case 1:
+        if (rem & 1) return false;
+        out.frames.push_back({p, rem / 2});
+        out.frames.push_back({p + rem / 2, rem / 2});
+        return true;
+    case 2: {
+        int l0;
+        if (!readLen(l0) || l0 > rem) return false;
+        out.frames.push_back({p, l0});
+        out.frames.push_back({p + l0, rem - l0});
+        return true;
+    }
+    default: {
+        if (rem < 1) return false;
+        const int ch = *p++;
+        rem--;
+        const int count = ch & 0x3F;
+        if (count == 0 || out.frameSize * count > 5760) return false;
+        int padding = 0;
+        if (ch & 0x40) {                                   // padding length, 255 = 254 more + continue
+            int b;
+            do {
+                if (rem < 1) return false;
+                b = *p++;
+                rem--;
+                padding += b == 255 ? 254 : b;
+            } while (b == 255);
+        }
+        rem -= padding;
+        if (rem < 0) return false;
+        if (ch & 0x80) {                                   // VBR: count-1 explicit lengths
+            std::vector<int> lens(count);
+            int sum = 0;
+            for (int i = 0; i < count - 1; i++) {
+                if (!readLen(lens[i])) return false;
+                sum += lens[i];
+            }
+            if (sum > rem) return false;
+            lens[count - 1] = rem - sum;
+            for (int i = 0; i < count; i++) {
+                out.frames.push_back({p, lens[i]});
+                p += lens[i];
+            }
+        } else {                                           // CBR
+            if (rem % count) return false;
+            const int l = rem / count;
+            for (int i = 0; i < count; i++) out.frames.push_back({p + i * l, l});
+        }
+        return true;
+    }
+    }
+}
+
+}  // namespace nyq_host

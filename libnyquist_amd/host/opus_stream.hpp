@@ -1,0 +1,48 @@
+// opus_stream.hpp -- the container and packet layers in front of the CELT frame decoder:
+//   * Ogg page / packet demultiplexing and the OpusHead header (RFC 3533, RFC 7845) -- what the
+//     reference gets from third_party/libogg and third_party/opus/opusfile (op_test_memory,
+//     op_head, op_pcm_total, pre-skip and end trimming; used from src/OpusDecoder.cpp:44-122);
+//   * Opus packet framing: TOC byte, frame count codes 0-3, frame lengths (RFC 6716 section 3;
+//     reference: libopus/src/opus.c opus_packet_parse_impl, opus_decoder_clean.c:608-722).
+// Only what the MI355X decode path needs is here: CELT-only packets (TOC configurations 16-31) of
+// mono or stereo streams in channel mapping family 0.  SILK and hybrid packets are reported as
+// unsupported, exactly because the hot path this repository accelerates is CELT's.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace nyq_host {
+
+struct OpusHead {
+    int version = 0;
+    int channels = 0;
+    int preSkip = 0;
+    uint32_t inputRate = 0;
+    int outputGainQ8 = 0;
+    int mappingFamily = 0;
+};
+
+struct OggOpusFile {
+    OpusHead head;
+    std::vector<std::vector<uint8_t>> packets;   // audio packets in order
+    int64_t lastGranule = -1;                    // granule position of the last page (samples at 48 kHz incl. pre-skip)
+};
+
+// Parse a whole Ogg Opus file held in memory; throws std::runtime_error on malformed input.
+OggOpusFile parseOggOpus(const uint8_t *data, size_t size);
+
+struct PacketFrames {
+    int config = 0;            // TOC >> 3
+    bool stereo = false;       // TOC bit 2
+    int frameSize = 0;         // samples per frame at 48 kHz
+    int bandwidthEnd = 21;     // CELT end band for the packet's audio bandwidth
+    std::vector<std::pair<const uint8_t *, int>> frames;   // (pointer, length) of each compressed frame
+};
+
+// Split one Opus packet into its frames.  Returns false if the packet is malformed.
+bool parseOpusPacket(const uint8_t *data, int len, PacketFrames &out);
+
+}  // namespace nyq_host

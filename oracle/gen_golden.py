@@ -25,6 +25,10 @@ Writes DATA only (inputs + expected outputs):
                                       same frames the post-filter parameters and state, the filtered
                                       history, the de-emphasis memory and the FINAL decoded PCM
                                       (AudioData::samples) -- the whole freq[] -> PCM chain
+  short.opus, short_opus_digest.npz   the bundled test file itself plus per-frame digests of the
+                                      reference decoder's freq[] for all 220 frames, its post-filter
+                                      parameters and its complete decoded PCM (end-to-end check of
+                                      the host-side decoder + GPU chain)
 Everything is seeded; re-running reproduces the files bit for bit.
 """
 import os
@@ -241,6 +245,20 @@ def main():
         sb_reverie=np.array([rv["samples"], rv["calls"], len(rv["flags"]), int(rv["flags"].sum())], np.int64),
         sb_reverie_sum=np.float32(rv["sum"]), sb_reverie_transient=rv["flags"],
         window=np.array([lo, hi]))
+    # The bundled Opus test file itself (a data file the reference's tests hold) so that the host-side
+    # decoder can be exercised where /root/reference does not exist, with per-frame digests of what the
+    # reference decoder computed for EVERY frame of it: sum, sum of squares and peak of freq[] per
+    # channel, the transient flag and the post-filter parameters.
+    shutil.copyfile(f"{REFDATA}/short.opus", f"{OUT}/short.opus")
+    fr = sh_["freq"].astype(np.float64)
+    np.savez_compressed(
+        f"{OUT}/short_opus_digest.npz",
+        freq_sum=fr.sum(axis=2), freq_sq=(fr ** 2).sum(axis=2), freq_peak=np.abs(fr).max(axis=2),
+        transient=sh_["flags"],
+        pf_pitch=np.array([second(f, 0)["T1"] for f in range(len(sh_["flags"]))], np.int32),
+        pf_gain=np.array([second(f, 0)["g1"] for f in range(len(sh_["flags"]))], np.float32),
+        pf_tapset=np.array([second(f, 0)["ts1"] for f in range(len(sh_["flags"]))], np.int32),
+        final=sh_["final"], preskip=np.int64(ps), samples=np.int64(sh_["samples"]))
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"wrote {len(os.listdir(OUT))} files, {total/1024:.0f} KiB -> {OUT}")
 

@@ -187,6 +187,8 @@ class Ref:
         L.test_opus_ifft.argtypes = [C.c_int, _f32p, _f32p]
         L.ref_imdct_bench.argtypes = [_f32p, _f32p, C.c_int, C.c_long, C.c_int]
         L.ref_imdct_bench.restype = C.c_double
+        _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+        L.ref_get_alloc_tables.argtypes = [_i16p, _i16p, _u8p, _u8p]
 
     def tables(self):
         t = np.empty(481, np.float32)
@@ -196,7 +198,13 @@ class Ref:
         fa = np.empty(64, np.int16)
         n = self.lib.ref_get_tables(t, w, tw, br, fa)
         assert n == 1920
-        return dict(trig=t, window=w, tw=tw.reshape(480, 2), bitrev=br, factors=fa.reshape(4, 16))
+        logn = np.zeros(21, np.int16)
+        cidx = np.zeros(105, np.int16)
+        cbits = np.zeros(1024, np.uint8)
+        ccaps = np.zeros(168, np.uint8)
+        nb = self.lib.ref_get_alloc_tables(logn, cidx, cbits, ccaps)
+        return dict(trig=t, window=w, tw=tw.reshape(480, 2), bitrev=br, factors=fa.reshape(4, 16),
+                    logN=logn, cache_index=cidx, cache_bits=cbits[:nb].copy(), cache_caps=ccaps)
 
     def imdct(self, x, out, shift, stride=1):
         x = np.ascontiguousarray(x, np.float32)

@@ -51,6 +51,19 @@ int ref_get_tables(float *trig, float *window, float *tw, short *bitrev, short *
 
 int ref_overlap(void) { return ref_mode()->overlap; }
 
+/* allocation-side tables of the static mode (static_modes_float.h:36-97): logN[21],
+ * cache.index[105], cache.bits[size], cache.caps[168]; returns cache.size */
+int ref_get_alloc_tables(short *logN, short *index, unsigned char *bits, unsigned char *caps)
+{
+    const CELTMode *m = ref_mode();
+    int i;
+    for (i = 0; i < m->nbEBands; i++) logN[i] = m->logN[i];
+    for (i = 0; i < m->nbEBands * (m->maxLM + 2); i++) index[i] = m->cache.index[i];
+    for (i = 0; i < m->cache.size; i++) bits[i] = m->cache.bits[i];
+    for (i = 0; i < (m->maxLM + 1) * 2 * m->nbEBands; i++) caps[i] = m->cache.caps[i];
+    return m->cache.size;
+}
+
 /* out is read-modify-write over (1920>>shift)/2 + overlap/2 floats */
 void ref_imdct(float *in, float *out, int shift, int stride)
 {
