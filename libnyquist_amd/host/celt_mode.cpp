@@ -89,7 +89,7 @@ void buildPulseCache(CeltMode &m) {
                     int N = N0;
                     for (int k = 0; k < i - LM0; k++) {                  // plus every time split's theta
                         maxBits <<= 1;
-                        const int offset = ((m.logN[j] + ((LM0 + k) << kBitRes)) >> 1) - kQThetaOffset;
+                        const int offset = ((m.logN[j] + (LM0 + k) * (1 << kBitRes)) >> 1) - kQThetaOffset;
                         const int32_t num = 459 * (int32_t)((2 * N - 1) * offset + maxBits);
                         const int32_t den = ((int32_t)(2 * N - 1) << 9) - 459;
                         maxBits += std::min((num + (den >> 1)) / den, 57);
