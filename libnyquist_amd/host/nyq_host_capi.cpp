@@ -100,6 +100,27 @@ long nyqh_nyquistio_load(const char *path, float *samples, long capacity, long *
     }
 }
 
+// The same through NyquistIO::Load(AudioData*, const std::vector<uint8_t>&) (magic sniffing).
+long nyqh_nyquistio_load_buffer(const unsigned char *file, long size, float *samples, long capacity, long *info) {
+    try {
+        nqr::NyquistIO loader;
+        nqr::AudioData data;
+        std::vector<uint8_t> buf(file, file + size);
+        loader.Load(&data, buf);
+        info[0] = data.channelCount;
+        info[1] = data.sampleRate;
+        info[2] = (long)data.frameSize;
+        info[3] = (long)data.lengthSeconds;
+        if (samples && capacity >= (long)data.samples.size())
+            std::memcpy(samples, data.samples.data(), data.samples.size() * sizeof(float));
+        return (long)data.samples.size();
+    } catch (const nqr::UnsupportedExtensionEx &) {
+        return -2;
+    } catch (const std::exception &) {
+        return -1;
+    }
+}
+
 // `count` copies of one file decoded as ONE batch (config 4 shape: many concurrent streams).
 // Copies the first and the last decoded stream out for checking; stats = {cpu_s, gpu_s, frames, threads}.
 long nyqh_batch_decode(const unsigned char *file, long size, long count, int threads, float *first, float *last,

@@ -55,6 +55,25 @@ OggOpusFile parseOggOpus(const uint8_t *data, size_t size) {
                         f.head.inputRate = rd32(&pending[12]);
                         f.head.outputGainQ8 = (int16_t)(pending[16] | pending[17] << 8);
                         f.head.mappingFamily = pending[18];
+                        if (f.head.channels < 1) throw std::runtime_error("OpusHead: zero channels");
+                        if (f.head.mappingFamily == 0) {
+                            if (f.head.channels > 2) throw std::runtime_error("OpusHead: family 0 with more than 2 channels");
+                            f.head.streamCount = 1;
+                            f.head.coupledCount = f.head.channels == 2;
+                            f.head.mapping[0] = 0;
+                            f.head.mapping[1] = 1;
+                        } else {
+                            if (pending.size() < (size_t)21 + f.head.channels) throw std::runtime_error("OpusHead: truncated mapping table");
+                            f.head.streamCount = pending[19];
+                            f.head.coupledCount = pending[20];
+                            if (f.head.streamCount < 1 || f.head.coupledCount > f.head.streamCount)
+                                throw std::runtime_error("OpusHead: bad stream counts");
+                            for (int c = 0; c < f.head.channels; c++) {
+                                f.head.mapping[c] = pending[21 + c];
+                                if (f.head.mapping[c] != 255 && f.head.mapping[c] >= f.head.streamCount + f.head.coupledCount)
+                                    throw std::runtime_error("OpusHead: mapping index out of range");
+                            }
+                        }
                     } else if (packetIndex == 1) {
                         if (pending.size() < 8 || std::memcmp(pending.data(), "OpusTags", 8) != 0)
                             throw std::runtime_error("OpusTags packet missing");
@@ -74,7 +93,7 @@ OggOpusFile parseOggOpus(const uint8_t *data, size_t size) {
     return f;
 }
 
-bool parseOpusPacket(const uint8_t *data, int len, PacketFrames &out) {
+bool parseOpusPacket(const uint8_t *data, int len, PacketFrames &out, bool selfDelimited, int *consumed) {
     out.frames.clear();
     if (len < 1) return false;
     const int toc = data[0];
@@ -101,21 +120,21 @@ bool parseOpusPacket(const uint8_t *data, int len, PacketFrames &out) {
         p += 2; rem -= 2;
         return true;
     };
+    std::vector<int> lens;
+    int padding = 0;
     switch (toc & 3) {
     case 0:
-        out.frames.push_back({p, rem});
-        return true;
+        lens.assign(1, -1);
+        break;
     case 1:
-        if (rem & 1) return false;
-        out.frames.push_back({p, rem / 2});
-        out.frames.push_back({p + rem / 2, rem / 2});
-        return true;
+        lens.assign(2, -1);                                // two frames of equal size
+        break;
     case 2: {
         int l0;
-        if (!readLen(l0) || l0 > rem) return false;
-        out.frames.push_back({p, l0});
-        out.frames.push_back({p + l0, rem - l0});
-        return true;
+        if (!readLen(l0)) return false;
+        lens.assign(2, -1);
+        lens[0] = l0;
+        break;
     }
     default: {
         if (rem < 1) return false;
@@ -123,7 +142,6 @@ bool parseOpusPacket(const uint8_t *data, int len, PacketFrames &out) {
         rem--;
         const int count = ch & 0x3F;
         if (count == 0 || out.frameSize * count > 5760) return false;
-        int padding = 0;
         if (ch & 0x40) {                                   // padding length, 255 = 254 more + continue
             int b;
             do {
@@ -133,29 +151,50 @@ bool parseOpusPacket(const uint8_t *data, int len, PacketFrames &out) {
                 padding += b == 255 ? 254 : b;
             } while (b == 255);
         }
-        rem -= padding;
-        if (rem < 0) return false;
+        lens.assign(count, -1);
         if (ch & 0x80) {                                   // VBR: count-1 explicit lengths
-            std::vector<int> lens(count);
-            int sum = 0;
-            for (int i = 0; i < count - 1; i++) {
+            for (int i = 0; i < count - 1; i++)
                 if (!readLen(lens[i])) return false;
-                sum += lens[i];
-            }
-            if (sum > rem) return false;
-            lens[count - 1] = rem - sum;
-            for (int i = 0; i < count; i++) {
-                out.frames.push_back({p, lens[i]});
-                p += lens[i];
-            }
-        } else {                                           // CBR
-            if (rem % count) return false;
-            const int l = rem / count;
-            for (int i = 0; i < count; i++) out.frames.push_back({p + i * l, l});
+        } else {
+            lens.assign(count, -2);                        // CBR: all equal
         }
-        return true;
+        break;
     }
     }
+    // the last (or, for CBR, the common) frame length: explicit in self-delimited framing
+    const int count = (int)lens.size();
+    const bool cbr = lens[count - 1] == -2 || ((toc & 3) == 1);
+    int known = 0;
+    for (int i = 0; i < count - 1; i++)
+        if (lens[i] >= 0) known += lens[i];
+    if (selfDelimited) {
+        int l;
+        if (!readLen(l)) return false;
+        if (cbr) lens.assign(count, l);
+        else lens[count - 1] = l;
+    } else {
+        const int avail = rem - padding;
+        if (avail < 0) return false;
+        if (cbr) {
+            if (avail % count) return false;
+            lens.assign(count, avail / count);
+        } else {
+            if (known > avail) return false;
+            lens[count - 1] = avail - known;
+        }
+    }
+    int total = 0;
+    for (int l : lens) {
+        if (l < 0 || l > 1275) return false;
+        total += l;
+    }
+    if (total + padding > rem) return false;
+    for (int l : lens) {
+        out.frames.push_back({p, l});
+        p += l;
+    }
+    if (consumed) *consumed = (int)(p - data) + padding;
+    return true;
 }
 
 }  // namespace nyq_host

@@ -4,8 +4,8 @@
 //     op_head, op_pcm_total, pre-skip and end trimming; used from src/OpusDecoder.cpp:44-122);
 //   * Opus packet framing: TOC byte, frame count codes 0-3, frame lengths (RFC 6716 section 3;
 //     reference: libopus/src/opus.c opus_packet_parse_impl, opus_decoder_clean.c:608-722).
-// Only what the MI355X decode path needs is here: CELT-only packets (TOC configurations 16-31) of
-// mono or stereo streams in channel mapping family 0.  SILK and hybrid packets are reported as
+// Only what the MI355X decode path needs is here: CELT-only packets (TOC configurations 16-31) in
+// channel mapping family 0 (mono/stereo) or family 1/255 (multistream, e.g. 5.1 or 8 channels).  SILK and hybrid packets are reported as
 // unsupported, exactly because the hot path this repository accelerates is CELT's.
 #pragma once
 #include <cstddef>
@@ -23,6 +23,10 @@ struct OpusHead {
     uint32_t inputRate = 0;
     int outputGainQ8 = 0;
     int mappingFamily = 0;
+    // channel mapping (RFC 7845 section 5.1.1); family 0 is filled in as 1 stream, coupled iff stereo
+    int streamCount = 1;
+    int coupledCount = 0;
+    uint8_t mapping[255] = {0};
 };
 
 struct OggOpusFile {
@@ -43,6 +47,8 @@ struct PacketFrames {
 };
 
 // Split one Opus packet into its frames.  Returns false if the packet is malformed.
-bool parseOpusPacket(const uint8_t *data, int len, PacketFrames &out);
+// selfDelimited: the framing of RFC 6716 appendix B used for all but the last stream of a
+// multistream packet; *consumed receives the number of bytes the packet occupies.
+bool parseOpusPacket(const uint8_t *data, int len, PacketFrames &out, bool selfDelimited = false, int *consumed = nullptr);
 
 }  // namespace nyq_host

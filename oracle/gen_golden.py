@@ -259,6 +259,34 @@ def main():
         pf_gain=np.array([second(f, 0)["g1"] for f in range(len(sh_["flags"]))], np.float32),
         pf_tapset=np.array([second(f, 0)["ts1"] for f in range(len(sh_["flags"]))], np.int32),
         final=sh_["final"], preskip=np.int64(ps), samples=np.int64(sh_["samples"]))
+    # A 4-channel MULTISTREAM file (channel mapping family 1: two coupled streams, mapping [2,0,3,1]) muxed
+    # from the packets of short.opus by tools/oggopus.py (stream B = the same packets rotated by 57), decoded
+    # by the reference decoder: ground truth for the multistream / channel-mapping path
+    # (opus_multistream_decoder.c:184-331).  The file is rebuilt from short.opus by the tests; only digests
+    # of the reference's output are stored.
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import oggopus
+    pk, _gr, last = oggopus.read_packets(open(f"{REFDATA}/short.opus", "rb").read())
+    aud = pk[2:]
+    ms = oggopus.mux_family1([aud, aud[57:220] + aud[:57] + aud[220:]], 2, [2, 0, 3, 1], 312,
+                             [(i + 1) * 960 for i in range(220)] + [last])
+    with tempfile.TemporaryDirectory() as td:
+        src, cap = os.path.join(td, "ms4.opus"), os.path.join(td, "cap.bin")
+        open(src, "wb").write(ms)
+        subprocess.run([os.path.join(ROOT, "oracle", "_ref", "ref_capture"), src, cap, "0"], check=True, stdout=subprocess.DEVNULL)
+        p = open(cap + ".post", "rb").read()
+    ncomb, mch = struct.unpack("<2i", p[:8])
+    off = 8
+    for _k in range(ncomb):
+        (hh,) = struct.unpack("<i", p[off + 28:off + 32])
+        off += 32 + (1088 * 4 if hh else 0)
+    mpcm = np.frombuffer(p[off + 8:], np.float32).reshape(-1, mch)
+    assert mch == 4 and np.array_equal(mpcm[:, 1], sh_["final"][:, 0]) and np.array_equal(mpcm[:, 3], sh_["final"][:, 1])
+    nb = mpcm.shape[0] // 960
+    np.savez_compressed(f"{OUT}/multistream_digest.npz", samples=np.int64(mpcm.size), channels=np.int64(mch),
+                        block_sum=mpcm[: nb * 960].astype(np.float64).reshape(nb, 960, mch).sum(axis=1),
+                        block_sq=(mpcm[: nb * 960].astype(np.float64) ** 2).reshape(nb, 960, mch).sum(axis=1),
+                        head=mpcm[:9600].copy(), tail=mpcm[-2000:].copy(), mapping=np.array([2, 0, 3, 1]), rotate=np.int64(57))
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"wrote {len(os.listdir(OUT))} files, {total/1024:.0f} KiB -> {OUT}")
 

@@ -64,3 +64,35 @@ def test_example_program_reports_reference_numbers():
     want = float(np.float32(0) + d["final"].reshape(-1).astype(np.float32).sum(dtype=np.float32))
     got = float(r.stdout.split("sum:")[1].split()[0])
     assert abs(got - want) < 0.05          # float accumulation order differs; Main.cpp compares (int)sum
+
+
+def test_multistream_four_channels_matches_reference(host):
+    """Channel mapping family 1 (opus_multistream_decoder.c:184-331): a 4-channel file with two coupled
+    streams and mapping [2,0,3,1], muxed from short.opus' packets; ground truth = the reference decoder's
+    output for the very same file (digests in multistream_digest.npz)."""
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import oggopus
+    d = np.load(os.path.join(GOLDEN, "multistream_digest.npz"))
+    pk, _gr, last = oggopus.read_packets(open(os.path.join(GOLDEN, "short.opus"), "rb").read())
+    aud = pk[2:]
+    r = int(d["rotate"])
+    ms = oggopus.mux_family1([aud, aud[r:220] + aud[:r] + aud[220:]], 2, [int(v) for v in d["mapping"]], 312,
+                             [(i + 1) * 960 for i in range(220)] + [last])
+    info = np.zeros(4, np.int64)
+    n = host.nyqh_nyquistio_load_buffer(ms, len(ms), None, 0, info)
+    assert n == int(d["samples"]) and int(info[0]) == 4
+    buf = np.zeros(n, np.float32)
+    assert host.nyqh_nyquistio_load_buffer(ms, len(ms), buf.ctypes.data_as(C.c_void_p), n, info) == n
+    got = buf.reshape(-1, 4)
+    assert np.abs(got[:9600] - d["head"]).max() <= 2e-6
+    assert np.abs(got[-2000:] - d["tail"]).max() <= 2e-6
+    nb = got.shape[0] // 960
+    bs = got[: nb * 960].astype(np.float64).reshape(nb, 960, 4).sum(axis=1)
+    bq = (got[: nb * 960].astype(np.float64) ** 2).reshape(nb, 960, 4).sum(axis=1)
+    assert np.abs(bs - d["block_sum"]).max() <= 2e-3
+    assert (np.abs(bq - d["block_sq"]) / np.maximum(d["block_sq"], 1e-9)).max() <= 1e-4
+    # stream A's channels are the stereo file's (mapping 0 -> out 1, 1 -> out 3)
+    st = np.load(os.path.join(GOLDEN, "short_opus_digest.npz"))["final"]
+    assert np.abs(got[:, 1] - st[:, 0]).max() <= 2e-6 and np.abs(got[:, 3] - st[:, 1]).max() <= 2e-6

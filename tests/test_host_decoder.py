@@ -27,6 +27,8 @@ def load_host():
     H.nyqh_decode_to_freq.argtypes = [C.c_char_p, C.c_long, C.c_long, _f32, _i32, _f32, _u32, _i64]
     H.nyqh_nyquistio_load.argtypes = [C.c_char_p, C.c_void_p, C.c_long, _i64]
     H.nyqh_nyquistio_load.restype = C.c_long
+    H.nyqh_nyquistio_load_buffer.argtypes = [C.c_char_p, C.c_long, C.c_void_p, C.c_long, _i64]
+    H.nyqh_nyquistio_load_buffer.restype = C.c_long
     H.nyqh_batch_decode.argtypes = [C.c_char_p, C.c_long, C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_long,
                                     np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")]
     H.nyqh_batch_decode.restype = C.c_long
