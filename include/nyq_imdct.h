@@ -131,12 +131,19 @@ int nyq_celt_post_dev(nyq_ctx *ctx, int LM, const float *d_pcm, const int *d_pf_
                       float *d_pf_state_out, float *d_hist, float *d_deemph, float *d_out,
                       size_t nstreams, size_t nframes, int channels);
 
+/* libvorbis' mdct_backward (third_party/libvorbis/src/mdct.c:397-491) on `batch` rows: n/2 coefficients
+ * in, n samples out per row, n a power of two in 64..4096 (the Vorbis block sizes; 8192 is not built).
+ * d_in [batch][n/2], d_out [batch][n].  out[i] = sum_k in[k] cos(2 pi/n (i + 1/2 + n/4)(k + 1/2)):
+ * no window, no overlap-add (libvorbis does those in block.c). */
+int nyq_vorbis_imdct_batch_dev(nyq_ctx *ctx, int n, const float *d_in, float *d_out, size_t batch);
+
 /* ---- host-buffer variants (synchronous: H2D, kernel, D2H through context scratch) ---- */
 int nyq_ifft_batch(nyq_ctx *ctx, int nfft, const float *in, float *out, size_t batch);
 int nyq_imdct_batch(nyq_ctx *ctx, int shift, const float *in, const float *carry,
                     float *fin, float *tail, size_t batch);
 int nyq_imdct_chain(nyq_ctx *ctx, int shift, const float *in, const float *carry0,
                     float *pcm, float *tail_out, size_t nchains, size_t len);
+int nyq_vorbis_imdct_batch(nyq_ctx *ctx, int n, const float *in, float *out, size_t batch);
 int nyq_celt_synth(nyq_ctx *ctx, int LM, const float *freq, const unsigned char *transient,
                    float *pcm, float *state, size_t nstreams, size_t nframes, int channels);
 /* freq[] -> interleaved PCM in one call: nyq_celt_synth_dev followed by nyq_celt_post_dev:

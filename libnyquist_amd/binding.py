@@ -22,7 +22,7 @@ EXPORTS = [
     "nyq_ctx_synchronize", "nyq_ctx_set_tables", "nyq_ctx_get_tables", "nyq_ctx_device_info",
     "nyq_ifft_batch_dev", "nyq_imdct_batch_dev", "nyq_imdct_chain_dev",
     "nyq_celt_synth_work_floats", "nyq_celt_synth_dev", "nyq_celt_synth", "nyq_celt_post_dev",
-    "nyq_celt_frames_to_pcm", "nyq_celt_state_floats",
+    "nyq_celt_frames_to_pcm", "nyq_celt_state_floats", "nyq_vorbis_imdct_batch_dev", "nyq_vorbis_imdct_batch",
     "nyq_ifft_batch", "nyq_imdct_batch", "nyq_imdct_chain",
     "processMDCTCuda", "processMDCTCudaB1C2", "cleanupCudaBuffers", "printCudaVersion",
 ]
@@ -85,6 +85,8 @@ def load(path=None):
     L.nyq_celt_frames_to_pcm.argtypes = [vp, i, fp, fp, fp, fp, fp, fp, fp, sz, sz, i]
     L.nyq_celt_state_floats.argtypes = [sz, i]
     L.nyq_celt_state_floats.restype = sz
+    L.nyq_vorbis_imdct_batch_dev.argtypes = [vp, i, fp, fp, sz]
+    L.nyq_vorbis_imdct_batch.argtypes = [vp, i, fp, fp, sz]
     L.nyq_ifft_batch.argtypes = [vp, i, fp, fp, sz]
     L.nyq_imdct_batch.argtypes = [vp, i, fp, fp, fp, fp, sz]
     L.nyq_imdct_chain.argtypes = [vp, i, fp, fp, fp, fp, sz, sz]
@@ -223,6 +225,16 @@ class Context:
         self._ck(self.lib.nyq_celt_frames_to_pcm(self.h, lm, _np(freq), _np(tr), _np(pp), _np(pg), _np(pt), _np(out),
                                                  _np(state), ns, nf, channels))
         return out
+
+    def vorbis_imdct_batch(self, n, x):
+        """libvorbis mdct_backward on rows: x [batch][n/2] -> [batch][n]."""
+        x = _f32(x, (-1, n // 2))
+        y = np.empty((x.shape[0], n), np.float32)
+        self._ck(self.lib.nyq_vorbis_imdct_batch(self.h, n, _np(x), _np(y), x.shape[0]))
+        return y
+
+    def vorbis_imdct_batch_dev(self, n, d_in, d_out, batch):
+        self._ck(self.lib.nyq_vorbis_imdct_batch_dev(self.h, n, C.c_void_p(d_in), C.c_void_p(d_out), batch))
 
     def celt_synth_work_floats(self, nstreams, nframes, channels):
         return int(self.lib.nyq_celt_synth_work_floats(nstreams, nframes, channels))

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/nyq_imdct.h"
 
@@ -43,6 +44,9 @@ struct nyq_ctx {
     int res_synth_long[4] = {0, 0, 0, 0};
     int res_synth_short = 0;
     int res_post = 0;
+    int res_vorbis[11] = {0};
+    float *d_vtab = nullptr;             // Vorbis rotation + twiddle tables of every block size, one allocation
+    size_t vrot_off[11] = {0}, vtw_off[11] = {0};   // float offsets by log2(n/4)
     std::string err;
     char devname[256];
 };
@@ -81,6 +85,31 @@ static int upload_tables(nyq_ctx *ctx) {
     return NYQ_OK;
 }
 
+// Vorbis tables (mdct_init, third_party/libvorbis/src/mdct.c:52-91, restated for this factorisation):
+// per block size n = 4 << m: rot[i] = (cos, sin)(2 pi (i + 1/8)/n) and twid[k] = (cos, sin)(2 pi k/(n/4)).
+static int build_vorbis_tables(nyq_ctx *ctx) {
+    std::vector<float> h;
+    for (int m = 4; m <= 10; m++) {
+        const int n4 = 1 << m, n = 4 * n4;
+        ctx->vrot_off[m] = h.size();
+        for (int i = 0; i < n4; i++) {
+            const double a = 2.0 * M_PI * (i + 0.125) / n;
+            h.push_back((float)std::cos(a));
+            h.push_back((float)std::sin(a));
+        }
+        ctx->vtw_off[m] = h.size();
+        for (int k = 0; k < n4; k++) {
+            const double a = 2.0 * M_PI * k / n4;
+            h.push_back((float)std::cos(a));
+            h.push_back((float)std::sin(a));
+        }
+    }
+    NYQ_HIP(ctx, hipMalloc(&ctx->d_vtab, h.size() * sizeof(float)));
+    NYQ_HIP(ctx, hipMemcpyAsync(ctx->d_vtab, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    NYQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NYQ_OK;
+}
+
 extern "C" int nyq_ctx_create(nyq_ctx **out, int device) {
     if (!out) return fail(nullptr, NYQ_ERR_INVALID, "nyq_ctx_create: out is NULL");
     *out = nullptr;
@@ -114,6 +143,12 @@ extern "C" int nyq_ctx_create(nyq_ctx **out, int device) {
         nyq_ctx_destroy(ctx);
         return fail(nullptr, rc, m);
     }
+    rc = build_vorbis_tables(ctx);
+    if (rc != NYQ_OK) {
+        std::string m = ctx->err;
+        nyq_ctx_destroy(ctx);
+        return fail(nullptr, rc, m);
+    }
     *out = ctx;
     return NYQ_OK;
 }
@@ -123,6 +158,7 @@ extern "C" void nyq_ctx_destroy(nyq_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_vtab) (void)hipFree(ctx->d_vtab);
     if (ctx->d_trig) (void)hipFree(ctx->d_trig);
     if (ctx->d_window) (void)hipFree(ctx->d_window);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -382,6 +418,70 @@ extern "C" int nyq_celt_post_dev(nyq_ctx *ctx, int LM, const float *d_pcm, const
     hipLaunchKernelGGL((celt_post_kernel<kPostWavesPerBlock>), dim3(grid), dim3(kWave * kPostWavesPerBlock), 0,
                        ctx->stream, A, LM, ctx->d_window);
     NYQ_HIP(ctx, hipGetLastError());
+    return NYQ_OK;
+}
+
+// ---- Vorbis inverse MDCT ---------------------------------------------------------------------
+constexpr int kVorbisWavesPerBlock = 2;
+static int need_scratch(nyq_ctx *ctx, size_t bytes);
+static size_t round16f(size_t nfloats);
+
+template <int LOGN4>
+static int launch_vorbis(nyq_ctx *ctx, const float *d_in, float *d_out, size_t batch) {
+    using V = VGeo<LOGN4>;
+    VTables T{ctx->d_vtab + ctx->vrot_off[LOGN4], ctx->d_vtab + ctx->vtw_off[LOGN4]};
+    if (ctx->res_vorbis[LOGN4] == 0) {
+        int per_cu = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vorbis_imdct_kernel<LOGN4, kVorbisWavesPerBlock>,
+                                                                    kWave * kVorbisWavesPerBlock, 0);
+        if (e != hipSuccess || per_cu < 1) per_cu = 1;
+        if (per_cu > 4) per_cu = 4;
+        ctx->res_vorbis[LOGN4] = per_cu * ctx->cus;
+    }
+    const size_t ngroups = (batch + V::G - 1) / V::G;
+    const size_t need = (ngroups + kVorbisWavesPerBlock - 1) / kVorbisWavesPerBlock;
+    const unsigned grid = (unsigned)(need < (size_t)ctx->res_vorbis[LOGN4] ? need : (size_t)ctx->res_vorbis[LOGN4]);
+    hipLaunchKernelGGL((vorbis_imdct_kernel<LOGN4, kVorbisWavesPerBlock>), dim3(grid), dim3(kWave * kVorbisWavesPerBlock), 0,
+                       ctx->stream, d_in, d_out, (long)batch, T);
+    NYQ_HIP(ctx, hipGetLastError());
+    return NYQ_OK;
+}
+
+extern "C" int nyq_vorbis_imdct_batch_dev(nyq_ctx *ctx, int n, const float *d_in, float *d_out, size_t batch) {
+    if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_vorbis_imdct_batch_dev: ctx is NULL");
+    int m = -1;
+    for (int k = 4; k <= 10; k++)
+        if (n == (4 << k)) m = k;
+    if (m < 0) return fail(ctx, NYQ_ERR_INVALID, "nyq_vorbis_imdct_batch_dev: n must be a power of two in 64..4096");
+    if (batch == 0) return NYQ_OK;
+    if (!d_in || !d_out || d_in == d_out) return fail(ctx, NYQ_ERR_INVALID, "nyq_vorbis_imdct_batch_dev: NULL or aliased buffers");
+    if (!aligned16(d_in) || !aligned16(d_out))
+        return fail(ctx, NYQ_ERR_INVALID, "nyq_vorbis_imdct_batch_dev: device pointers must be 16-byte aligned");
+    switch (m) {
+    case 4: return launch_vorbis<4>(ctx, d_in, d_out, batch);
+    case 5: return launch_vorbis<5>(ctx, d_in, d_out, batch);
+    case 6: return launch_vorbis<6>(ctx, d_in, d_out, batch);
+    case 7: return launch_vorbis<7>(ctx, d_in, d_out, batch);
+    case 8: return launch_vorbis<8>(ctx, d_in, d_out, batch);
+    case 9: return launch_vorbis<9>(ctx, d_in, d_out, batch);
+    default: return launch_vorbis<10>(ctx, d_in, d_out, batch);
+    }
+}
+
+extern "C" int nyq_vorbis_imdct_batch(nyq_ctx *ctx, int n, const float *in, float *out, size_t batch) {
+    if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_vorbis_imdct_batch: ctx is NULL");
+    if (batch == 0) return NYQ_OK;
+    if (!in || !out || n < 64 || n > 4096) return fail(ctx, NYQ_ERR_INVALID, "nyq_vorbis_imdct_batch: bad argument");
+    NYQ_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n_in = round16f(batch * (size_t)(n / 2)), n_out = round16f(batch * (size_t)n);
+    int rc = need_scratch(ctx, (n_in + n_out) * sizeof(float));
+    if (rc != NYQ_OK) return rc;
+    float *d_in = ctx->d_scratch, *d_out = d_in + n_in;
+    NYQ_HIP(ctx, hipMemcpyAsync(d_in, in, batch * (size_t)(n / 2) * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    rc = nyq_vorbis_imdct_batch_dev(ctx, n, d_in, d_out, batch);
+    if (rc != NYQ_OK) return rc;
+    NYQ_HIP(ctx, hipMemcpyAsync(out, d_out, batch * (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    NYQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return NYQ_OK;
 }
 

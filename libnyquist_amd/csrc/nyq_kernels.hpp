@@ -278,3 +278,51 @@ __global__ __launch_bounds__(kWave *WPB) void ifft_rows_kernel(const float *__re
 }
 
 }  // namespace nyq
+
+// ---- Vorbis inverse MDCT (row f4) ------------------------------------------------------------------
+#include "nyq_vorbis_lanes.hpp"
+
+namespace nyq {
+
+template <int LOGN4, int WPB>
+__global__ __launch_bounds__(kWave *WPB) void vorbis_imdct_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                                   long nrows, VTables T) {
+    using V = VGeo<LOGN4>;
+    __shared__ __attribute__((aligned(16))) float smem[WPB * 2 * V::LDS_CPX];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wv = threadIdx.x >> 6;
+    cpx *lds = reinterpret_cast<cpx *>(smem) + wv * V::LDS_CPX;
+    VTwid<LOGN4> W;
+    v_twid_init<LOGN4>(W, lane, T);
+    const long ngroups = (nrows + V::G - 1) / V::G;
+    const long nwaves = (long)gridDim.x * WPB;
+    for (long gi = (long)blockIdx.x * WPB + wv; gi < ngroups; gi += nwaves) {
+        const long row0 = gi * V::G;
+        VStage<LOGN4> R;
+        v_stage_in_load<LOGN4>(R, lane, in, row0, nrows);
+        NYQ_WAVE_SYNC();
+        v_stage_in_store<LOGN4>(R, lane, lds, T);
+        NYQ_WAVE_SYNC();
+#pragma unroll
+        for (int it = 0; it < V::P1_ITERS; it++) {
+            cpx u[V::R2];
+            int g, k1;
+            const bool ok = v_pass1_load<LOGN4>(lane, it, lds, u, g, k1);
+            NYQ_WAVE_SYNC();
+            if (ok) v_pass1_store<LOGN4>(g, k1, lds, u);
+            NYQ_WAVE_SYNC();
+        }
+#pragma unroll
+        for (int it = 0; it < V::P2_ITERS; it++) {
+            cpx v[V::R1];
+            int g, n2;
+            const bool ok = v_pass2_load<LOGN4>(lane, it, lds, W, v, g, n2);
+            NYQ_WAVE_SYNC();
+            if (ok) v_pass2_store<LOGN4>(g, n2, lds, v);
+            NYQ_WAVE_SYNC();
+        }
+        v_stage_out<LOGN4>(lane, lds, out, row0, nrows, T);
+    }
+}
+
+}  // namespace nyq

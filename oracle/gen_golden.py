@@ -25,6 +25,7 @@ Writes DATA only (inputs + expected outputs):
                                       same frames the post-filter parameters and state, the filtered
                                       history, the de-emphasis memory and the FINAL decoded PCM
                                       (AudioData::samples) -- the whole freq[] -> PCM chain
+  ref_vorbis.npz                      libvorbis mdct_backward (mdct.c compiled standalone), block sizes 64..4096
   short.opus, short_opus_digest.npz   the bundled test file itself plus per-frame digests of the
                                       reference decoder's freq[] for all 220 frames, its post-filter
                                       parameters and its complete decoded PCM (end-to-end check of
@@ -287,6 +288,16 @@ def main():
                         block_sum=mpcm[: nb * 960].astype(np.float64).reshape(nb, 960, mch).sum(axis=1),
                         block_sq=(mpcm[: nb * 960].astype(np.float64) ** 2).reshape(nb, 960, mch).sum(axis=1),
                         head=mpcm[:9600].copy(), tail=mpcm[-2000:].copy(), mapping=np.array([2, 0, 3, 1]), rotate=np.int64(57))
+    # libvorbis mdct_backward (third_party/libvorbis/src/mdct.c compiled standalone): 3 rows per block size
+    from oracle.pyoracle import VorbisRef
+    vr = VorbisRef()
+    vb = {}
+    for n in (64, 128, 256, 512, 1024, 2048, 4096):
+        xv = np.concatenate([rng.uniform(-1, 1, (1, n // 2)), rng.standard_normal((1, n // 2)) * 30,
+                             np.eye(1, n // 2, 3) * 100.0]).astype(np.float32)
+        vb[f"x{n}"] = xv
+        vb[f"y{n}"] = vr.backward(n, xv)
+    np.savez(f"{OUT}/ref_vorbis.npz", **vb)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"wrote {len(os.listdir(OUT))} files, {total/1024:.0f} KiB -> {OUT}")
 

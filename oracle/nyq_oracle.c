@@ -696,6 +696,36 @@ int nyq_oracle_celt_post(int LM, float *pcm, long pitch, long pre, const int *pf
     return 0;
 }
 
+/* ---- Vorbis inverse MDCT ---------------------------------------------- */
+/* libvorbis mdct_backward (third_party/libvorbis/src/mdct.c:397-491) evaluated from its closed form in
+ * double precision:  out[i] = sum_k in[k] cos(2 pi / n (i + 1/2 + n/4)(k + 1/2)),  i < n, k < n/2.
+ * O(n^2): a known-answer restatement, pinned to outputs of the compiled libvorbis file
+ * (oracle/_ref/libvorbis_ref.so, fixtures tests/golden/ref_vorbis.npz) to <= 1e-6 relative RMS --
+ * libvorbis' own factorised float arithmetic is not reproduced bit for bit. */
+int nyq_oracle_vorbis_imdct(int n, const float *in, float *out, long rows)
+{
+    long r;
+    int i, k;
+    double *ctab;
+    if (n < 16 || (n & (n - 1))) return -1;
+    /* cos(2 pi m / (4n)) for m < 4n: (2i + 1 + n/2)(2k + 1) is an integer, reduce it mod 4n */
+    ctab = (double *)malloc(sizeof(double) * 4 * (size_t)n);
+    if (!ctab) return -2;
+    for (i = 0; i < 4 * n; i++) ctab[i] = cos(2.0 * M_PI * i / (4.0 * n));
+    for (r = 0; r < rows; r++) {
+        const float *x = in + r * (n / 2);
+        float *y = out + r * n;
+        for (i = 0; i < n; i++) {
+            double acc = 0;
+            const long a = 2L * i + 1 + n / 2;
+            for (k = 0; k < n / 2; k++) acc += x[k] * ctab[(a * (2L * k + 1)) % (4L * n)];
+            y[i] = (float)acc;
+        }
+    }
+    free(ctab);
+    return 0;
+}
+
 int nyq_oracle_max_threads(void)
 {
 #ifdef _OPENMP

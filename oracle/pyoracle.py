@@ -55,6 +55,7 @@ class Oracle:
         L.nyq_oracle_imdct_chain.argtypes = [C.c_int, _f32p, C.c_void_p, _f32p, C.c_void_p, C.c_long]
         L.nyq_oracle_celt_synth.argtypes = [C.c_int, _f32p, C.c_void_p, _f32p, C.c_void_p, C.c_long, C.c_long,
                                             C.c_int, C.c_int]
+        L.nyq_oracle_vorbis_imdct.argtypes = [C.c_int, _f32p, _f32p, C.c_long]
         L.nyq_oracle_celt_post.argtypes = [C.c_int, _f32p, C.c_long, C.c_long, _i32p, _f32p, _i32p, _f32p, _f32p,
                                            _f32p, C.c_long, C.c_long, C.c_int]
         if tables is None:
@@ -169,6 +170,14 @@ class Oracle:
         return out, pcm, st, dm
 
 
+    def vorbis_imdct(self, n, x):
+        """libvorbis mdct_backward from its closed form (double precision): [rows][n/2] -> [rows][n]."""
+        x = np.ascontiguousarray(x, np.float32).reshape(-1, n // 2)
+        y = np.empty((x.shape[0], n), np.float32)
+        assert self.lib.nyq_oracle_vorbis_imdct(n, x.reshape(-1), y.reshape(-1), x.shape[0]) == 0
+        return y
+
+
 def ref_available():
     return os.path.exists(REF_SO)
 
@@ -233,3 +242,30 @@ class Ref:
         x = np.ascontiguousarray(x, np.float32).reshape(-1, n2)
         scratch = np.zeros((x.shape[0], n2 + HALF_OV), np.float32)
         return float(self.lib.ref_imdct_bench(x.reshape(-1), scratch.reshape(-1), shift, x.shape[0], reps))
+
+
+class VorbisRef:
+    """libvorbis' own mdct.c compiled standalone (oracle/_ref/libvorbis_ref.so)."""
+
+    class _Lookup(C.Structure):
+        _fields_ = [("n", C.c_int), ("log2n", C.c_int), ("trig", C.c_void_p), ("bitrev", C.c_void_p), ("scale", C.c_float)]
+
+    def __init__(self):
+        so = os.path.join(HERE, "_ref", "libvorbis_ref.so")
+        if not os.path.exists(so):
+            raise FileNotFoundError(so)
+        L = self.lib = C.CDLL(so)
+        L.mdct_init.argtypes = [C.POINTER(self._Lookup), C.c_int]
+        L.mdct_backward.argtypes = [C.POINTER(self._Lookup), _f32p, _f32p]
+        self._lu = {}
+
+    def backward(self, n, x):
+        if n not in self._lu:
+            lu = self._Lookup()
+            self.lib.mdct_init(C.byref(lu), n)
+            self._lu[n] = lu
+        x = np.ascontiguousarray(x, np.float32).reshape(-1, n // 2)
+        y = np.zeros((x.shape[0], n), np.float32)
+        for r in range(x.shape[0]):
+            self.lib.mdct_backward(C.byref(self._lu[n]), x[r].copy(), y[r])
+        return y

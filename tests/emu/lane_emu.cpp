@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "nyq_imdct_lanes.hpp"
+#include "nyq_vorbis_lanes.hpp"
 
 using namespace nyq;
 
@@ -160,6 +161,68 @@ extern "C" int emu_celt_synth(int LM, const float *freq, const unsigned char *tr
             for (int i = 0; i < kHalfOv; i++)
                 state[sc * kHalfOv + i] = tails[((size_t)sc * (nframes + 1) + nframes) * kHalfOv + i];
     return 0;
+}
+
+// mirrors vorbis_imdct_kernel (nyq_kernels.hpp)
+template <int LOGN4>
+static void emu_vorbis(const float *in, float *out, long nrows, const float *rot, const float *twid) {
+    using V = VGeo<LOGN4>;
+    std::vector<cpx> lds(V::LDS_CPX, cpx{0, 0});
+    VTables T{rot, twid};
+    std::vector<VTwid<LOGN4>> W(kWave);
+    for (int l = 0; l < kWave; l++) v_twid_init<LOGN4>(W[l], l, T);
+    std::vector<VStage<LOGN4>> R(kWave);
+    for (long row0 = 0; row0 < nrows; row0 += V::G) {
+        for (int l = 0; l < kWave; l++) v_stage_in_load<LOGN4>(R[l], l, in, row0, nrows);
+        for (int l = 0; l < kWave; l++) v_stage_in_store<LOGN4>(R[l], l, lds.data(), T);
+        for (int it = 0; it < V::P1_ITERS; it++) {
+            std::vector<std::vector<cpx>> u(kWave, std::vector<cpx>(V::R2));
+            int g[kWave], k1[kWave];
+            bool ok[kWave];
+            for (int l = 0; l < kWave; l++) {
+                cpx tmp[V::R2];
+                ok[l] = v_pass1_load<LOGN4>(l, it, lds.data(), tmp, g[l], k1[l]);
+                for (int k = 0; k < V::R2; k++) u[l][k] = tmp[k];
+            }
+            for (int l = 0; l < kWave; l++)
+                if (ok[l]) {
+                    cpx tmp[V::R2];
+                    for (int k = 0; k < V::R2; k++) tmp[k] = u[l][k];
+                    v_pass1_store<LOGN4>(g[l], k1[l], lds.data(), tmp);
+                }
+        }
+        for (int it = 0; it < V::P2_ITERS; it++) {
+            std::vector<std::vector<cpx>> v(kWave, std::vector<cpx>(V::R1));
+            int g[kWave], n2[kWave];
+            bool ok[kWave];
+            for (int l = 0; l < kWave; l++) {
+                cpx tmp[V::R1];
+                ok[l] = v_pass2_load<LOGN4>(l, it, lds.data(), W[l], tmp, g[l], n2[l]);
+                for (int k = 0; k < V::R1; k++) v[l][k] = tmp[k];
+            }
+            for (int l = 0; l < kWave; l++)
+                if (ok[l]) {
+                    cpx tmp[V::R1];
+                    for (int k = 0; k < V::R1; k++) tmp[k] = v[l][k];
+                    v_pass2_store<LOGN4>(g[l], n2[l], lds.data(), tmp);
+                }
+        }
+        for (int l = 0; l < kWave; l++) v_stage_out<LOGN4>(l, lds.data(), out, row0, nrows, T);
+    }
+}
+
+// rot: (cos, sin)(2 pi (i + 1/8)/n), i < n/4;  twid: (cos, sin)(2 pi k/(n/4)), k < n/4 -- as nyq_imdct.hip builds them
+extern "C" int emu_vorbis_imdct(int n, const float *in, float *out, long nrows, const float *rot, const float *twid) {
+    switch (n) {
+    case 64: emu_vorbis<4>(in, out, nrows, rot, twid); return 0;
+    case 128: emu_vorbis<5>(in, out, nrows, rot, twid); return 0;
+    case 256: emu_vorbis<6>(in, out, nrows, rot, twid); return 0;
+    case 512: emu_vorbis<7>(in, out, nrows, rot, twid); return 0;
+    case 1024: emu_vorbis<8>(in, out, nrows, rot, twid); return 0;
+    case 2048: emu_vorbis<9>(in, out, nrows, rot, twid); return 0;
+    case 4096: emu_vorbis<10>(in, out, nrows, rot, twid); return 0;
+    }
+    return -1;
 }
 
 // single in-register DFT, for unit-testing nyq_fft_core.hpp
