@@ -62,6 +62,38 @@ __global__ void copy_gs_u(const v4 *__restrict__ in, v4 *__restrict__ out, size_
     }
 }
 
+// E: like B but every 3840-byte row is written 240 bytes further on (the IMDCT's fin rows: raw[p] lands at
+// fin[60 + p]); rows of 60 float4 (= 960 floats), 4 rows per wave, lane-contiguous 1 KB stores that straddle lines
+template <int SHIFT4>
+__global__ void copy_rows_shifted(const v4 *__restrict__ in, v4 *__restrict__ out, size_t nrows) {
+    const int lane = threadIdx.x & 63;
+    size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    size_t nw = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t g = wave; g * 4 < nrows; g += nw) {
+        v4 r[16];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                int j = (h & 1) * 64 + lane;                       // 120 float4 per half row pair
+                const v4 *row = in + (g * 4 + k) * 240;
+                r[k * 4 + h] = (j < 120) ? row[(h < 2) ? j : 239 - j] : v4{0, 0, 0, 0};
+            }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                int j = (h & 1) * 64 + lane;
+                v4 *row = out + (g * 4 + k) * 240;
+                if (j < 120) {
+                    int pos = (h < 2) ? j : 239 - j;
+                    pos = (pos + SHIFT4) % 240;                    // SHIFT4 = 15: +240 bytes with wrap (head region)
+                    row[pos] = r[k * 4 + h];
+                }
+            }
+    }
+}
+
 template <typename F>
 static double timeit(F f, int reps) {
     hipEvent_t a, b;
@@ -110,6 +142,19 @@ int main(int argc, char **argv) {
             snprintf(nm, sizeof nm, "grid-stride f4 x4, %d blk/CU", bpc);
             rep(nm, timeit([&] { copy_gs_u<4><<<256 * bpc, 256>>>(in, out, n4); }, 5));
         }
+    }
+    for (int wpc : {6}) {
+        char nm[128];
+        int grid = 256 * wpc;
+        size_t nrows = (bytes / 3840) & ~(size_t)3;   // whole groups of 4 rows only: the kernel has no tail guard
+        snprintf(nm, sizeof nm, "rows 3840B aligned stores, %d waves/CU", wpc);
+        rep(nm, timeit([&] { copy_rows_shifted<0><<<grid, 64>>>(in, out, nrows); }, 8));
+        snprintf(nm, sizeof nm, "rows 3840B stores shifted +240B, %d waves/CU", wpc);
+        rep(nm, timeit([&] { copy_rows_shifted<15><<<grid, 64>>>(in, out, nrows); }, 8));
+        snprintf(nm, sizeof nm, "rows 3840B aligned stores (again), %d waves/CU", wpc);
+        rep(nm, timeit([&] { copy_rows_shifted<0><<<grid, 64>>>(in, out, nrows); }, 8));
+        snprintf(nm, sizeof nm, "rows 3840B stores shifted +240B (again), %d waves/CU", wpc);
+        rep(nm, timeit([&] { copy_rows_shifted<15><<<grid, 64>>>(in, out, nrows); }, 8));
     }
     for (int wpc : {2, 3, 4, 6}) {
         char nm[128];
