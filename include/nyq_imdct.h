@@ -137,7 +137,14 @@ int nyq_celt_post_dev(nyq_ctx *ctx, int LM, const float *d_pcm, const int *d_pf_
  * no window, no overlap-add (libvorbis does those in block.c). */
 int nyq_vorbis_imdct_batch_dev(nyq_ctx *ctx, int n, const float *d_in, float *d_out, size_t batch);
 
-/* ---- host-buffer variants (synchronous: H2D, kernel, D2H through context scratch) ---- */
+/* ---- host-buffer variants (synchronous: H2D, kernel, D2H through context scratch) ----
+ * This is the shape of the reference's own FFI (host pointers in, host pointers out:
+ * third_party/opus/celt/mdct.c:52-55).  nyq_imdct_batch / nyq_imdct_chain cut a large batch into pieces
+ * and run the upload of piece k+1, the kernel of piece k and the download of piece k-1 concurrently on
+ * three HIP streams.  Buffers from nyq_host_alloc (pinned) make those copies true DMA transfers;
+ * pageable buffers are accepted and staged by the runtime. */
+void *nyq_host_alloc(size_t bytes);   /* NULL on failure */
+void nyq_host_free(void *p);
 int nyq_ifft_batch(nyq_ctx *ctx, int nfft, const float *in, float *out, size_t batch);
 int nyq_imdct_batch(nyq_ctx *ctx, int shift, const float *in, const float *carry,
                     float *fin, float *tail, size_t batch);

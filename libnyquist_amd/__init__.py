@@ -5,4 +5,4 @@ from hand-written gfx950 HIP kernels under csrc/.  This Python package is the ha
 used by tests/ and bench.py: a ctypes binding plus the in-tree build helper.
 """
 from ._build import LIB as LIB_PATH, build  # noqa: F401
-from .binding import EXPORTS, Context, NyqError, load, n2_of  # noqa: F401
+from .binding import EXPORTS, Context, NyqError, load, n2_of, pinned_empty  # noqa: F401

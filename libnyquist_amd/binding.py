@@ -23,9 +23,34 @@ EXPORTS = [
     "nyq_ifft_batch_dev", "nyq_imdct_batch_dev", "nyq_imdct_chain_dev",
     "nyq_celt_synth_work_floats", "nyq_celt_synth_dev", "nyq_celt_synth", "nyq_celt_post_dev",
     "nyq_celt_frames_to_pcm", "nyq_celt_state_floats", "nyq_vorbis_imdct_batch_dev", "nyq_vorbis_imdct_batch",
-    "nyq_ifft_batch", "nyq_imdct_batch", "nyq_imdct_chain",
+    "nyq_ifft_batch", "nyq_imdct_batch", "nyq_imdct_chain", "nyq_host_alloc", "nyq_host_free",
     "processMDCTCuda", "processMDCTCudaB1C2", "cleanupCudaBuffers", "printCudaVersion",
 ]
+
+
+def pinned_empty(shape, dtype="float32"):
+    """numpy array over page-locked host memory from nyq_host_alloc (freed when the array is collected)."""
+    L = load()
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    p = L.nyq_host_alloc(max(n, 1))
+    if not p:
+        raise MemoryError(f"nyq_host_alloc({n}) failed")
+    buf = (C.c_char * max(n, 1)).from_address(p)
+    arr = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+
+    class _Owner:
+        def __init__(self, ptr):
+            self.ptr = ptr
+
+        def __del__(self):
+            try:
+                L.nyq_host_free(self.ptr)
+            except Exception:
+                pass
+
+    buf._nyq_owner = _Owner(p)   # every numpy view keeps `buf` (its base) alive, and with it the allocation
+    return arr
 
 
 class NyqError(RuntimeError):
@@ -90,6 +115,10 @@ def load(path=None):
     L.nyq_ifft_batch.argtypes = [vp, i, fp, fp, sz]
     L.nyq_imdct_batch.argtypes = [vp, i, fp, fp, fp, fp, sz]
     L.nyq_imdct_chain.argtypes = [vp, i, fp, fp, fp, fp, sz, sz]
+    L.nyq_host_alloc.argtypes = [sz]
+    L.nyq_host_alloc.restype = vp
+    L.nyq_host_free.argtypes = [vp]
+    L.nyq_host_free.restype = None
     L.processMDCTCuda.argtypes = [fp, fp, fp, i, i, i, C.c_float, i, fp]
     L.processMDCTCuda.restype = None
     L.processMDCTCudaB1C2.argtypes = [C.POINTER(fp), C.POINTER(fp), fp, i, i, i, C.c_float, i, fp]
@@ -176,23 +205,25 @@ class Context:
         self._ck(self.lib.nyq_ifft_batch(self.h, nfft, _np(x), _np(y), x.shape[0]))
         return y
 
-    def imdct_batch(self, shift, x, carry=None, want_tail=True):
+    def imdct_batch(self, shift, x, carry=None, want_tail=True, pinned=False):
+        """pinned=True returns page-locked outputs (pass inputs made by pinned_empty for DMA both ways)."""
         n2 = n2_of(shift)
         x = _f32(x, (-1, n2))
         b = x.shape[0]
         carry = None if carry is None else _f32(carry, (b, HALF_OV))
-        fin = np.empty((b, n2), np.float32)
-        tail = np.empty((b, HALF_OV), np.float32) if want_tail else None
+        empty = pinned_empty if pinned else np.empty
+        fin = empty((b, n2), np.float32)
+        tail = empty((b, HALF_OV), np.float32) if want_tail else None
         self._ck(self.lib.nyq_imdct_batch(self.h, shift, _np(x), _np(carry), _np(fin), _np(tail), b))
         return fin, tail
 
-    def imdct_chain(self, shift, x, carry0=None, nchains=1):
+    def imdct_chain(self, shift, x, carry0=None, nchains=1, pinned=False):
         n2 = n2_of(shift)
         x = _f32(x, (-1, n2))
         rows = x.shape[0]
         assert rows % nchains == 0
         carry0 = None if carry0 is None else _f32(carry0, (nchains, HALF_OV))
-        pcm = np.empty((rows, n2), np.float32)
+        pcm = (pinned_empty if pinned else np.empty)((rows, n2), np.float32)
         tail = np.empty((nchains, HALF_OV), np.float32)
         self._ck(self.lib.nyq_imdct_chain(self.h, shift, _np(x), _np(carry0), _np(pcm), _np(tail), nchains,
                                           rows // nchains))

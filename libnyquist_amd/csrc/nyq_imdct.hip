@@ -39,11 +39,14 @@ struct nyq_ctx {
     // scratch for the host-buffer entry points
     float *d_scratch = nullptr;
     size_t scratch_bytes = 0;
+    // copy engines of the host-buffer entry points: uploads and downloads run beside the kernels
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    std::vector<hipEvent_t> ev_pool;
     int res_imdct[4] = {0, 0, 0, 0};   // resident blocks per kernel instance (occupancy query, cached)
     int res_ifft[4] = {0, 0, 0, 0};
     int res_synth_long[4] = {0, 0, 0, 0};
     int res_synth_short = 0;
-    int res_post = 0;
+    int res_post[4] = {0, 0, 0, 0};
     int res_vorbis[11] = {0};
     float *d_vtab = nullptr;             // Vorbis rotation + twiddle tables of every block size, one allocation
     size_t vrot_off[11] = {0}, vtw_off[11] = {0};   // float offsets by log2(n/4)
@@ -157,6 +160,9 @@ extern "C" void nyq_ctx_destroy(nyq_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    if (ctx->s_h2d) { (void)hipStreamSynchronize(ctx->s_h2d); (void)hipStreamDestroy(ctx->s_h2d); }
+    if (ctx->s_d2h) { (void)hipStreamSynchronize(ctx->s_d2h); (void)hipStreamDestroy(ctx->s_d2h); }
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_vtab) (void)hipFree(ctx->d_vtab);
     if (ctx->d_trig) (void)hipFree(ctx->d_trig);
@@ -380,6 +386,24 @@ extern "C" int nyq_imdct_chain_dev(nyq_ctx *ctx, int shift, const float *d_in, c
 // ---- post-filter + de-emphasis + interleave ---------------------------------------------
 constexpr int kPostWavesPerBlock = 4;
 
+template <int LM>
+static int launch_post(nyq_ctx *ctx, const PostArgs &A) {
+    const size_t nsc = (size_t)A.nstreams * (size_t)A.channels;
+    if (ctx->res_post[LM] == 0) {
+        int per_cu = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, celt_post_kernel<LM, kPostWavesPerBlock>,
+                                                                    kWave * kPostWavesPerBlock, 0);
+        if (e != hipSuccess || per_cu < 1) per_cu = 1;
+        ctx->res_post[LM] = per_cu * ctx->cus;
+    }
+    const size_t need = (nsc + kPostWavesPerBlock - 1) / kPostWavesPerBlock;
+    const unsigned grid = (unsigned)(need < (size_t)ctx->res_post[LM] ? need : (size_t)ctx->res_post[LM]);
+    hipLaunchKernelGGL((celt_post_kernel<LM, kPostWavesPerBlock>), dim3(grid), dim3(kWave * kPostWavesPerBlock), 0,
+                       ctx->stream, A, ctx->d_window);
+    NYQ_HIP(ctx, hipGetLastError());
+    return NYQ_OK;
+}
+
 extern "C" int nyq_celt_post_dev(nyq_ctx *ctx, int LM, const float *d_pcm, const int *d_pf_pitch, const float *d_pf_gain,
                                  const int *d_pf_tapset, const float *d_pf_state_in, float *d_pf_state_out,
                                  float *d_hist, float *d_deemph, float *d_out, size_t nstreams, size_t nframes,
@@ -405,20 +429,14 @@ extern "C" int nyq_celt_post_dev(nyq_ctx *ctx, int LM, const float *d_pcm, const
     A.nstreams = (long)nstreams;
     A.nframes = (long)nframes;
     A.channels = channels;
-    const size_t nsc = nstreams * (size_t)channels;
-    if (ctx->res_post == 0) {
-        int per_cu = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, celt_post_kernel<kPostWavesPerBlock>,
-                                                                    kWave * kPostWavesPerBlock, 0);
-        if (e != hipSuccess || per_cu < 1) per_cu = 1;
-        ctx->res_post = per_cu * ctx->cus;
+    if (((uintptr_t)d_pcm | (uintptr_t)d_out) & 15)
+        return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_post_dev: pcm and out must be 16-byte aligned");
+    switch (LM) {
+        case 0: return launch_post<0>(ctx, A);
+        case 1: return launch_post<1>(ctx, A);
+        case 2: return launch_post<2>(ctx, A);
+        default: return launch_post<3>(ctx, A);
     }
-    const size_t need = (nsc + kPostWavesPerBlock - 1) / kPostWavesPerBlock;
-    const unsigned grid = (unsigned)(need < (size_t)ctx->res_post ? need : (size_t)ctx->res_post);
-    hipLaunchKernelGGL((celt_post_kernel<kPostWavesPerBlock>), dim3(grid), dim3(kWave * kPostWavesPerBlock), 0,
-                       ctx->stream, A, LM, ctx->d_window);
-    NYQ_HIP(ctx, hipGetLastError());
-    return NYQ_OK;
 }
 
 // ---- Vorbis inverse MDCT ---------------------------------------------------------------------
@@ -522,6 +540,34 @@ extern "C" int nyq_ifft_batch(nyq_ctx *ctx, int nfft, const float *in, float *ou
     return NYQ_OK;
 }
 
+// Pinned host memory for callers of the host-buffer entry points: copies from/to such buffers are DMA
+// transfers that overlap the kernels; pageable buffers work too but are staged by the runtime.
+extern "C" void *nyq_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+extern "C" void nyq_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
+static int need_copy_streams(nyq_ctx *ctx, size_t nevents) {
+    if (!ctx->s_h2d) NYQ_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_h2d, hipStreamNonBlocking));
+    if (!ctx->s_d2h) NYQ_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_d2h, hipStreamNonBlocking));
+    while (ctx->ev_pool.size() < nevents) {
+        hipEvent_t e;
+        NYQ_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->ev_pool.push_back(e);
+    }
+    return NYQ_OK;
+}
+
+// Host rows -> device -> host, cut into pieces of whole chains so that the upload of piece k+1, the kernel
+// of piece k and the download of piece k-1 run at the same time (three streams, events between them).
+constexpr size_t kHostPieceBytes = (size_t)32 << 20;   // of input per piece
+constexpr size_t kHostMaxPieces = 64;
+
 static int imdct_host(nyq_ctx *ctx, int shift, const float *in, const float *carry, size_t carry_rows, float *fin,
                       float *tail, size_t tail_rows, size_t nchains, size_t len, bool chain) {
     const size_t rows = nchains * len;
@@ -532,18 +578,49 @@ static int imdct_host(nyq_ctx *ctx, int shift, const float *in, const float *car
     int rc = need_scratch(ctx, (2 * n_in + n_c + n_t + n_to) * sizeof(float));
     if (rc != NYQ_OK) return rc;
     float *d_in = ctx->d_scratch, *d_fin = d_in + n_in, *d_c = d_fin + n_in, *d_t = d_c + n_c, *d_to = d_t + n_t;
-    NYQ_HIP(ctx, hipMemcpyAsync(d_in, in, rows * n2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    if (carry)
-        NYQ_HIP(ctx, hipMemcpyAsync(d_c, carry, carry_rows * NYQ_HALF_OV * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    if (chain)
-        rc = nyq_imdct_chain_dev(ctx, shift, d_in, carry ? d_c : nullptr, d_fin, tail ? d_to : nullptr, d_t, nchains, len);
-    else
-        rc = nyq_imdct_batch_dev(ctx, shift, d_in, carry ? d_c : nullptr, d_fin, tail ? d_t : nullptr, rows);
+    // chains per piece: whole chains, a multiple of 4 rows so that device pointers stay 16-byte aligned
+    const size_t chain_bytes = len * n2 * sizeof(float);
+    size_t per = (kHostPieceBytes + chain_bytes - 1) / chain_bytes;
+    if ((nchains + per - 1) / per > kHostMaxPieces) per = (nchains + kHostMaxPieces - 1) / kHostMaxPieces;
+    per = (per + 3) & ~(size_t)3;
+    const size_t npieces = (nchains + per - 1) / per;
+    rc = need_copy_streams(ctx, 2 * npieces + 1);
     if (rc != NYQ_OK) return rc;
-    NYQ_HIP(ctx, hipMemcpyAsync(fin, d_fin, rows * n2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    if (tail)
-        NYQ_HIP(ctx, hipMemcpyAsync(tail, chain ? d_to : d_t, tail_rows * NYQ_HALF_OV * sizeof(float),
-                                    hipMemcpyDeviceToHost, ctx->stream));
+    // the copy streams start after whatever the caller queued on the compute stream before this call
+    hipEvent_t ev0 = ctx->ev_pool[2 * npieces];
+    NYQ_HIP(ctx, hipEventRecord(ev0, ctx->stream));
+    NYQ_HIP(ctx, hipStreamWaitEvent(ctx->s_h2d, ev0, 0));
+    NYQ_HIP(ctx, hipStreamWaitEvent(ctx->s_d2h, ev0, 0));
+    const size_t work_per_chain = (len + 1) * NYQ_HALF_OV;   // nyq_imdct_chain_dev's d_work layout
+    for (size_t k = 0; k < npieces; k++) {
+        const size_t c0 = k * per, nc = (nchains - c0 < per ? nchains - c0 : per), r0 = c0 * len, nr = nc * len;
+        hipEvent_t up = ctx->ev_pool[2 * k], done = ctx->ev_pool[2 * k + 1];
+        NYQ_HIP(ctx, hipMemcpyAsync(d_in + r0 * n2, in + r0 * n2, nr * n2 * sizeof(float), hipMemcpyHostToDevice, ctx->s_h2d));
+        if (carry)
+            NYQ_HIP(ctx, hipMemcpyAsync(d_c + c0 * NYQ_HALF_OV, carry + c0 * NYQ_HALF_OV, nc * NYQ_HALF_OV * sizeof(float),
+                                        hipMemcpyHostToDevice, ctx->s_h2d));
+        NYQ_HIP(ctx, hipEventRecord(up, ctx->s_h2d));
+        NYQ_HIP(ctx, hipStreamWaitEvent(ctx->stream, up, 0));
+        if (chain)
+            rc = nyq_imdct_chain_dev(ctx, shift, d_in + r0 * n2, carry ? d_c + c0 * NYQ_HALF_OV : nullptr, d_fin + r0 * n2,
+                                     tail ? d_to + c0 * NYQ_HALF_OV : nullptr, d_t + c0 * work_per_chain, nc, len);
+        else
+            rc = nyq_imdct_batch_dev(ctx, shift, d_in + r0 * n2, carry ? d_c + c0 * NYQ_HALF_OV : nullptr, d_fin + r0 * n2,
+                                     tail ? d_t + c0 * NYQ_HALF_OV : nullptr, nr);
+        if (rc != NYQ_OK) {
+            (void)hipStreamSynchronize(ctx->s_h2d);
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipStreamSynchronize(ctx->s_d2h);
+            return rc;
+        }
+        NYQ_HIP(ctx, hipEventRecord(done, ctx->stream));
+        NYQ_HIP(ctx, hipStreamWaitEvent(ctx->s_d2h, done, 0));
+        NYQ_HIP(ctx, hipMemcpyAsync(fin + r0 * n2, d_fin + r0 * n2, nr * n2 * sizeof(float), hipMemcpyDeviceToHost, ctx->s_d2h));
+        if (tail)
+            NYQ_HIP(ctx, hipMemcpyAsync(tail + c0 * NYQ_HALF_OV, (chain ? d_to : d_t) + c0 * NYQ_HALF_OV,
+                                        nc * NYQ_HALF_OV * sizeof(float), hipMemcpyDeviceToHost, ctx->s_d2h));
+    }
+    NYQ_HIP(ctx, hipStreamSynchronize(ctx->s_d2h));
     NYQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return NYQ_OK;
 }

@@ -105,6 +105,34 @@ def test_imdct_vs_oracle_ragged(ctx, oracle, shift, rows):
     assert none is None and np.array_equal(fin2, ctx.imdct_batch(shift, x, carry)[0])
 
 
+@pytest.mark.parametrize("pinned", [False, True])
+def test_host_path_pipelined_pieces_vs_oracle(ctx, oracle, pinned):
+    """The host-buffer entry points cut big batches into 32 MB pieces that flow through three streams
+    (upload / kernel / download): several pieces with a ragged last one, pageable and pinned buffers."""
+    import libnyquist_amd as nyq
+    rng = np.random.default_rng(77)
+    ctx.set_tables(*oracle.tables()[:2])
+    rows = 20011                                            # 3 pieces of 8740 rows at nfft 480
+    x = (nyq.pinned_empty if pinned else np.empty)((rows, 960), np.float32)
+    x[:] = rng.standard_normal((rows, 960)) * 30
+    carry = (rng.standard_normal((rows, 60)) * 30).astype(np.float32)
+    fin, tail = ctx.imdct_batch(0, x, carry, pinned=pinned)
+    wf, wt = oracle.imdct_batch(0, x, carry, nthreads=8)
+    assert rel_rms(fin, wf) <= 1e-6 and rel_rms(tail, wt) <= 1e-6
+    for lo in (0, 8739, 8740, 17480, rows - 1):            # piece edges, row by row
+        assert rel_rms(fin[lo], wf[lo]) <= 1e-6 and rel_rms(tail[lo], wt[lo]) <= 1e-6
+    nchains, length = 301, 40                               # 46 MB: two pieces of whole chains
+    xc = (rng.standard_normal((nchains * length, 960)) * 30).astype(np.float32)
+    c0 = (rng.standard_normal((nchains, 60)) * 30).astype(np.float32)
+    pcm, tails = ctx.imdct_chain(0, xc, c0, nchains=nchains, pinned=pinned)
+    for c in (0, 1, 227, 228, 229, nchains - 1):
+        wp, wt1 = oracle.imdct_chain(0, xc[c * length:(c + 1) * length], c0[c])
+        assert rel_rms(pcm[c * length:(c + 1) * length], wp) <= 1e-6
+        assert rel_rms(tails[c], wt1) <= 1e-6
+    small, _ = ctx.imdct_batch(3, x[:5, :120].copy(), None)   # and a batch far below one piece
+    assert rel_rms(small, oracle.imdct_batch(3, x[:5, :120].copy(), None)[0]) <= 1e-6
+
+
 def test_empty_batch_and_bad_arguments(ctx):
     import libnyquist_amd as nyq
     fin, tail = ctx.imdct_batch(0, np.zeros((0, 960), np.float32))

@@ -54,7 +54,7 @@ for n, rows in () if ONLY and ONLY != 'vorbis' else ((2048, 1 << 19), (256, 1 <<
     ms = timeit(lambda: ctx.vorbis_imdct_batch_dev(n, x.data_ptr(), y.data_ptr(), rows))
     res.append(dict(op=f"vorbis_imdct_batch_dev n {n}", rows=rows, ms=ms, alg_GBps=rows * n * 6 / ms / 1e6, rows_per_s=rows / ms * 1e3))
     del x, y
-ns, nf, ch = 1024, 256, 2
+ns, nf, ch = 1024, int(os.environ.get("SWEEP_NF", "256")), 2
 pcm = torch.randn((ns * ch, nf * 960), generator=g, device=dev) * 300
 out = torch.empty((ns, nf * 960, ch), device=dev)
 pt = torch.randint(0, 3, (ns, nf), generator=g, device=dev, dtype=torch.int32)
