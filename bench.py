@@ -68,6 +68,46 @@ def cpu_share():
     return n
 
 
+def opus_file_decode_leg(count=256):
+    """File-level decode of `count` copies of tests/golden/short.opus (220 stereo 20 ms CELT frames + one
+    closing 2.5 ms frame each, 123 kbit/s) as ONE batch through libnyquist_host (CPU entropy stage in
+    threads, IMDCT/post-filter pieces on the GPU behind it, PCIe included), and the same files through the
+    reference's own NyquistIO::Load on the same number of host threads (oracle/_ref/libref_decode.so: the
+    cpu_baseline of this leg)."""
+    threads = cpu_share()
+    raw = open(os.path.join(ROOT, "tests", "golden", "short.opus"), "rb").read()
+    H = ctypes.CDLL(os.path.join(ROOT, "libnyquist_amd", "libnyquist_host.so"))
+    H.nyqh_batch_decode.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_long, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")]
+    H.nyqh_batch_decode.restype = ctypes.c_long
+    n = 421930
+    first = np.zeros(n, np.float32)
+    stats = np.zeros(4, np.float64)
+    H.nyqh_batch_decode(raw, len(raw), count, threads, first.ctypes.data_as(ctypes.c_void_p), None, n, stats)   # contexts, pinned staging
+    got = H.nyqh_batch_decode(raw, len(raw), count, threads, first.ctypes.data_as(ctypes.c_void_p), None, n, stats)
+    if got != n:
+        raise RuntimeError(f"nyqh_batch_decode returned {got}")
+    cpu_s, tail_s, frames, thr = stats
+    leg = {"files": count, "frames": int(frames), "host_threads": int(thr), "seconds": cpu_s + tail_s,
+           "files_per_sec": count / (cpu_s + tail_s), "frames_per_sec": frames / (cpu_s + tail_s),
+           "cpu_entropy_stage_s": cpu_s, "not_hidden_gpu_and_trim_s": tail_s,
+           "x_realtime": count * (n / 2 / 48000.0) / (cpu_s + tail_s), "checksum_file0": float(first.astype(np.float64).sum())}
+    rp = os.path.join(ROOT, "oracle", "_ref", "libref_decode.so")
+    if os.path.exists(rp):
+        R = ctypes.CDLL(rp)
+        R.ref_decode_bench.restype = ctypes.c_double
+        R.ref_decode_bench.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.POINTER(ctypes.c_long),
+                                       ctypes.POINTER(ctypes.c_double)]
+        ns, ck = ctypes.c_long(0), ctypes.c_double(0)
+        R.ref_decode_bench(raw, len(raw), min(count, 2 * threads), threads, ctypes.byref(ns), ctypes.byref(ck))   # warm
+        secs = R.ref_decode_bench(raw, len(raw), count, threads, ctypes.byref(ns), ctypes.byref(ck))
+        leg["cpu_baseline"] = {"kind": "reference", "cores": threads, "seconds": secs, "files_per_sec": count / secs,
+                               "samples_per_file": int(ns.value), "checksum_file0": ck.value,
+                               "sample": f"{count} in-memory copies of short.opus through the reference's NyquistIO::Load, {threads} threads"}
+        leg["vs_cpu_baseline"] = secs / (cpu_s + tail_s)
+    return leg
+
+
 def cpu_baseline(x_sample, seconds=12.0):
     """Time the CPU path on `x_sample` ([rows][960] float32) for about `seconds` of wall time:
     one thread per usable core, each looping over its own slice until the deadline."""
@@ -285,6 +325,13 @@ def main():
         except Exception as e:
             host_boundary = {"error": repr(e)}
 
+    file_leg = None
+    if rank == 0 and world == 1 and not args.no_host_leg:
+        try:
+            file_leg = opus_file_decode_leg()
+        except Exception as e:
+            file_leg = {"error": repr(e)}
+
     if world > 1:
         t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -340,6 +387,7 @@ def main():
             "parity_rel_rms_vs_oracle": parity,
             "opus_frame_synthesis": synth,
             "host_boundary": host_boundary,
+            "opus_file_decode": file_leg,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "nyq::imdct_rows_kernel<32, KCfg<1,false,0>>", "kernel_avg_ms": kern_avg_ms,

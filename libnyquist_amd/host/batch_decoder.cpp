@@ -5,10 +5,15 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
+#include <mutex>
 #include <stdexcept>
 #include <thread>
+#include <tuple>
 
 #include "../../include/nyq_imdct.h"
 #include "celt_decoder.hpp"
@@ -19,6 +24,13 @@ namespace nyq_host {
 namespace {
 
 // a run of consecutive frames of one size
+struct SegPlan {
+    int LM = 0;
+    long nframes = 0;
+};
+
+// decoded storage of a segment that is NOT the first of its stream (rare: encoders often close a stream
+// with shorter frames); first segments are decoded in place into the group buffers below
 struct Segment {
     int LM = 0;
     long nframes = 0;
@@ -28,37 +40,38 @@ struct Segment {
     std::vector<float> pfGain;
 };
 
-// what pass 1 leaves behind for one elementary (mono or coupled) Opus stream
+// one elementary (mono or coupled) Opus stream
 struct StreamFrames {
     int channels = 0;
-    std::vector<Segment> segs;          // usually one; encoders often close a stream with shorter frames
+    std::vector<SegPlan> plan;          // from the scan: frame sizes and counts, nothing decoded yet
+    std::vector<Segment> later;         // plan[1..] decoded
+    // where the first segment goes (set by the layout step): slot `slot` of group `group`
+    size_t group = 0, slot = 0, piece = 0;
+    float *freq0 = nullptr;
+    uint8_t *tr0 = nullptr;
+    int *pp0 = nullptr, *pt0 = nullptr;
+    float *pg0 = nullptr;
     long nframes = 0, transientCount = 0;
     int64_t samples = 0;                // decoded samples per channel over all segments
 };
 
-// one input file: its header and its elementary streams (one for mapping family 0)
+// one input file: its demultiplexed packets, header and elementary streams (one for mapping family 0)
 struct FileJob {
-    OpusHead head;
-    int64_t lastGranule = -1;
+    OggOpusFile f;
     std::vector<StreamFrames> subs;
     std::string error;
 };
 
-void entropyDecode(const std::vector<uint8_t> &file, FileJob &job) {
-    OggOpusFile f = parseOggOpus(file.data(), file.size());
-    if (f.head.mappingFamily != 0 && f.head.mappingFamily != 1 && f.head.mappingFamily != 255)
+// pass 0: container and packet framing only -- how many frames of which size every stream holds
+void scanFile(const std::vector<uint8_t> &file, FileJob &job) {
+    job.f = parseOggOpus(file.data(), file.size());
+    const OpusHead &h = job.f.head;
+    if (h.mappingFamily != 0 && h.mappingFamily != 1 && h.mappingFamily != 255)
         throw std::runtime_error("unsupported channel mapping family");
-    job.head = f.head;
-    job.lastGranule = f.lastGranule;
-    const int S = f.head.streamCount;
+    const int S = h.streamCount;
     job.subs.assign(S, StreamFrames());
-    std::vector<CeltDecoder> decs;
-    decs.reserve(S);
-    for (int k = 0; k < S; k++) {
-        job.subs[k].channels = k < f.head.coupledCount ? 2 : 1;
-        decs.emplace_back(job.subs[k].channels);
-    }
-    for (const auto &pkt : f.packets) {
+    for (int k = 0; k < S; k++) job.subs[k].channels = k < h.coupledCount ? 2 : 1;
+    for (const auto &pkt : job.f.packets) {
         const uint8_t *p = pkt.data();
         int rem = (int)pkt.size();
         for (int k = 0; k < S; k++) {                       // opus_multistream_decoder.c:237-290
@@ -69,28 +82,10 @@ void entropyDecode(const std::vector<uint8_t> &file, FileJob &job) {
             StreamFrames &s = job.subs[k];
             int LM = 0;
             while ((120 << LM) != pf.frameSize) LM++;
-            if (s.segs.empty() || s.segs.back().LM != LM) {
-                s.segs.emplace_back();
-                s.segs.back().LM = LM;
-            }
-            Segment &g = s.segs.back();
-            decs[k].setEndBand(pf.bandwidthEnd);
-            decs[k].setStreamChannels(pf.stereo ? 2 : 1);
-            const size_t N = (size_t)pf.frameSize;
-            for (const auto &fr : pf.frames) {
-                g.freq.resize((size_t)(g.nframes + 1) * s.channels * N);
-                CeltFrame info;
-                const int rc = decs[k].decode(fr.first, fr.second, pf.frameSize, g.freq.data() + (size_t)g.nframes * s.channels * N, info);
-                if (rc < 0) throw std::runtime_error("CELT frame failed to decode");
-                g.transient.push_back(info.transient);
-                g.pfPitch.push_back(info.pfPitch);
-                g.pfTapset.push_back(info.pfTapset);
-                g.pfGain.push_back(info.pfGain);
-                s.transientCount += info.transient;
-                g.nframes++;
-                s.nframes++;
-                s.samples += (int64_t)N;
-            }
+            if (s.plan.empty() || s.plan.back().LM != LM) s.plan.push_back({LM, 0});
+            s.plan.back().nframes += (long)pf.frames.size();
+            s.nframes += (long)pf.frames.size();
+            s.samples += (int64_t)pf.frames.size() * pf.frameSize;
             p += used;
             rem -= used;
         }
@@ -99,16 +94,129 @@ void entropyDecode(const std::vector<uint8_t> &file, FileJob &job) {
         if (s.nframes == 0 || s.samples != job.subs[0].samples) throw std::runtime_error("no audio frames / streams of unequal length");
 }
 
+// pass 1: the bit-serial half of every frame (range decoder ... denormalisation), first segments straight
+// into the group buffers the GPU reads
+void entropyDecode(FileJob &job) {
+    const int S = job.f.head.streamCount;
+    std::vector<CeltDecoder> decs;
+    decs.reserve(S);
+    std::vector<size_t> seg(S, 0);
+    std::vector<long> done(S, 0);                           // frames decoded in the current segment
+    for (int k = 0; k < S; k++) {
+        StreamFrames &s = job.subs[k];
+        decs.emplace_back(s.channels);
+        s.later.resize(s.plan.size() - 1);
+        for (size_t g = 1; g < s.plan.size(); g++) {
+            Segment &L = s.later[g - 1];
+            L.LM = s.plan[g].LM;
+            L.nframes = s.plan[g].nframes;
+            L.freq.resize((size_t)L.nframes * s.channels * ((size_t)120 << L.LM));
+            L.transient.resize(L.nframes);
+            L.pfPitch.resize(L.nframes);
+            L.pfTapset.resize(L.nframes);
+            L.pfGain.resize(L.nframes);
+        }
+    }
+    for (const auto &pkt : job.f.packets) {
+        const uint8_t *p = pkt.data();
+        int rem = (int)pkt.size();
+        for (int k = 0; k < S; k++) {
+            PacketFrames pf;
+            int used = rem;
+            parseOpusPacket(p, rem, pf, k != S - 1, &used);  // validated by the scan
+            StreamFrames &s = job.subs[k];
+            decs[k].setEndBand(pf.bandwidthEnd);
+            decs[k].setStreamChannels(pf.stereo ? 2 : 1);
+            const size_t N = (size_t)pf.frameSize;
+            for (const auto &fr : pf.frames) {
+                if (done[k] == s.plan[seg[k]].nframes) { seg[k]++; done[k] = 0; }
+                const long i = done[k]++;
+                Segment *L = seg[k] ? &s.later[seg[k] - 1] : nullptr;
+                float *dst = (L ? L->freq.data() : s.freq0) + (size_t)i * s.channels * N;
+                CeltFrame info;
+                if (decs[k].decode(fr.first, fr.second, pf.frameSize, dst, info) < 0)
+                    throw std::runtime_error("CELT frame failed to decode");
+                (L ? L->transient.data() : s.tr0)[i] = info.transient;
+                (L ? L->pfPitch.data() : s.pp0)[i] = info.pfPitch;
+                (L ? L->pfTapset.data() : s.pt0)[i] = info.pfTapset;
+                (L ? L->pfGain.data() : s.pg0)[i] = info.pfGain;
+                s.transientCount += info.transient;
+            }
+            p += used;
+            rem -= used;
+        }
+    }
+}
+
+// streams of one shape (channels, frame size of the first segment), padded to the longest
+struct Group {
+    int ch = 0, LM = 0;
+    size_t N = 0, ns = 0, maxF = 0;
+    std::vector<size_t> ids;            // flattened stream indices, slot order
+    float *freq = nullptr, *out = nullptr, *pg = nullptr;
+    int *pp = nullptr, *pt = nullptr;
+    uint8_t *tr = nullptr;
+};
+
+// a run of slots of one group: the unit handed to the GPU as soon as its streams are decoded
+struct Piece {
+    size_t group = 0, k0 = 0, k1 = 0;
+    std::atomic<int> remaining{0};
+    bool anyMore = false;               // some stream continues with another segment: fetch decoder state
+    Piece() = default;
+    Piece(const Piece &o) : group(o.group), k0(o.k0), k1(o.k1), remaining(o.remaining.load()), anyMore(o.anyMore) {}
+};
+
+constexpr size_t kPieceBytes = (size_t)24 << 20;   // of freq per piece
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+template <class F>
+void parallelFor(size_t n, int threads, F &&body) {
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (size_t i = next++; i < n; i = next++) body(i);
+    };
+    std::vector<std::thread> pool;
+    const int extra = (int)std::min<size_t>(threads > 0 ? threads - 1 : 0, n > 0 ? n - 1 : 0);
+    for (int t = 0; t < extra; t++) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+}
+
 }  // namespace
 
 BatchOpusDecoder::BatchOpusDecoder(int device) {
-    nyq_ctx *c = nullptr;
-    if (nyq_ctx_create(&c, device) != NYQ_OK)
-        throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(nullptr));
-    ctx_ = c;
+    for (int k = 0; k < 2; k++) {      // two contexts: one piece uploads while the previous one downloads
+        nyq_ctx *c = nullptr;
+        if (nyq_ctx_create(&c, device) != NYQ_OK) {
+            if (ctx_) nyq_ctx_destroy((nyq_ctx *)ctx_);
+            throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(nullptr));
+        }
+        (k == 0 ? ctx_ : ctx2_) = c;
+    }
 }
 
-BatchOpusDecoder::~BatchOpusDecoder() { nyq_ctx_destroy((nyq_ctx *)ctx_); }
+BatchOpusDecoder::~BatchOpusDecoder() {
+    if (arena_) (pinned_ ? nyq_host_free(arena_) : std::free(arena_));
+    nyq_ctx_destroy((nyq_ctx *)ctx2_);
+    nyq_ctx_destroy((nyq_ctx *)ctx_);
+}
+
+// page-locked staging memory, kept from call to call (grow only); pageable memory if pinning fails
+void *BatchOpusDecoder::arena(size_t bytes) {
+    if (bytes <= arenaBytes_) return arena_;
+    if (arena_) (pinned_ ? nyq_host_free(arena_) : std::free(arena_));
+    arena_ = nullptr;
+    arenaBytes_ = 0;
+    const size_t want = bytes + bytes / 8;
+    arena_ = nyq_host_alloc(want);
+    pinned_ = arena_ != nullptr;
+    if (!arena_) arena_ = std::aligned_alloc(4096, (want + 4095) & ~(size_t)4095);
+    if (!arena_) throw std::bad_alloc();
+    arenaBytes_ = want;
+    return arena_;
+}
 
 void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &files, std::vector<DecodedStream> &out,
                               BatchStats *stats, int threads) {
@@ -116,25 +224,15 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
     out.assign(nfiles, DecodedStream());
     std::vector<FileJob> jobs(nfiles);
     if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
-    threads = (int)std::min<size_t>(threads, std::max<size_t>(nfiles, 1));
     auto t0 = std::chrono::steady_clock::now();
-    {   // pass 1: one file at a time per thread
-        std::atomic<size_t> next{0};
-        auto work = [&]() {
-            for (size_t i = next++; i < nfiles; i = next++) {
-                try {
-                    entropyDecode(*files[i], jobs[i]);
-                } catch (const std::exception &e) {
-                    jobs[i].error = e.what();
-                }
-            }
-        };
-        std::vector<std::thread> pool;
-        for (int t = 1; t < threads; t++) pool.emplace_back(work);
-        work();
-        for (auto &t : pool) t.join();
-    }
-    auto t1 = std::chrono::steady_clock::now();
+    // pass 0: scan
+    parallelFor(nfiles, threads, [&](size_t i) {
+        try {
+            scanFile(*files[i], jobs[i]);
+        } catch (const std::exception &e) {
+            jobs[i].error = e.what();
+        }
+    });
     // the GPU batch is over ELEMENTARY streams: flatten (file, stream) pairs
     std::vector<StreamFrames *> sfp;
     std::vector<size_t> firstSub(nfiles, 0);
@@ -148,123 +246,280 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
         std::vector<StreamFrames *> &v;
         StreamFrames &operator[](size_t i) { return *v[i]; }
     } sf{sfp};
-    // pass 2: the first segment of every stream, grouped by (channels, LM) and padded to the longest,
-    // goes to the GPU as one call per group; decoder state comes back so that the rare later segments
-    // (a different frame size) continue exactly where the previous one stopped.
-    nyq_ctx *ctx = (nyq_ctx *)ctx_;
-    std::vector<std::vector<float>> pcmAll(n);            // interleaved, all segments, untrimmed
-    std::vector<std::vector<float>> stateOf(n);           // per-stream decoder state (nstreams = 1 layout)
-    std::map<std::pair<int, int>, std::vector<size_t>> groups;
-    for (size_t i = 0; i < n; i++) groups[{sf[i].channels, sf[i].segs[0].LM}].push_back(i);
-    long totalFrames = 0;
-    for (auto &g : groups) {
-        const int ch = g.first.first, LM = g.first.second;
-        const size_t N = (size_t)120 << LM;
-        const std::vector<size_t> &ids = g.second;
-        size_t maxF = 0;
-        for (size_t i : ids) maxF = std::max(maxF, (size_t)sf[i].segs[0].nframes);
-        const size_t ns = ids.size(), nsc = ns * ch;
-        std::vector<float> freq(ns * maxF * ch * N, 0.f), pcm(ns * maxF * N * ch);
-        std::vector<uint8_t> tr(ns * maxF, 0);
-        std::vector<int> pp(ns * maxF, 0), pt(ns * maxF, 0);
-        std::vector<float> pg(ns * maxF, 0.f);
-        bool anyMore = false;
-        for (size_t k = 0; k < ns; k++) {
-            const Segment &s = sf[ids[k]].segs[0];
-            std::memcpy(&freq[k * maxF * ch * N], s.freq.data(), s.freq.size() * sizeof(float));
-            std::memcpy(&tr[k * maxF], s.transient.data(), s.transient.size());
-            std::memcpy(&pp[k * maxF], s.pfPitch.data(), s.pfPitch.size() * sizeof(int));
-            std::memcpy(&pt[k * maxF], s.pfTapset.data(), s.pfTapset.size() * sizeof(int));
-            std::memcpy(&pg[k * maxF], s.pfGain.data(), s.pfGain.size() * sizeof(float));
-            totalFrames += s.nframes;
-            anyMore |= sf[ids[k]].segs.size() > 1;
+    // layout: the first segment of every stream, grouped by (channels, LM) and padded to the longest; a
+    // group is cut into pieces of consecutive slots, each one GPU call
+    std::map<std::pair<int, int>, size_t> groupOf;
+    std::vector<Group> groups;
+    for (size_t i = 0; i < n; i++) {
+        const std::pair<int, int> key{sf[i].channels, sf[i].plan[0].LM};
+        auto it = groupOf.find(key);
+        if (it == groupOf.end()) {
+            it = groupOf.emplace(key, groups.size()).first;
+            groups.emplace_back();
+            groups.back().ch = key.first;
+            groups.back().LM = key.second;
+            groups.back().N = (size_t)120 << key.second;
         }
-        // the state is only meaningful for streams whose first segment fills the whole padded length;
-        // streams that continue with another segment are therefore given their own call when they are shorter
-        std::vector<float> state(anyMore ? nyq_celt_state_floats(ns, ch) : 0, 0.f);
-        if (nyq_celt_frames_to_pcm(ctx, LM, freq.data(), tr.data(), pp.data(), pg.data(), pt.data(), pcm.data(),
-                                   anyMore ? state.data() : nullptr, ns, maxF, ch) != NYQ_OK)
-            throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(ctx));
-        for (size_t k = 0; k < ns; k++) {
-            const size_t i = ids[k];
-            const Segment &s = sf[i].segs[0];
-            pcmAll[i].assign(&pcm[k * maxF * N * ch], &pcm[k * maxF * N * ch] + (size_t)s.nframes * N * ch);
-            if (sf[i].segs.size() > 1) {
-                if ((size_t)s.nframes != maxF) {           // padded with silent frames: redo alone for an exact state
-                    std::vector<float> st1(nyq_celt_state_floats(1, ch), 0.f), out1((size_t)s.nframes * N * ch);
-                    if (nyq_celt_frames_to_pcm(ctx, LM, s.freq.data(), s.transient.data(), s.pfPitch.data(), s.pfGain.data(),
-                                               s.pfTapset.data(), out1.data(), st1.data(), 1, (size_t)s.nframes, ch) != NYQ_OK)
-                        throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(ctx));
-                    stateOf[i] = st1;
-                } else {                                   // slice stream k out of the group state
-                    std::vector<float> st1(nyq_celt_state_floats(1, ch));
-                    const float *ov = state.data(), *hi = ov + nsc * 60, *de = hi + nsc * 1088, *pf = de + nsc;
-                    float *o = st1.data();
-                    std::memcpy(o, ov + k * ch * 60, sizeof(float) * ch * 60); o += ch * 60;
-                    std::memcpy(o, hi + k * ch * 1088, sizeof(float) * ch * 1088); o += ch * 1088;
-                    std::memcpy(o, de + k * ch, sizeof(float) * ch); o += ch;
-                    std::memcpy(o, pf + k * 6, sizeof(float) * 6);
-                    stateOf[i] = st1;
-                }
+        Group &g = groups[it->second];
+        sf[i].group = it->second;
+        sf[i].slot = g.ids.size();
+        g.ids.push_back(i);
+        g.maxF = std::max(g.maxF, (size_t)sf[i].plan[0].nframes);
+    }
+    size_t bytes = 0;
+    for (Group &g : groups) {
+        g.ns = g.ids.size();
+        const size_t x = g.ns * g.maxF * g.ch * g.N * sizeof(float), q = g.ns * g.maxF;
+        bytes += 2 * align256(x) + 3 * align256(q * 4) + align256(q);
+    }
+    char *base = (char *)arena(bytes);
+    std::vector<Piece> pieces;
+    for (size_t gi = 0; gi < groups.size(); gi++) {
+        Group &g = groups[gi];
+        const size_t x = g.ns * g.maxF * g.ch * g.N * sizeof(float), q = g.ns * g.maxF;
+        g.freq = (float *)base; base += align256(x);
+        g.out = (float *)base; base += align256(x);
+        g.pg = (float *)base; base += align256(q * 4);
+        g.pp = (int *)base; base += align256(q * 4);
+        g.pt = (int *)base; base += align256(q * 4);
+        g.tr = (uint8_t *)base; base += align256(q);
+        std::memset(g.pg, 0, q * 4);                        // padded frames: no post-filter, not transient
+        std::memset(g.pp, 0, q * 4);
+        std::memset(g.pt, 0, q * 4);
+        std::memset(g.tr, 0, q);
+        const size_t per = std::max<size_t>(1, kPieceBytes / std::max<size_t>(1, g.maxF * g.ch * g.N * sizeof(float)));
+        for (size_t k0 = 0; k0 < g.ns; k0 += per) {
+            pieces.emplace_back();
+            Piece &p = pieces.back();
+            p.group = gi;
+            p.k0 = k0;
+            p.k1 = std::min(g.ns, k0 + per);
+            p.remaining = (int)(p.k1 - p.k0);
+        }
+    }
+    {   // slots -> pieces, destination pointers
+        size_t pi = 0;
+        for (size_t gi = 0; gi < groups.size(); gi++) {
+            Group &g = groups[gi];
+            for (size_t k = 0; k < g.ns; k++) {
+                while (!(pieces[pi].group == gi && k >= pieces[pi].k0 && k < pieces[pi].k1)) pi++;
+                StreamFrames &s = sf[g.ids[k]];
+                s.piece = pi;
+                s.freq0 = g.freq + k * g.maxF * g.ch * g.N;
+                s.tr0 = g.tr + k * g.maxF;
+                s.pp0 = g.pp + k * g.maxF;
+                s.pt0 = g.pt + k * g.maxF;
+                s.pg0 = g.pg + k * g.maxF;
+                if (s.plan.size() > 1) pieces[pi].anyMore = true;
             }
         }
     }
-    for (size_t i = 0; i < n; i++) {                       // later segments, one stream at a time
-        const int ch = sf[i].channels;
-        for (size_t g = 1; g < sf[i].segs.size(); g++) {
-            const Segment &s = sf[i].segs[g];
-            const size_t N = (size_t)120 << s.LM;
-            std::vector<float> out1((size_t)s.nframes * N * ch);
-            if (nyq_celt_frames_to_pcm(ctx, s.LM, s.freq.data(), s.transient.data(), s.pfPitch.data(), s.pfGain.data(),
-                                       s.pfTapset.data(), out1.data(), stateOf[i].data(), 1, (size_t)s.nframes, ch) != NYQ_OK)
+    // pass 1 (CPU threads) and pass 2 (two feeder threads, one GPU context each) run at the same time: a
+    // piece goes to the GPU when the last of its streams has been decoded
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<size_t> ready;
+    size_t handedOut = 0;
+    std::string gpuError;
+    std::vector<std::vector<float>> stateOf(n);           // decoder state of streams that continue (nstreams = 1 layout)
+    std::atomic<long> totalFrames{0};
+    double gpuBusy[2] = {0, 0};
+    auto feeder = [&](int which) {
+        nyq_ctx *ctx = (nyq_ctx *)(which == 0 ? ctx_ : ctx2_);
+        for (;;) {
+            size_t pi;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !ready.empty() || handedOut == pieces.size(); });
+                if (ready.empty()) return;
+                pi = ready.front();
+                ready.pop_front();
+            }
+            const Piece &p = pieces[pi];
+            const Group &g = groups[p.group];
+            const size_t ns = p.k1 - p.k0, nsc = ns * g.ch, so = p.k0 * g.maxF;
+            std::vector<float> state(p.anyMore ? nyq_celt_state_floats(ns, g.ch) : 0, 0.f);
+            auto c0 = std::chrono::steady_clock::now();
+            try {
+                if (nyq_celt_frames_to_pcm(ctx, g.LM, g.freq + so * g.ch * g.N, g.tr + so, g.pp + so, g.pg + so, g.pt + so,
+                                           g.out + so * g.ch * g.N, p.anyMore ? state.data() : nullptr, ns, g.maxF, g.ch) != NYQ_OK)
+                    throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(ctx));
+                // the group state is exact only for streams whose first segment fills the whole padded length;
+                // a shorter stream that continues with another segment is given its own call
+                for (size_t k = p.k0; p.anyMore && k < p.k1; k++) {
+                    const size_t i = g.ids[k];
+                    StreamFrames &s = sf[i];
+                    if (s.plan.size() < 2) continue;
+                    std::vector<float> st1(nyq_celt_state_floats(1, g.ch), 0.f);
+                    if ((size_t)s.plan[0].nframes != g.maxF) {
+                        std::vector<float> out1((size_t)s.plan[0].nframes * g.N * g.ch);
+                        if (nyq_celt_frames_to_pcm(ctx, g.LM, s.freq0, s.tr0, s.pp0, s.pg0, s.pt0, out1.data(), st1.data(), 1,
+                                                   (size_t)s.plan[0].nframes, g.ch) != NYQ_OK)
+                            throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(ctx));
+                    } else {                               // slice stream k out of the piece's state
+                        const size_t kk = k - p.k0;
+                        const float *ov = state.data(), *hi = ov + nsc * 60, *de = hi + nsc * 1088, *pf = de + nsc;
+                        float *o = st1.data();
+                        std::memcpy(o, ov + kk * g.ch * 60, sizeof(float) * g.ch * 60); o += g.ch * 60;
+                        std::memcpy(o, hi + kk * g.ch * 1088, sizeof(float) * g.ch * 1088); o += g.ch * 1088;
+                        std::memcpy(o, de + kk * g.ch, sizeof(float) * g.ch); o += g.ch;
+                        std::memcpy(o, pf + kk * 6, sizeof(float) * 6);
+                    }
+                    stateOf[i] = std::move(st1);
+                }
+            } catch (const std::exception &e) {
+                std::lock_guard<std::mutex> lk(mu);
+                if (gpuError.empty()) gpuError = e.what();
+            }
+            gpuBusy[which] += std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
+        }
+    };
+    std::thread feed0(feeder, 0), feed1(feeder, 1);
+    parallelFor(nfiles, threads, [&](size_t i) {
+        FileJob &job = jobs[i];
+        if (!job.error.empty()) return;
+        try {
+            entropyDecode(job);
+        } catch (const std::exception &e) {
+            job.error = e.what();
+        }
+        for (StreamFrames &s : job.subs) {
+            const Group &g = groups[s.group];
+            const size_t have = job.error.empty() ? (size_t)s.plan[0].nframes : 0;   // a failed file plays as silence
+            std::memset(s.freq0 + have * g.ch * g.N, 0, (g.maxF - have) * g.ch * g.N * sizeof(float));
+            if (!job.error.empty()) {
+                std::memset(s.tr0, 0, g.maxF);
+                std::memset(s.pp0, 0, g.maxF * 4);
+                std::memset(s.pt0, 0, g.maxF * 4);
+                std::memset(s.pg0, 0, g.maxF * 4);
+            }
+            totalFrames += s.plan[0].nframes;
+            if (--pieces[s.piece].remaining == 0) {
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    ready.push_back(s.piece);
+                    handedOut++;
+                }
+                cv.notify_all();
+            }
+        }
+    });
+    auto t1 = std::chrono::steady_clock::now();
+    {
+        std::lock_guard<std::mutex> lk(mu);   // nothing to decode at all: let the feeders leave
+        if (pieces.empty()) handedOut = 0;
+    }
+    cv.notify_all();
+    feed0.join();
+    feed1.join();
+    if (!gpuError.empty()) throw std::runtime_error(gpuError);
+    nyq_ctx *ctx = (nyq_ctx *)ctx_;
+    // Later segments (a stream that changes its frame size, typically a short closing frame): round r takes
+    // segment r of every stream that has one, batched over the streams of equal shape (channels, frame size,
+    // frame count -- no padding, so the decoder state that comes back is exact) with their states gathered
+    // into the batch layout and scattered back.
+    std::vector<std::vector<float>> laterPcm(n);
+    for (size_t r = 1;; r++) {
+        std::map<std::tuple<int, int, long>, std::vector<size_t>> shapes;
+        for (size_t i = 0; i < n; i++)
+            if (sf[i].later.size() >= r && !stateOf[i].empty())   // (no state: the file failed in pass 1)
+                shapes[std::make_tuple(sf[i].channels, sf[i].later[r - 1].LM, sf[i].later[r - 1].nframes)].push_back(i);
+        if (shapes.empty()) break;
+        for (const auto &kv : shapes) {
+            const int ch = std::get<0>(kv.first), LM = std::get<1>(kv.first);
+            const size_t nf = (size_t)std::get<2>(kv.first), N = (size_t)120 << LM;
+            const std::vector<size_t> &ids = kv.second;
+            const size_t ns = ids.size(), nsc = ns * ch, per = nf * ch * N;
+            std::vector<float> freq(ns * per), pcm(ns * per), pg(ns * nf), state(nyq_celt_state_floats(ns, ch));
+            std::vector<int> pp(ns * nf), pt(ns * nf);
+            std::vector<uint8_t> tr(ns * nf);
+            float *ov = state.data(), *hi = ov + nsc * 60, *de = hi + nsc * 1088, *pf = de + nsc;
+            for (size_t k = 0; k < ns; k++) {
+                const Segment &sg = sf[ids[k]].later[r - 1];
+                std::memcpy(&freq[k * per], sg.freq.data(), per * sizeof(float));
+                std::memcpy(&tr[k * nf], sg.transient.data(), nf);
+                std::memcpy(&pp[k * nf], sg.pfPitch.data(), nf * sizeof(int));
+                std::memcpy(&pt[k * nf], sg.pfTapset.data(), nf * sizeof(int));
+                std::memcpy(&pg[k * nf], sg.pfGain.data(), nf * sizeof(float));
+                const float *o = stateOf[ids[k]].data();
+                std::memcpy(ov + k * ch * 60, o, sizeof(float) * ch * 60); o += ch * 60;
+                std::memcpy(hi + k * ch * 1088, o, sizeof(float) * ch * 1088); o += ch * 1088;
+                std::memcpy(de + k * ch, o, sizeof(float) * ch); o += ch;
+                std::memcpy(pf + k * 6, o, sizeof(float) * 6);
+            }
+            if (nyq_celt_frames_to_pcm(ctx, LM, freq.data(), tr.data(), pp.data(), pg.data(), pt.data(), pcm.data(), state.data(),
+                                       ns, nf, ch) != NYQ_OK)
                 throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(ctx));
-            pcmAll[i].insert(pcmAll[i].end(), out1.begin(), out1.end());
-            totalFrames += s.nframes;
+            for (size_t k = 0; k < ns; k++) {
+                const size_t i = ids[k];
+                laterPcm[i].insert(laterPcm[i].end(), &pcm[k * per], &pcm[k * per] + per);
+                float *o = stateOf[i].data();
+                std::memcpy(o, ov + k * ch * 60, sizeof(float) * ch * 60); o += ch * 60;
+                std::memcpy(o, hi + k * ch * 1088, sizeof(float) * ch * 1088); o += ch * 1088;
+                std::memcpy(o, de + k * ch, sizeof(float) * ch); o += ch;
+                std::memcpy(o, pf + k * 6, sizeof(float) * 6);
+                totalFrames += (long)nf;
+            }
         }
     }
     // pass 3: channel mapping (opus_multistream_decoder.c:305-331), then trimming (opusfile: skip pre_skip
     // samples, stop at the last page's granule position) and the header gain
-    for (size_t i = 0; i < nfiles; i++) {
-        if (!jobs[i].error.empty()) continue;
+    parallelFor(nfiles, threads, [&](size_t i) {
+        if (!jobs[i].error.empty()) return;
         const FileJob &job = jobs[i];
+        const OpusHead &head = job.f.head;
         DecodedStream &d = out[i];
-        const int ch = job.head.channels;
+        const int ch = head.channels;
         d.channels = ch;
-        d.preSkip = job.head.preSkip;
+        d.preSkip = head.preSkip;
         const int64_t decoded = job.subs[0].samples;
         for (const auto &sub : job.subs) {
             d.frames += sub.nframes;
             d.transientFrames += sub.transientCount;
         }
-        const int64_t endSample = job.lastGranule >= 0 ? std::min<int64_t>(decoded, job.lastGranule) : decoded;
-        int64_t total = endSample - job.head.preSkip;
+        const int64_t endSample = job.f.lastGranule >= 0 ? std::min<int64_t>(decoded, job.f.lastGranule) : decoded;
+        int64_t total = endSample - head.preSkip;
         if (total < 0) total = 0;
         d.totalSamples = total;
-        d.pcm.assign((size_t)total * ch, 0.f);
-        const float gain = job.head.outputGainQ8 == 0 ? 1.f   // OPUS_SET_GAIN, opus_decoder_clean.c:700-712
-                                                       : (float)std::exp(0.6931471805599453094 * (6.48814081e-4 * job.head.outputGainQ8));
+        d.pcm.resize((size_t)total * ch);
+        const float gain = head.outputGainQ8 == 0 ? 1.f   // OPUS_SET_GAIN, opus_decoder_clean.c:700-712
+                                                   : (float)std::exp(0.6931471805599453094 * (6.48814081e-4 * head.outputGainQ8));
         for (int c = 0; c < ch; c++) {
-            const int idx = job.head.mapping[c];
-            if (idx == 255) continue;                      // silent channel
-            int sub, sc;
-            if (idx < 2 * job.head.coupledCount) { sub = idx / 2; sc = idx & 1; }
-            else { sub = idx - job.head.coupledCount; sc = 0; }
-            const size_t flat = firstSub[i] + (size_t)sub;
-            const int sch = sf[flat].channels;
-            const float *src = pcmAll[flat].data() + (size_t)job.head.preSkip * sch + sc;
+            const int idx = head.mapping[c];
             float *dst = d.pcm.data() + c;
-            if (gain == 1.f)
-                for (int64_t t = 0; t < total; t++) dst[t * ch] = src[t * sch];
-            else
-                for (int64_t t = 0; t < total; t++) dst[t * ch] = src[t * sch] * gain;
+            if (idx == 255) {                              // silent channel
+                for (int64_t t = 0; t < total; t++) dst[t * ch] = 0.f;
+                continue;
+            }
+            int sub, sc;
+            if (idx < 2 * head.coupledCount) { sub = idx / 2; sc = idx & 1; }
+            else { sub = idx - head.coupledCount; sc = 0; }
+            const size_t flat = firstSub[i] + (size_t)sub;
+            const StreamFrames &s = sf[flat];
+            const Group &g = groups[s.group];
+            const int sch = s.channels;
+            // samples [0, n0) come from the group output, the rest from the later segments
+            const int64_t n0 = (int64_t)s.plan[0].nframes * (int64_t)g.N;
+            const float *src0 = g.out + s.slot * g.maxF * g.N * sch;
+            const float *src1 = laterPcm[flat].data();
+            const int64_t a = head.preSkip, b = head.preSkip + total;
+            if (ch == sch && ch <= 2 && sub == 0 && gain == 1.f && idx == c && b <= n0) {
+                if (c == 0) std::memcpy(d.pcm.data(), src0 + a * sch, (size_t)total * ch * sizeof(float));   // whole frames at once
+                continue;
+            }
+            for (int64_t t = a; t < b; t++) {
+                const float v = t < n0 ? src0[t * sch + sc] : src1[(t - n0) * sch + sc];
+                dst[(t - a) * ch] = gain == 1.f ? v : v * gain;
+            }
         }
-    }
+    });
     auto t2 = std::chrono::steady_clock::now();
     for (size_t i = 0; i < nfiles; i++)
         if (!jobs[i].error.empty()) out[i].error = jobs[i].error;
     if (stats) {
         stats->cpuSeconds = std::chrono::duration<double>(t1 - t0).count();
         stats->gpuSeconds = std::chrono::duration<double>(t2 - t1).count();
+        stats->gpuBusySeconds = gpuBusy[0] + gpuBusy[1];
         stats->frames = totalFrames;
         stats->threads = threads;
     }

@@ -1,8 +1,11 @@
 // batch_decoder.hpp -- the batched two-pass Opus frame loop:
-//   pass 1 (CPU, bit-serial, one thread per stream): Ogg demux -> Opus packets -> CeltDecoder -> freq[]
-//   pass 2 (MI355X, one call per group of equally shaped streams): nyq_celt_frames_to_pcm
-//           = inverse MDCTs + TDAC chaining + post-filter + de-emphasis + interleave
-//   pass 3 (CPU): pre-skip / end trimming (RFC 7845 section 4), header gain.
+//   pass 0 (CPU): Ogg demux + packet framing -> how many frames of which size every stream holds; streams
+//           of one shape form a group with page-locked freq/PCM buffers, cut into pieces of ~24 MB
+//   pass 1 (CPU, bit-serial, one thread per file): CeltDecoder -> freq[] written in place into the group
+//   pass 2 (MI355X, overlapping pass 1): as soon as the streams of a piece are decoded, one of two feeder
+//           threads (one GPU context each: a piece uploads while the previous one downloads) runs
+//           nyq_celt_frames_to_pcm = inverse MDCTs + TDAC chaining + post-filter + de-emphasis + interleave
+//   pass 3 (CPU threads): channel mapping, pre-skip / end trimming (RFC 7845 section 4), header gain.
 // Replaces the per-packet loop of src/OpusDecoder.cpp:95-122 (op_read_float).
 #pragma once
 #include <cstdint>
@@ -24,7 +27,8 @@ struct DecodedStream {
 
 struct BatchStats {
     double cpuSeconds = 0;             // wall time of pass 1
-    double gpuSeconds = 0;             // wall time of pass 2 incl. PCIe copies
+    double gpuSeconds = 0;             // wall time after pass 1: GPU work not hidden behind it, and pass 3
+    double gpuBusySeconds = 0;         // time the two feeder threads spent inside GPU calls (PCIe included)
     long frames = 0;                   // channel-independent frame count over all streams
     int threads = 0;
 };
@@ -40,7 +44,11 @@ public:
                 BatchStats *stats = nullptr, int threads = 0);
 
 private:
-    void *ctx_ = nullptr;              // nyq_ctx*
+    void *arena(size_t bytes);
+    void *ctx_ = nullptr, *ctx2_ = nullptr;   // nyq_ctx*
+    void *arena_ = nullptr;            // staging memory of the groups, kept between calls
+    size_t arenaBytes_ = 0;
+    bool pinned_ = false;
 };
 
 }  // namespace nyq_host

@@ -342,28 +342,31 @@ int computeAllocation(const CeltMode &m, int start, int end, const int *offsets,
 
 // ---- PVQ shape decoding (cwrs.c:469-540, vq.c) ----------------------------------------------------
 void decodePulseVector(int n, int k, uint32_t idx, int *y) {             // cwrsi
+    // U is symmetric, so every lookup of a step reads row n of the table: contiguous in k
+    const uint64_t *T = pvqTable();
     uint64_t i = idx;
     while (n > 2) {
+        const uint64_t *row = T + (size_t)n * kPvqTableDim;
         uint64_t p, q;
         int s, k0;
         if (k >= n) {                                                    // many pulses
-            p = pvqU(n, k + 1);
+            p = row[k + 1];
             s = -(i >= p);
             i -= p & (uint64_t)(int64_t)s;
             k0 = k;
-            q = pvqU(n, n);
+            q = row[n];
             if (q > i) {
                 k = n;
-                do p = pvqU(--k, n);
+                do p = row[--k];
                 while (p > i);
             } else {
-                for (p = pvqU(n, k); p > i; p = pvqU(n, k)) k--;
+                for (p = row[k]; p > i; p = row[k]) k--;
             }
             i -= p;
             *y++ = (k0 - k + s) ^ s;
         } else {                                                         // many dimensions
-            p = pvqU(k, n);
-            q = pvqU(k + 1, n);
+            p = row[k];
+            q = row[k + 1];
             if (p <= i && i < q) {
                 i -= p;
                 *y++ = 0;
@@ -371,7 +374,7 @@ void decodePulseVector(int n, int k, uint32_t idx, int *y) {             // cwrs
                 s = -(i >= q);
                 i -= q & (uint64_t)(int64_t)s;
                 k0 = k;
-                do p = pvqU(--k, n);
+                do p = row[--k];
                 while (p > i);
                 i -= p;
                 *y++ = (k0 - k + s) ^ s;

@@ -9,7 +9,7 @@ namespace nyq_host {
 
 namespace {
 
-constexpr int kMaxDim = 178;   // widest band at LM 3 is 22*8 = 176 bins; k up to 129 is needed
+constexpr int kMaxDim = kPvqTableDim;   // widest band at LM 3 is 22*8 = 176 bins; k up to 129 is needed
 uint64_t g_U[kMaxDim][kMaxDim];
 std::once_flag g_once;
 CeltMode g_mode;
@@ -152,6 +152,11 @@ const CeltMode &mode48k() {
 uint64_t pvqU(int n, int k) {
     std::call_once(g_once, buildMode);
     return g_U[n][k];
+}
+
+const uint64_t *pvqTable() {
+    std::call_once(g_once, buildMode);
+    return &g_U[0][0];
 }
 
 uint64_t pvqV(int n, int k) {

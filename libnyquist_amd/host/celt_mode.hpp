@@ -47,6 +47,8 @@ const CeltMode &mode48k();
 // V(n,k) = U(n,k) + U(n,k+1) codewords of k pulses in n dimensions.  Saturating 64-bit.
 uint64_t pvqU(int n, int k);
 uint64_t pvqV(int n, int k);
+constexpr int kPvqTableDim = 178;      // widest band at LM 3 is 176 bins
+const uint64_t *pvqTable();            // U(n,k) at [n * kPvqTableDim + k], symmetric in (n,k)
 // conservative integer log2 with `frac` fractional bits (cwrs.c:45-71)
 int log2Frac(uint32_t val, int frac);
 inline int ilog(uint32_t v) { return v ? 32 - __builtin_clz(v) : 0; }   // EC_ILOG

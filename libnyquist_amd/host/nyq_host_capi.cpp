@@ -128,7 +128,9 @@ long nyqh_batch_decode(const unsigned char *file, long size, long count, int thr
     try {
         std::vector<uint8_t> buf(file, file + size);
         std::vector<const std::vector<uint8_t> *> files((size_t)count, &buf);
-        nyq_host::BatchOpusDecoder dec(0);
+        // kept for the life of the process (its page-locked staging memory is reused; never destroyed, so no
+        // HIP call runs from a static destructor after the runtime has shut down)
+        static nyq_host::BatchOpusDecoder &dec = *new nyq_host::BatchOpusDecoder(0);
         std::vector<nyq_host::DecodedStream> out;
         nyq_host::BatchStats st;
         dec.decode(files, out, &st, threads);

@@ -23,12 +23,17 @@ raw = open(os.path.join(ROOT, "tests", "golden", "short.opus"), "rb").read()
 n = 421930
 first = np.zeros(n, np.float32)
 stats = np.zeros(4, np.float64)
-H.nyqh_batch_decode(raw, len(raw), 8, threads, first.ctypes.data_as(C.c_void_p), None, n, stats)   # warm up
+import time  # noqa: E402
+
+H.nyqh_batch_decode(raw, len(raw), count, threads, first.ctypes.data_as(C.c_void_p), None, n, stats)   # warm up: contexts, pinned staging
+t0 = time.perf_counter()
 got = H.nyqh_batch_decode(raw, len(raw), count, threads, first.ctypes.data_as(C.c_void_p), None, n, stats)
+wall = time.perf_counter() - t0
 assert got == n
-cpu_s, gpu_s, frames, thr = stats
+cpu_s, tail_s, frames, thr = stats
 print(json.dumps({"streams": count, "frames": int(frames), "threads": int(thr),
                   "cpu_entropy_s": cpu_s, "cpu_frames_per_s": frames / cpu_s, "cpu_frames_per_s_per_thread": frames / cpu_s / thr,
-                  "gpu_stage_s_incl_pcie": gpu_s, "gpu_frames_per_s_incl_pcie": frames / gpu_s,
+                  "after_cpu_s": tail_s, "note": "GPU pieces (PCIe included) overlap the CPU stage; after_cpu_s = what was not hidden + trimming copy",
+                  "wall_s_of_the_call": wall,
                   "audio_seconds": count * 210965 / 48000.0,
-                  "realtime_factor": count * 210965 / 48000.0 / (cpu_s + gpu_s)}))
+                  "realtime_factor": count * 210965 / 48000.0 / (cpu_s + tail_s)}))
