@@ -236,8 +236,8 @@ static int resident_blocks(nyq_ctx *ctx, K kernel, int *cache) {
     return *cache;
 }
 
-static unsigned grid_for(size_t batch, int resident) {
-    const size_t ngroups = (batch + kGroup - 1) / kGroup;
+static unsigned grid_for(size_t batch, int rows_per_group, int resident) {
+    const size_t ngroups = (batch + rows_per_group - 1) / rows_per_group;
     const size_t need = (ngroups + kWavesPerBlock - 1) / kWavesPerBlock;
     return (unsigned)(need < (size_t)resident ? need : (size_t)resident);
 }
@@ -246,7 +246,7 @@ template <int N2R>
 static int launch_imdct(nyq_ctx *ctx, const float *d_in, const float *d_carry, float *d_fin, float *d_tail,
                         size_t batch) {
     const int res = resident_blocks(ctx, imdct_rows_kernel<N2R, Cfg>, &ctx->res_imdct[Geo<N2R>::SHIFT]);
-    hipLaunchKernelGGL((imdct_rows_kernel<N2R, Cfg>), dim3(grid_for(batch, res)), dim3(kWave * kWavesPerBlock), 0,
+    hipLaunchKernelGGL((imdct_rows_kernel<N2R, Cfg>), dim3(grid_for(batch, Geo<N2R>::G, res)), dim3(kWave * kWavesPerBlock), 0,
                        ctx->stream, d_in, d_carry, d_fin, d_tail, (long)batch, ctx->d_trig, ctx->d_window);
     NYQ_HIP(ctx, hipGetLastError());
     return NYQ_OK;
@@ -255,7 +255,7 @@ static int launch_imdct(nyq_ctx *ctx, const float *d_in, const float *d_carry, f
 template <int N2R>
 static int launch_ifft(nyq_ctx *ctx, const float *d_in, float *d_out, size_t batch) {
     const int res = resident_blocks(ctx, ifft_rows_kernel<N2R, kWavesPerBlock>, &ctx->res_ifft[Geo<N2R>::SHIFT]);
-    hipLaunchKernelGGL((ifft_rows_kernel<N2R, kWavesPerBlock>), dim3(grid_for(batch, res)), dim3(kWave * kWavesPerBlock), 0,
+    hipLaunchKernelGGL((ifft_rows_kernel<N2R, kWavesPerBlock>), dim3(grid_for(batch, Geo<N2R>::G, res)), dim3(kWave * kWavesPerBlock), 0,
                        ctx->stream, d_in, d_out, (long)batch);
     NYQ_HIP(ctx, hipGetLastError());
     return NYQ_OK;
@@ -331,12 +331,12 @@ static int synth_core(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned 
     A.nstreams = (long)nstreams;
     A.nframes = (long)nframes;
     A.channels = channels;
-    int rc;
+    int rc, chain_frames;
     switch (LM) {
-    case 3: rc = launch_synth_long<32>(ctx, A); break;
-    case 2: rc = launch_synth_long<16>(ctx, A); break;
-    case 1: rc = launch_synth_long<8>(ctx, A); break;
-    default: rc = launch_synth_long<4>(ctx, A); break;
+    case 3: rc = launch_synth_long<32>(ctx, A); chain_frames = Geo<32>::CHAIN_FRAMES; break;
+    case 2: rc = launch_synth_long<16>(ctx, A); chain_frames = Geo<16>::CHAIN_FRAMES; break;
+    case 1: rc = launch_synth_long<8>(ctx, A); chain_frames = Geo<8>::CHAIN_FRAMES; break;
+    default: rc = launch_synth_long<4>(ctx, A); chain_frames = Geo<4>::CHAIN_FRAMES; break;
     }
     if (rc != NYQ_OK) return rc;
     const size_t units = nsc * nframes;
@@ -350,7 +350,7 @@ static int synth_core(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned 
     }
     const size_t per_block = (size_t)kWave * kFixupWaves;
     hipLaunchKernelGGL(synth_fixup_kernel, dim3((unsigned)((units + per_block - 1) / per_block)),
-                       dim3(kWave * kFixupWaves), 0, ctx->stream, A, 120 << LM, ctx->d_window);
+                       dim3(kWave * kFixupWaves), 0, ctx->stream, A, 120 << LM, chain_frames, ctx->d_window);
     NYQ_HIP(ctx, hipGetLastError());
     if (d_state_out)
         NYQ_HIP(ctx, hipMemcpy2DAsync(d_state_out, slot, d_work + nframes * NYQ_HALF_OV, pitch, slot, nsc,

@@ -64,7 +64,6 @@ NYQ_HD void st_f4(float *p, f4 v) {
 
 constexpr int kOverlap = 120;   // static_modes_float.h:579
 constexpr int kHalfOv = 60;
-constexpr int kGroup = 4;       // rows per wave-group
 constexpr int kWave = 64;
 
 template <int N2R>
@@ -75,15 +74,20 @@ struct Geo {
     static constexpr int SHIFT = N2R == 32 ? 0 : N2R == 16 ? 1 : N2R == 8 ? 2 : 3;
     static constexpr int NT = N4 / 4;                 // stage tasks per row (4 points each)
     static constexpr int SLOT = NT > 64 ? 128 : NT > 32 ? 64 : NT > 16 ? 32 : 16;
-    static constexpr int SUBS = kGroup * SLOT / kWave;   // stage sub-iterations per group
+    // rows per wave-group: enough that the radix-15 pass (N2R lanes per row) fills the wavefront and that a
+    // group keeps >= 7.5 KB of loads in flight: 4, 4, 8, 16 rows for nfft 480, 240, 120, 60
+    static constexpr int G = N2R == 32 ? 4 : N2R == 16 ? 8 : 16;
+    static constexpr int SUBS = G * SLOT / kWave;        // stage sub-iterations per group
     static constexpr int JSETS = SLOT > kWave ? SLOT / kWave : 1;
     static constexpr int S = (N4 % 32 <= 16) ? (N4 - N4 % 32 + 16) : (N4 - N4 % 32 + 48);
     static constexpr int T1 = inv_mod(N2R, 15);
     static constexpr int T2 = inv_mod(15, N2R);
-    static constexpr int P2_ROWS = kWave / N2R;       // rows per pass-2 iteration (may exceed 4)
-    static constexpr int P2_ITERS = P2_ROWS >= kGroup ? 1 : kGroup / P2_ROWS;
-    static constexpr int LDS_CPX = kGroup * S;        // per-wave LDS slice for the rows, in cpx
-    static constexpr int RING_FLOATS = (kGroup + 1) * 60;   // tail ring (chained rows only)
+    static constexpr int P1_ITERS = G / 4;            // pass 1: four rows (16-lane slots) per iteration
+    static constexpr int P2_ROWS = kWave / N2R;       // rows per pass-2 iteration
+    static constexpr int P2_ITERS = P2_ROWS >= G ? 1 : G / P2_ROWS;
+    static constexpr int LDS_CPX = G * S;             // per-wave LDS slice for the rows, in cpx
+    static constexpr int RING_FLOATS = (G + 1) * 60;  // tail ring (chained rows only)
+    static constexpr int CHAIN_FRAMES = 4 * G;        // frames of one channel a wave chains in-wave (kChainGroups groups)
     // sine = 2*PI*0.125/N with the reference's float PI (mdct.c:292, mathops.h:83)
     static constexpr float SINE = (float)2 * 3.141592653f * (.125f) / (float)(4 * N4);
 };
@@ -163,7 +167,7 @@ NYQ_HD cpx postrot(cpx v, float c, float s, float sine) {
 }
 
 // ---- row sources ---------------------------------------------------------------
-// A "Rows" object tells the lane program where the 4 rows of the current group live.  It is a
+// A "Rows" object tells the lane program where the G rows of the current group live.  It is a
 // handful of wave-uniform scalars with inline accessors, so addresses are recomputed from
 // g instead of being kept per row:
 //   static constexpr bool STRIDED   input elements are `stride()` floats apart (interleaved
@@ -211,32 +215,33 @@ struct SynthArgs {
     int channels;
 };
 
-// Long frames.  A wave visits CHUNKS of kChainGroups groups = 16 consecutive frames of one
+// Long frames.  A wave visits CHUNKS of kChainGroups groups = 4 G consecutive frames of one
 // (stream, channel); inside a chunk every long frame that follows a long frame takes its carry
 // in-wave (LDS tail ring, handed from group to group by ring_rotate).  Chunk-first frames and
 // frames after a transient frame are mirrored against zeros here and receive their carry in
 // synth_fixup; their predecessors publish a tail to the tails buffer.
 constexpr int kChainGroups = 4;
-constexpr int kChainFrames = kChainGroups * kGroup;
 
 template <int N2R>
 struct FrameLongRows {
     static constexpr bool STRIDED = false;
     static constexpr bool CHAINS = true;
     static constexpr int N = Geo<N2R>::NIN;
+    static constexpr int G = Geo<N2R>::G;
+    static constexpr int kChainFrames = Geo<N2R>::CHAIN_FRAMES;
     const float *in0;   // frame f0, this channel
     float *fin0;        // pcm of frame f0
     float *tail0;       // tails slot f0+1
     long in_step;       // channels * N
-    unsigned longmask;  // bit g+1 set <=> frame f0+g exists and is long (g = -1..4)
+    unsigned longmask;  // bit g+1 set <=> frame f0+g exists and is long (g = -1..G)
     int qq;             // group inside the chunk
-    // chunk ci = sc * chunks_per_channel + k covers frames 16k .. 16k+15 of channel sc
+    // chunk ci = sc * chunks_per_channel + k covers frames 4Gk .. 4Gk+4G-1 of channel sc
     NYQ_HD static long chunks_per_channel(long nframes) { return (nframes + kChainFrames - 1) / kChainFrames; }
     NYQ_HD FrameLongRows(const SynthArgs &A, long ci, int qq_) {
         const long cpc = chunks_per_channel(A.nframes);
         const long sc = ci / cpc, k = ci - sc * cpc;
         const long s = sc / A.channels, c = sc - s * A.channels;
-        const long f0 = k * kChainFrames + (long)qq_ * kGroup;
+        const long f0 = k * kChainFrames + (long)qq_ * G;
         qq = qq_;
         in_step = (long)A.channels * N;
         in0 = A.freq + ((s * A.nframes + f0) * A.channels + c) * (long)N;
@@ -245,12 +250,12 @@ struct FrameLongRows {
         longmask = 0;
         const unsigned char *t = A.transient + s * A.nframes;
 #pragma unroll
-        for (int g = -1; g <= kGroup; g++) {
+        for (int g = -1; g <= G; g++) {
             const long f = f0 + g;
             if (f >= 0 && f < A.nframes && !(A.transient && t[f])) longmask |= 1u << (g + 1);
         }
     }
-    NYQ_HD bool any() const { return (longmask & 0x1Eu) != 0; }
+    NYQ_HD bool any() const { return (longmask & (((1u << G) - 1u) << 1)) != 0; }
     NYQ_HD bool is_long(int g) const { return (longmask >> (g + 1)) & 1u; }
     NYQ_HD bool valid(int g) const { return is_long(g); }
     NYQ_HD const float *in(int g) const { return in0 + g * in_step; }
@@ -261,13 +266,13 @@ struct FrameLongRows {
     NYQ_HD const float *carry(int) const { return nullptr; }
     // publish the tail unless the next frame's head is completed in-wave
     NYQ_HD float *tail(int g) const {
-        const bool next_in_wave = is_long(g + 1) && (g < kGroup - 1 || qq < kChainGroups - 1);
+        const bool next_in_wave = is_long(g + 1) && (g < G - 1 || qq < kChainGroups - 1);
         return next_in_wave ? nullptr : tail0 + g * (long)kHalfOv;
     }
 };
 
-// The B short blocks of ONE transient frame of one (stream, channel), four at a time
-// (h = 0 .. ceil(B/4)-1, same wave, chained through the tail ring).  Always N2R = 4.
+// The B <= 8 short blocks of ONE transient frame of one (stream, channel): one group of Geo<4>::G = 16 rows
+// holds them all (h stays for generality), chained through the tail ring.  Always N2R = 4.
 struct FrameShortRows {
     static constexpr bool STRIDED = true;
     static constexpr bool CHAINS = true;
@@ -279,7 +284,7 @@ struct FrameShortRows {
         const long s = sc / A.channels, c = sc - s * A.channels;
         const long N = 120L * B_;
         B = B_;
-        b0 = h * kGroup;
+        b0 = h * Geo<4>::G;
         in0 = A.freq + ((s * A.nframes + f) * A.channels + c) * N;
         fin0 = A.pcm + (sc * A.nframes + f) * N;
         tail_slot = A.tails + (sc * (A.nframes + 1) + f + 1) * (long)kHalfOv;
@@ -295,8 +300,8 @@ struct FrameShortRows {
 
 // Is the head of frame f (its first 120 samples) already mirrored against the true carry?
 // Only long frames that chained in-wave are; every other head gets its carry in synth_fixup.
-NYQ_HD bool head_done_in_wave(const unsigned char *t, long f) {
-    return (f % kChainFrames) != 0 && !(t && (t[f] || t[f - 1]));
+NYQ_HD bool head_done_in_wave(const unsigned char *t, long f, int chain_frames) {
+    return (f % chain_frames) != 0 && !(t && (t[f] || t[f - 1]));
 }
 
 // ---- phase A -----------------------------------------------------------
@@ -357,15 +362,19 @@ NYQ_HD void stage_in_store(const StageRegs<N2R> &R, const LaneConst<N2R> &K, int
 template <int N2R>
 NYQ_HD void pass1(int lane, cpx *lds) {
     using Gm = Geo<N2R>;
-    const int g = lane >> 4, k1 = lane & 15;
+    const int k1 = lane & 15;
     if (k1 < 15) {
-        cpx *p = lds + g * Gm::S + k1;
-        cpx u[N2R];
 #pragma unroll
-        for (int k2 = 0; k2 < N2R; k2++) u[k2] = p[15 * k2];
-        Dft<N2R>::run(u);
+        for (int it = 0; it < Gm::P1_ITERS; it++) {       // in place, every (row, k1) column on its own
+            const int g = 4 * it + (lane >> 4);
+            cpx *p = lds + g * Gm::S + k1;
+            cpx u[N2R];
 #pragma unroll
-        for (int n2 = 0; n2 < N2R; n2++) p[15 * n2] = u[n2];
+            for (int k2 = 0; k2 < N2R; k2++) u[k2] = p[15 * k2];
+            Dft<N2R>::run(u);
+#pragma unroll
+            for (int n2 = 0; n2 < N2R; n2++) p[15 * n2] = u[n2];
+        }
     }
 }
 
@@ -375,7 +384,7 @@ NYQ_HD bool pass2_load(int lane, int it, const cpx *lds, cpx (&v)[15], int &g, i
     using Gm = Geo<N2R>;
     g = it * Gm::P2_ROWS + lane / N2R;
     n2 = lane % N2R;
-    if (g >= kGroup) return false;
+    if (g >= Gm::G) return false;
     const cpx *p = lds + g * Gm::S + 15 * n2;
 #pragma unroll
     for (int k1 = 0; k1 < 15; k1++) v[k1] = p[k1];
@@ -428,7 +437,7 @@ struct HeadRegs {
 
 // Part 1: post-rotation, body stores; head lanes (j < 15) either finish at once (no chaining)
 // or park F/Bk and publish their raw tail in the wave's LDS tail ring: ring[g+1] = tail of row g
-// (ring[0] = tail left by the previous group).  ring: 5 x 60 floats.
+// (ring[0] = tail left by the previous group).  ring: (G + 1) x 60 floats.
 template <int N2R, int NT, class Rows>
 NYQ_HD void stage_out(const LaneConst<N2R> &K, int lane, const cpx *lds, float *ring, const Rows &rows,
                       HeadRegs<N2R> &H) {
@@ -503,28 +512,37 @@ NYQ_HD void stage_out_heads(const LaneConst<N2R> &K, int lane, const float *ring
 }
 
 // Part 3 (CHAINS only, after part 2): hand the last row's tail to the next group of this wave.
+template <int N2R>
 NYQ_HD void ring_rotate(int lane, float *ring) {
     if (lane < 15) {
-        f4 v = *reinterpret_cast<const f4 *>(ring + kGroup * kHalfOv + 4 * lane);
+        f4 v = *reinterpret_cast<const f4 *>(ring + Geo<N2R>::G * kHalfOv + 4 * lane);
         *reinterpret_cast<f4 *>(ring + 4 * lane) = v;
     }
 }
 
 // ---- IFFT-only variant (opus_ifft, kiss_fft.c:696-747; golden-vector op) -----
 // in/out: [nrows][N4] interleaved complex, natural order, unscaled inverse.
+// The G x N4/2 float4 pieces (two complex points each) of a group are dealt to the lanes round robin, so
+// every load / store instruction has all 64 lanes busy whatever the row length.
 template <int N2R>
 NYQ_HD void ifft_stage_in(int lane, const float *in, cpx *lds, long row0, long nrows) {
     using Gm = Geo<N2R>;
     constexpr int PAIRS = Gm::N4 / 2;   // float4 = two complex points
+    constexpr int ITERS = (Gm::G * PAIRS + kWave - 1) / kWave;
+    f4 v[ITERS];
 #pragma unroll
-    for (int g = 0; g < kGroup; g++) {
-        if (row0 + g >= nrows) continue;
-        const float *row = in + (row0 + g) * (long)(2 * Gm::N4);
-        cpx *lrow = lds + g * Gm::S;
-        for (int p = lane; p < PAIRS; p += kWave) {
-            f4 v = *reinterpret_cast<const f4 *>(row + 4 * p);
-            lrow[slot_of<N2R>(2 * p)] = cpx{v.x, v.y};
-            lrow[slot_of<N2R>(2 * p + 1)] = cpx{v.z, v.w};
+    for (int it = 0; it < ITERS; it++) {
+        const int idx = it * kWave + lane, g = idx / PAIRS, p = idx - g * PAIRS;
+        v[it] = f4{0, 0, 0, 0};
+        if (g < Gm::G && row0 + g < nrows) v[it] = *reinterpret_cast<const f4 *>(in + (row0 + g) * (long)(2 * Gm::N4) + 4 * p);
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int idx = it * kWave + lane, g = idx / PAIRS, p = idx - g * PAIRS;
+        if (g < Gm::G) {
+            cpx *lrow = lds + g * Gm::S;
+            lrow[slot_of<N2R>(2 * p)] = cpx{v[it].x, v[it].y};
+            lrow[slot_of<N2R>(2 * p + 1)] = cpx{v[it].z, v[it].w};
         }
     }
 }
@@ -533,14 +551,14 @@ template <int N2R>
 NYQ_HD void ifft_stage_out(int lane, const cpx *lds, float *out, long row0, long nrows) {
     using Gm = Geo<N2R>;
     constexpr int PAIRS = Gm::N4 / 2;
+    constexpr int ITERS = (Gm::G * PAIRS + kWave - 1) / kWave;
 #pragma unroll
-    for (int g = 0; g < kGroup; g++) {
-        if (row0 + g >= nrows) continue;
-        float *row = out + (row0 + g) * (long)(2 * Gm::N4);
-        const cpx *lrow = lds + g * Gm::S;
-        for (int p = lane; p < PAIRS; p += kWave) {
-            cpx a = lrow[2 * p], b = lrow[2 * p + 1];
-            *reinterpret_cast<f4 *>(row + 4 * p) = f4{a.re, a.im, b.re, b.im};
+    for (int it = 0; it < ITERS; it++) {
+        const int idx = it * kWave + lane, g = idx / PAIRS, p = idx - g * PAIRS;
+        if (g < Gm::G && row0 + g < nrows) {
+            const cpx *lrow = lds + g * Gm::S;
+            const cpx a = lrow[2 * p], b = lrow[2 * p + 1];
+            *reinterpret_cast<f4 *>(out + (row0 + g) * (long)(2 * Gm::N4) + 4 * p) = f4{a.re, a.im, b.re, b.im};
         }
     }
 }

@@ -85,7 +85,7 @@ __device__ __forceinline__ void run_group(const LaneConst<N2R> &K, int lane, cpx
     }
 }
 
-// per-wave LDS carve: rows slice, then (chained kernels only) the 5 x 60-float tail ring
+// per-wave LDS carve: rows slice, then (chained kernels only) the (G + 1) x 60-float tail ring
 template <int N2R, int WPB, bool RING>
 struct WaveLds {
     static constexpr int ROW_FLOATS = 2 * Geo<N2R>::LDS_CPX;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(kWave *Cfg::WPB) void imdct_rows_kernel(
     LaneConst<N2R> K;
     lane_init<N2R>(K, lane, trig, window);
 
-    const long ngroups_all = (nrows + kGroup - 1) / kGroup;
+    const long ngroups_all = (nrows + Gm::G - 1) / Gm::G;
     const long nwaves_all = (long)gridDim.x * Cfg::WPB;
     const long wid = (long)blockIdx.x * Cfg::WPB + wv;
     // grid-stride: wave w takes groups w, w+W, ...; chunked: wave w takes one contiguous run
@@ -122,12 +122,12 @@ __global__ __launch_bounds__(kWave *Cfg::WPB) void imdct_rows_kernel(
         // Software pipeline over this wave's groups: the float4 loads of group g+1 are issued
         // as soon as group g's registers have been pre-rotated into LDS.  (Measured: no gain.)
         if (gi < ngroups) {
-            IndepRows<N2R> rows{in, carry, fin, tail, gi * kGroup, nrows};
+            IndepRows<N2R> rows{in, carry, fin, tail, gi * Gm::G, nrows};
             stage_in_load<N2R, Cfg::NT_LD>(R, lane, rows);
         }
     }
     for (; gi < ngroups; gi += nwaves) {
-        IndepRows<N2R> rows{in, carry, fin, tail, gi * kGroup, nrows};
+        IndepRows<N2R> rows{in, carry, fin, tail, gi * Gm::G, nrows};
         if constexpr (!Cfg::PREFETCH) {
             stage_in_load<N2R, Cfg::NT_LD>(R, lane, rows);
             run_group<N2R, Cfg>(K, lane, lds, nullptr, rows, R);
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kWave *Cfg::WPB) void imdct_rows_kernel(
             NYQ_WAVE_SYNC();
             stage_in_store<N2R>(R, K, lane, lds);
             if (gi + nwaves < ngroups) {
-                IndepRows<N2R> nxt{in, carry, fin, tail, (gi + nwaves) * kGroup, nrows};
+                IndepRows<N2R> nxt{in, carry, fin, tail, (gi + nwaves) * Gm::G, nrows};
                 stage_in_load<N2R, Cfg::NT_LD>(R, lane, nxt);
             }
             NYQ_WAVE_SYNC();
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kWave *Cfg::WPB) void imdct_rows_kernel(
 }
 
 // ---- frame sequences: the compute_inv_mdcts replacement (celt_decoder_clean.c:264-312) ----
-// Long frames: chunks of 16 consecutive frames of one (stream, channel), chained in-wave.
+// Long frames: chunks of 4 G consecutive frames of one (stream, channel), chained in-wave.
 template <int N2R, typename Cfg>
 __global__ __launch_bounds__(kWave *Cfg::WPB) void synth_long_kernel(SynthArgs A, const float *__restrict__ trig,
                                                                       const float *__restrict__ window) {
@@ -172,13 +172,13 @@ __global__ __launch_bounds__(kWave *Cfg::WPB) void synth_long_kernel(SynthArgs A
             stage_in_load<N2R, Cfg::NT_LD>(R, lane, rows);
             run_group<N2R, Cfg>(K, lane, lds, ring, rows, R);
             NYQ_WAVE_SYNC();
-            ring_rotate(lane, ring);
+            ring_rotate<N2R>(lane, ring);
         }
     }
 }
 
-// Transient frames: a wave takes one (stream, channel, frame) and walks its B short blocks four
-// at a time; blocks chain through the tail ring, the last block publishes the frame's tail.
+// Transient frames: a wave takes one (stream, channel, frame) and runs its B <= 8 short blocks as one group
+// of 16 rows; blocks chain through the tail ring, the last block publishes the frame's tail.
 template <typename Cfg>
 __global__ __launch_bounds__(kWave *Cfg::WPB) void synth_short_kernel(SynthArgs A, int B,
                                                                        const float *__restrict__ trig,
@@ -211,13 +211,13 @@ __global__ __launch_bounds__(kWave *Cfg::WPB) void synth_short_kernel(SynthArgs 
             todo &= todo - 1;
             const long u = base + bit;
             const long sc = u / A.nframes, f = u - sc * A.nframes;
-            for (int h = 0; h * kGroup < B; h++) {
+            for (int h = 0; h * Geo<4>::G < B; h++) {
                 FrameShortRows rows(A, sc, f, B, h);
                 StageRegs<4> R;
                 stage_in_load<4, 0>(R, lane, rows);
                 run_group<4, Cfg>(K, lane, lds, ring, rows, R);
                 NYQ_WAVE_SYNC();
-                ring_rotate(lane, ring);
+                ring_rotate<4>(lane, ring);
             }
         }
     }
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kWave *Cfg::WPB) void synth_short_kernel(SynthArgs 
 // the raw tail that precedes frame f (slot 0: the state handed in).  mdct.c:371-372 is linear in
 // the carry, so  out[i] += w[119-i] c[i];  out[119-i] += w[i] c[i]  completes the mirror exactly.
 constexpr int kFixupWaves = 4;   // waves per block; each wave scans 64 (stream*channel, frame) units
-__global__ __launch_bounds__(kWave *kFixupWaves) void synth_fixup_kernel(SynthArgs A, int N,
+__global__ __launch_bounds__(kWave *kFixupWaves) void synth_fixup_kernel(SynthArgs A, int N, int chain_frames,
                                                                           const float *__restrict__ window) {
     // Few heads need work (one in 16 plus the neighbours of transient frames), so scan 64 units per
     // wave with one flag test per lane and a ballot, then let lanes 0..59 patch each hit.
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kWave *kFixupWaves) void synth_fixup_kernel(SynthAr
     bool need = false;
     if (mine < units) {
         const long sc = mine / A.nframes, f = mine - sc * A.nframes;
-        need = !head_done_in_wave(A.transient ? A.transient + (sc / A.channels) * A.nframes : nullptr, f);
+        need = !head_done_in_wave(A.transient ? A.transient + (sc / A.channels) * A.nframes : nullptr, f, chain_frames);
     }
     unsigned long long todo = __ballot(need);
     const float wa = lane < kHalfOv ? window[kOverlap - 1 - lane] : 0.f;
@@ -265,10 +265,10 @@ __global__ __launch_bounds__(kWave *WPB) void ifft_rows_kernel(const float *__re
     const int lane = threadIdx.x & (kWave - 1);
     const int wv = threadIdx.x >> 6;
     cpx *lds = lds_all + wv * Gm::LDS_CPX;
-    const long ngroups = (nrows + kGroup - 1) / kGroup;
+    const long ngroups = (nrows + Gm::G - 1) / Gm::G;
     const long nwaves = (long)gridDim.x * WPB;
     for (long gi = (long)blockIdx.x * WPB + wv; gi < ngroups; gi += nwaves) {
-        const long row0 = gi * kGroup;
+        const long row0 = gi * Gm::G;
         NYQ_WAVE_SYNC();
         ifft_stage_in<N2R>(lane, in, lds, row0, nrows);
         NYQ_WAVE_SYNC();

@@ -49,7 +49,7 @@ struct WaveEmu {
             for (int l = 0; l < kWave; l++) stage_out_heads<N2R, 0>(K[l], l, ring.data(), rows, H[l]);
     }
     void rotate() {
-        for (int l = 0; l < kWave; l++) ring_rotate(l, ring.data());
+        for (int l = 0; l < kWave; l++) ring_rotate<N2R>(l, ring.data());
     }
 };
 
@@ -57,7 +57,7 @@ template <int N2R>
 static void emu_imdct(const float *in, const float *carry, float *fin, float *tail, long nrows,
                       const float *trig, const float *window) {
     WaveEmu<N2R> W(trig, window);
-    for (long row0 = 0; row0 < nrows; row0 += kGroup) {
+    for (long row0 = 0; row0 < nrows; row0 += Geo<N2R>::G) {
         IndepRows<N2R> rows{in, carry, fin, tail, row0, nrows};
         W.group(rows);
     }
@@ -68,7 +68,7 @@ static void emu_ifft(const float *in, float *out, long nrows) {
     using Gm = Geo<N2R>;
     std::vector<float> dummy_t(481, 1.f), dummy_w(120, 1.f);
     WaveEmu<N2R> W(dummy_t.data(), dummy_w.data());
-    for (long row0 = 0; row0 < nrows; row0 += kGroup) {
+    for (long row0 = 0; row0 < nrows; row0 += Gm::G) {
         for (int l = 0; l < kWave; l++) ifft_stage_in<N2R>(l, in, W.lds.data(), row0, nrows);
         W.fft();
         for (int l = 0; l < kWave; l++) ifft_stage_out<N2R>(l, W.lds.data(), out, row0, nrows);
@@ -95,7 +95,7 @@ static void emu_synth_short(const SynthArgs &A, int B, const float *trig, const 
     for (long u = 0; u < units; u++) {
         const long sc = u / A.nframes, f = u - sc * A.nframes, s = sc / A.channels;
         if (!A.transient[s * A.nframes + f]) continue;
-        for (int h = 0; h * kGroup < B; h++) {
+        for (int h = 0; h * Geo<4>::G < B; h++) {
             FrameShortRows rows(A, sc, f, B, h);
             W.group(rows);
             W.rotate();
@@ -103,11 +103,11 @@ static void emu_synth_short(const SynthArgs &A, int B, const float *trig, const 
     }
 }
 
-static void emu_synth_fixup(const SynthArgs &A, int N, const float *window) {
+static void emu_synth_fixup(const SynthArgs &A, int N, int chain_frames, const float *window) {
     const long units = A.nstreams * A.channels * A.nframes;
     for (long u = 0; u < units; u++) {
         const long sc = u / A.nframes, f = u - sc * A.nframes, s = sc / A.channels;
-        if (head_done_in_wave(A.transient ? A.transient + s * A.nframes : nullptr, f)) continue;
+        if (head_done_in_wave(A.transient ? A.transient + s * A.nframes : nullptr, f, chain_frames)) continue;
         for (int i = 0; i < kHalfOv; i++) {
             const float cv = A.tails[(sc * (A.nframes + 1) + f) * (long)kHalfOv + i];
             float *o = A.pcm + (sc * A.nframes + f) * (long)N;
@@ -148,14 +148,15 @@ extern "C" int emu_celt_synth(int LM, const float *freq, const unsigned char *tr
         for (int i = 0; i < kHalfOv; i++)
             tails[(size_t)sc * (nframes + 1) * kHalfOv + i] = state ? state[sc * kHalfOv + i] : 0.f;
     SynthArgs A{freq, LM > 0 ? transient : nullptr, pcm, tails.data(), nstreams, nframes, channels};
+    int chain_frames;
     switch (LM) {
-    case 3: emu_synth_long<32>(A, trig, window); break;
-    case 2: emu_synth_long<16>(A, trig, window); break;
-    case 1: emu_synth_long<8>(A, trig, window); break;
-    default: emu_synth_long<4>(A, trig, window); break;
+    case 3: emu_synth_long<32>(A, trig, window); chain_frames = Geo<32>::CHAIN_FRAMES; break;
+    case 2: emu_synth_long<16>(A, trig, window); chain_frames = Geo<16>::CHAIN_FRAMES; break;
+    case 1: emu_synth_long<8>(A, trig, window); chain_frames = Geo<8>::CHAIN_FRAMES; break;
+    default: emu_synth_long<4>(A, trig, window); chain_frames = Geo<4>::CHAIN_FRAMES; break;
     }
     if (A.transient) emu_synth_short(A, 1 << LM, trig, window);
-    emu_synth_fixup(A, 120 << LM, window);
+    emu_synth_fixup(A, 120 << LM, chain_frames, window);
     if (state)
         for (long sc = 0; sc < nsc; sc++)
             for (int i = 0; i < kHalfOv; i++)
