@@ -434,3 +434,58 @@ def test_post_vs_oracle_random_parameters(ctx, oracle, lm):
         assert np.array_equal(pst, wst)
         assert rel_rms(gh, filt[:, :, -1088:].reshape(ns * ch, 1088)) <= 1e-5
         assert rel_rms(gdm, wdm) <= 1e-5
+
+
+def test_device_entry_points_capture_into_a_hip_graph(ctx, oracle):
+    """The `_dev` entry points neither allocate nor synchronise, so a decode step (frame synthesis +
+    post-filter + a row batch) can be captured once into a hipGraph and replayed on new data: the replay
+    must equal the eager result bit for bit."""
+    import torch
+    dev = torch.device("cuda", 0)
+    ctx.set_tables(*oracle.tables()[:2])
+    ns, nf, ch, n = 24, 40, 2, 960
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    freq = torch.randn((ns, nf, ch, n), generator=g, device=dev) * 30
+    trans = (torch.rand((ns, nf), generator=g, device=dev) < 0.1).to(torch.uint8)
+    pitch = torch.randint(15, 1000, (ns, nf), generator=g, device=dev, dtype=torch.int32)
+    gain = (torch.randint(0, 9, (ns, nf), generator=g, device=dev) * 0.09375).float()
+    tap = torch.randint(0, 3, (ns, nf), generator=g, device=dev, dtype=torch.int32)
+    pcm = torch.empty((ns, ch, nf * n), device=dev)
+    out = torch.empty((ns, nf * n, ch), device=dev)
+    state = torch.zeros((ns * ch, 60), device=dev)
+    work = torch.empty(ctx.celt_synth_work_floats(ns, nf, ch), device=dev)
+    rows = torch.randn((1000, 240), generator=g, device=dev)
+    fin, tail = torch.empty_like(rows), torch.empty((1000, 60), device=dev)
+
+    def step():
+        ctx.celt_synth_dev(3, freq.data_ptr(), trans.data_ptr(), pcm.data_ptr(), state.data_ptr(), work.data_ptr(), ns, nf, ch)
+        ctx.celt_post_dev(3, pcm.data_ptr(), pitch.data_ptr(), gain.data_ptr(), tap.data_ptr(), 0, 0, 0, 0, out.data_ptr(), ns, nf, ch)
+        ctx.imdct_batch_dev(2, rows.data_ptr(), 0, fin.data_ptr(), tail.data_ptr(), rows.shape[0])
+
+    side = torch.cuda.Stream(dev)
+    ctx.set_stream(side.cuda_stream)
+    try:
+        with torch.cuda.stream(side):
+            step()                                          # warm: occupancy queries are cached per context
+            side.synchronize()
+            state.zero_()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                step()
+            # new data in the same buffers, replay, then the same step eagerly
+            freq.copy_(torch.randn((ns, nf, ch, n), generator=g, device=dev) * 30)
+            rows.copy_(torch.randn((1000, 240), generator=g, device=dev))
+            state.zero_()
+            graph.replay()
+            side.synchronize()
+            got = (out.clone(), fin.clone(), tail.clone(), state.clone())
+            state.zero_()
+            out.zero_()
+            fin.zero_()
+            step()
+            side.synchronize()
+        assert torch.equal(got[0], out) and torch.equal(got[1], fin) and torch.equal(got[2], tail) and torch.equal(got[3], state)
+        assert float(out.abs().max()) > 0
+    finally:
+        ctx.reset_stream()
