@@ -697,32 +697,63 @@ extern "C" int nyq_celt_frames_to_pcm(nyq_ctx *ctx, int LM, const float *freq, c
     unsigned char *d_t = reinterpret_cast<unsigned char *>(d_pt + n_p);
     float *d_ov = reinterpret_cast<float *>(d_pt + n_p) + n_t, *d_hi = d_ov + n_ov, *d_de = d_hi + n_hi,
           *d_pfi = d_de + n_de, *d_pfo = d_pfi + n_pf;
-    NYQ_HIP(ctx, hipMemcpyAsync(d_x, freq, nsc * nframes * N * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    if (transient) NYQ_HIP(ctx, hipMemcpyAsync(d_t, transient, nfr, hipMemcpyHostToDevice, ctx->stream));
-    NYQ_HIP(ctx, hipMemcpyAsync(d_pg, pf_gain, nfr * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    NYQ_HIP(ctx, hipMemcpyAsync(d_pp, pf_pitch, nfr * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    NYQ_HIP(ctx, hipMemcpyAsync(d_pt, pf_tapset, nfr * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     float *h_ov = state, *h_hi = state ? h_ov + nsc * NYQ_HALF_OV : nullptr, *h_de = state ? h_hi + nsc * kPostHist : nullptr,
           *h_pf = state ? h_de + nsc : nullptr;
-    if (state) {
-        NYQ_HIP(ctx, hipMemcpyAsync(d_ov, h_ov, nsc * NYQ_HALF_OV * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-        NYQ_HIP(ctx, hipMemcpyAsync(d_hi, h_hi, nsc * kPostHist * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-        NYQ_HIP(ctx, hipMemcpyAsync(d_de, h_de, nsc * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-        NYQ_HIP(ctx, hipMemcpyAsync(d_pfi, h_pf, nstreams * 6 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    }
-    rc = nyq_celt_synth_dev(ctx, LM, d_x, transient ? d_t : nullptr, d_pcm, state ? d_ov : nullptr, d_w, nstreams, nframes,
-                            channels);
+    // pieces of whole streams: upload of piece k+1, kernels of piece k, download of piece k-1 at the same time
+    const size_t stream_bytes = nframes * (size_t)channels * N * sizeof(float);
+    size_t per = (kHostPieceBytes + stream_bytes - 1) / stream_bytes;
+    if ((nstreams + per - 1) / per > kHostMaxPieces) per = (nstreams + kHostMaxPieces - 1) / kHostMaxPieces;
+    const size_t npieces = (nstreams + per - 1) / per;
+    rc = need_copy_streams(ctx, 2 * npieces + 1);
     if (rc != NYQ_OK) return rc;
-    rc = nyq_celt_post_dev(ctx, LM, d_pcm, d_pp, d_pg, d_pt, state ? d_pfi : nullptr, state ? d_pfo : nullptr,
-                           state ? d_hi : nullptr, state ? d_de : nullptr, d_out, nstreams, nframes, channels);
-    if (rc != NYQ_OK) return rc;
-    NYQ_HIP(ctx, hipMemcpyAsync(out, d_out, nsc * nframes * N * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    if (state) {
-        NYQ_HIP(ctx, hipMemcpyAsync(h_ov, d_ov, nsc * NYQ_HALF_OV * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        NYQ_HIP(ctx, hipMemcpyAsync(h_hi, d_hi, nsc * kPostHist * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        NYQ_HIP(ctx, hipMemcpyAsync(h_de, d_de, nsc * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        NYQ_HIP(ctx, hipMemcpyAsync(h_pf, d_pfo, nstreams * 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    hipEvent_t ev0 = ctx->ev_pool[2 * npieces];
+    NYQ_HIP(ctx, hipEventRecord(ev0, ctx->stream));
+    NYQ_HIP(ctx, hipStreamWaitEvent(ctx->s_h2d, ev0, 0));
+    NYQ_HIP(ctx, hipStreamWaitEvent(ctx->s_d2h, ev0, 0));
+    const size_t work_per_stream = (size_t)channels * (nframes + 1) * NYQ_HALF_OV;   // nyq_celt_synth_work_floats layout
+    for (size_t k = 0; k < npieces; k++) {
+        const size_t s0 = k * per, cnt = (nstreams - s0 < per ? nstreams - s0 : per);
+        const size_t xo = s0 * nframes * channels * N, xn = cnt * nframes * channels * N;   // freq / pcm / out floats
+        const size_t fo = s0 * nframes, fn = cnt * nframes;                                   // per-frame parameters
+        const size_t co = s0 * channels, cn = cnt * (size_t)channels;                         // (stream, channel) units
+        hipEvent_t up = ctx->ev_pool[2 * k], done = ctx->ev_pool[2 * k + 1];
+        hipStream_t hs = ctx->s_h2d, ds = ctx->s_d2h;
+        NYQ_HIP(ctx, hipMemcpyAsync(d_x + xo, freq + xo, xn * sizeof(float), hipMemcpyHostToDevice, hs));
+        if (transient) NYQ_HIP(ctx, hipMemcpyAsync(d_t + fo, transient + fo, fn, hipMemcpyHostToDevice, hs));
+        NYQ_HIP(ctx, hipMemcpyAsync(d_pg + fo, pf_gain + fo, fn * sizeof(float), hipMemcpyHostToDevice, hs));
+        NYQ_HIP(ctx, hipMemcpyAsync(d_pp + fo, pf_pitch + fo, fn * sizeof(int), hipMemcpyHostToDevice, hs));
+        NYQ_HIP(ctx, hipMemcpyAsync(d_pt + fo, pf_tapset + fo, fn * sizeof(int), hipMemcpyHostToDevice, hs));
+        if (state) {
+            NYQ_HIP(ctx, hipMemcpyAsync(d_ov + co * NYQ_HALF_OV, h_ov + co * NYQ_HALF_OV, cn * NYQ_HALF_OV * sizeof(float), hipMemcpyHostToDevice, hs));
+            NYQ_HIP(ctx, hipMemcpyAsync(d_hi + co * kPostHist, h_hi + co * kPostHist, cn * kPostHist * sizeof(float), hipMemcpyHostToDevice, hs));
+            NYQ_HIP(ctx, hipMemcpyAsync(d_de + co, h_de + co, cn * sizeof(float), hipMemcpyHostToDevice, hs));
+            NYQ_HIP(ctx, hipMemcpyAsync(d_pfi + s0 * 6, h_pf + s0 * 6, cnt * 6 * sizeof(float), hipMemcpyHostToDevice, hs));
+        }
+        NYQ_HIP(ctx, hipEventRecord(up, hs));
+        NYQ_HIP(ctx, hipStreamWaitEvent(ctx->stream, up, 0));
+        rc = nyq_celt_synth_dev(ctx, LM, d_x + xo, transient ? d_t + fo : nullptr, d_pcm + xo, state ? d_ov + co * NYQ_HALF_OV : nullptr,
+                                d_w + s0 * work_per_stream, cnt, nframes, channels);
+        if (rc == NYQ_OK)
+            rc = nyq_celt_post_dev(ctx, LM, d_pcm + xo, d_pp + fo, d_pg + fo, d_pt + fo, state ? d_pfi + s0 * 6 : nullptr,
+                                   state ? d_pfo + s0 * 6 : nullptr, state ? d_hi + co * kPostHist : nullptr,
+                                   state ? d_de + co : nullptr, d_out + xo, cnt, nframes, channels);
+        if (rc != NYQ_OK) {
+            (void)hipStreamSynchronize(hs);
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipStreamSynchronize(ds);
+            return rc;
+        }
+        NYQ_HIP(ctx, hipEventRecord(done, ctx->stream));
+        NYQ_HIP(ctx, hipStreamWaitEvent(ds, done, 0));
+        NYQ_HIP(ctx, hipMemcpyAsync(out + xo, d_out + xo, xn * sizeof(float), hipMemcpyDeviceToHost, ds));
+        if (state) {
+            NYQ_HIP(ctx, hipMemcpyAsync(h_ov + co * NYQ_HALF_OV, d_ov + co * NYQ_HALF_OV, cn * NYQ_HALF_OV * sizeof(float), hipMemcpyDeviceToHost, ds));
+            NYQ_HIP(ctx, hipMemcpyAsync(h_hi + co * kPostHist, d_hi + co * kPostHist, cn * kPostHist * sizeof(float), hipMemcpyDeviceToHost, ds));
+            NYQ_HIP(ctx, hipMemcpyAsync(h_de + co, d_de + co, cn * sizeof(float), hipMemcpyDeviceToHost, ds));
+            NYQ_HIP(ctx, hipMemcpyAsync(h_pf + s0 * 6, d_pfo + s0 * 6, cnt * 6 * sizeof(float), hipMemcpyDeviceToHost, ds));
+        }
     }
+    NYQ_HIP(ctx, hipStreamSynchronize(ctx->s_d2h));
     NYQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return NYQ_OK;
 }

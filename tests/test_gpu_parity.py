@@ -489,3 +489,42 @@ def test_device_entry_points_capture_into_a_hip_graph(ctx, oracle):
         assert float(out.abs().max()) > 0
     finally:
         ctx.reset_stream()
+
+
+def test_frames_to_pcm_pipelined_pieces_equal_single_calls(ctx, oracle):
+    """nyq_celt_frames_to_pcm cuts a big batch into pieces of whole streams (upload / kernels / download on
+    three streams).  Streams are independent, so any stream's PCM and decoder state must equal, bit for bit,
+    what a call on that stream alone returns -- across piece borders too."""
+    import libnyquist_amd as nyq
+    ctx.set_tables(*oracle.tables()[:2])
+    rng = np.random.default_rng(5)
+    ns, nf, ch, n = 500, 20, 2, 960                 # 77 MB of freq: three pieces of 219 streams
+    freq = (rng.standard_normal((ns, nf, ch, n)) * 30).astype(np.float32)
+    tr = (rng.random((ns, nf)) < 0.1).astype(np.uint8)
+    pp = rng.integers(15, 1000, (ns, nf)).astype(np.int32)
+    pg = (rng.integers(0, 9, (ns, nf)) * 0.09375).astype(np.float32)
+    pt = rng.integers(0, 3, (ns, nf)).astype(np.int32)
+    nst = int(ctx.lib.nyq_celt_state_floats(ns, ch))
+    state = np.zeros(nst, np.float32)
+    out = ctx.celt_frames_to_pcm(3, freq, tr, pp, pg, pt, ch, state=state)
+    assert np.isfinite(out).all() and np.abs(out).max() > 0
+    nsc = ns * ch
+    ov, hi, de, pf = np.split(state, [nsc * 60, nsc * 60 + nsc * 1088, nsc * 60 + nsc * 1088 + nsc])
+    for k in (0, 1, 218, 219, 220, 437, 438, ns - 1):
+        st1 = np.zeros(int(ctx.lib.nyq_celt_state_floats(1, ch)), np.float32)
+        o1 = ctx.celt_frames_to_pcm(3, freq[k:k + 1], tr[k:k + 1], pp[k:k + 1], pg[k:k + 1], pt[k:k + 1], ch, state=st1)
+        assert np.array_equal(o1[0], out[k])
+        o_ov, o_hi, o_de, o_pf = np.split(st1, [ch * 60, ch * 60 + ch * 1088, ch * 60 + ch * 1088 + ch])
+        assert np.array_equal(o_ov, ov[k * ch * 60:(k + 1) * ch * 60])
+        assert np.array_equal(o_hi, hi[k * ch * 1088:(k + 1) * ch * 1088])
+        assert np.array_equal(o_de, de[k * ch:(k + 1) * ch])
+        assert np.array_equal(o_pf, pf[k * 6:(k + 1) * 6])
+    # continuing from the returned state == decoding the concatenation in one go (stream 219, first of piece 2)
+    k = 219
+    both = ctx.celt_frames_to_pcm(3, np.concatenate([freq[k:k + 1], freq[k + 1:k + 2]], axis=1), np.concatenate([tr[k:k + 1], tr[k + 1:k + 2]], axis=1),
+                                  np.concatenate([pp[k:k + 1], pp[k + 1:k + 2]], axis=1), np.concatenate([pg[k:k + 1], pg[k + 1:k + 2]], axis=1),
+                                  np.concatenate([pt[k:k + 1], pt[k + 1:k + 2]], axis=1), ch)
+    st1 = np.zeros(int(ctx.lib.nyq_celt_state_floats(1, ch)), np.float32)
+    ctx.celt_frames_to_pcm(3, freq[k:k + 1], tr[k:k + 1], pp[k:k + 1], pg[k:k + 1], pt[k:k + 1], ch, state=st1)
+    second = ctx.celt_frames_to_pcm(3, freq[k + 1:k + 2], tr[k + 1:k + 2], pp[k + 1:k + 2], pg[k + 1:k + 2], pt[k + 1:k + 2], ch, state=st1)
+    assert rel_rms(second[0], both[0, nf * n:]) <= 1e-6
