@@ -391,6 +391,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "nyq::imdct_rows_kernel<32, KCfg<1,false,0>>", "kernel_avg_ms": kern_avg_ms,
+                         "kernel_median_ms_rank0": float(np.median(kern_ms)),
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_IMDCT * rows,
                          "measured_device_copy_GBps": copy_gbs},
         }

@@ -90,3 +90,4 @@ def test_gpu_mixed_codec_batch(oracle):
     assert rel_rms(o1[-4:].cpu().numpy(), oracle.vorbis_imdct(2048, v1[-4:].cpu().numpy())) <= 1e-6
     assert rel_rms(o2[:4].cpu().numpy(), oracle.vorbis_imdct(256, v2[:4].cpu().numpy())) <= 1e-6
     ctx.close()
+
