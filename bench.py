@@ -321,6 +321,20 @@ def main():
                              "pcie_GBps_both_directions": moved / best / 1e9,
                              "note": "nyq_imdct_batch on pinned host buffers in and out (nyq_host_alloc), best of 5"}
             del hfin, htail
+            # the reference's own per-call offload interface (mdct.c:219-254 -> processMDCTCuda): one row per call
+            trig, window = ctx.get_tables()
+            one_in = np.ascontiguousarray(x[0].cpu().numpy())
+            one_out = np.zeros(N2 + HALF_OV, np.float32)
+            L = ctx.lib
+            call_args = (fp(one_in), fp(one_out), fp(trig), 1920, 0, 1, ctypes.c_float(2 * 3.141592653 * 0.125 / 1920), 120, fp(window))
+            for _ in range(50):
+                L.processMDCTCuda(*call_args)
+            ncall = 2000
+            t0 = time.perf_counter()
+            for _ in range(ncall):
+                L.processMDCTCuda(*call_args)
+            host_boundary["dropin_processMDCTCuda_us_per_call"] = (time.perf_counter() - t0) / ncall * 1e6
+            L.cleanupCudaBuffers()
             del hx
         except Exception as e:
             host_boundary = {"error": repr(e)}

@@ -783,27 +783,44 @@ static nyq_ctx *shim_ctx(const char *who, const float *trig, const float *window
     return g_shim_ctx;
 }
 
+// One call of the reference's offload interface = one or two rows.  The round trip is latency, not
+// bandwidth, so the rows go through a small page-locked block that the GPU reads and writes in place over
+// PCIe (host memory from hipHostMalloc is device-addressable): marshal -> ONE kernel launch -> synchronise
+// -> copy out.  No H2D/D2H copy commands, no events.
+struct ShimPinned {
+    float in[2][NYQ_MDCT_N / 2];
+    float fin[2][NYQ_MDCT_N / 2];
+    float carry[2][NYQ_HALF_OV + 4];   // rows stay 16-byte aligned: 64 floats apart
+    float tail[2][NYQ_HALF_OV + 4];
+};
+static ShimPinned *g_shim_pin = nullptr;
+
 static void shim_rows(const char *who, int nch, const float *const *input, float *const *output, const float *trig,
                       int N, int shift, int stride, int overlap, const float *window) {
     if (shift < 0 || shift > 3 || N != (NYQ_MDCT_N >> shift) || overlap != NYQ_OVERLAP || stride < 1 || !trig || !window)
         shim_die(who, "unsupported call: only the static 48 kHz mode (mdct.n 1920, overlap 120, shift 0..3) exists");
     nyq_ctx *ctx = shim_ctx(who, trig, window);
-    const int n2 = N >> 1;
-    float in[2][NYQ_MDCT_N / 2], carry[2][NYQ_HALF_OV], fin[2][NYQ_MDCT_N / 2], tail[2][NYQ_HALF_OV];
-    for (int c = 0; c < nch; c++) {
-        for (int k = 0; k < n2; k++) in[c][k] = input[c][(size_t)k * stride];   // argument marshalling
-        std::memcpy(carry[c], output[c], sizeof(float) * NYQ_HALF_OV);
+    if (!g_shim_pin) {
+        g_shim_pin = static_cast<ShimPinned *>(nyq_host_alloc(sizeof(ShimPinned)));
+        if (!g_shim_pin) shim_die(who, "cannot allocate page-locked staging memory");
     }
-    // rows must be contiguous per array: pack channel 1 right after channel 0
-    float pin[2 * (NYQ_MDCT_N / 2)], pfin[2 * (NYQ_MDCT_N / 2)];
-    for (int c = 0; c < nch; c++) std::memcpy(pin + c * n2, in[c], sizeof(float) * n2);
-    if (nyq_imdct_batch(ctx, shift, pin, &carry[0][0], pfin, &tail[0][0], (size_t)nch) != NYQ_OK)
+    ShimPinned &P = *g_shim_pin;
+    const int n2 = N >> 1;
+    // rows must be contiguous per array: channel 1 right after channel 0 (n2 floats apart; carries 60 apart)
+    float *pin = &P.in[0][0], *pfin = &P.fin[0][0], *pcar = &P.carry[0][0], *ptail = &P.tail[0][0];
+    for (int c = 0; c < nch; c++) {
+        const float *src = input[c];
+        float *dst = pin + c * n2;
+        if (stride == 1) std::memcpy(dst, src, sizeof(float) * n2);
+        else for (int k = 0; k < n2; k++) dst[k] = src[(size_t)k * stride];   // argument marshalling
+        std::memcpy(pcar + c * NYQ_HALF_OV, output[c], sizeof(float) * NYQ_HALF_OV);
+    }
+    if (nyq_imdct_batch_dev(ctx, shift, pin, pcar, pfin, ptail, (size_t)nch) != NYQ_OK || nyq_ctx_synchronize(ctx) != NYQ_OK)
         shim_die(who, nyq_last_error(ctx));
     for (int c = 0; c < nch; c++) {
         std::memcpy(output[c], pfin + c * n2, sizeof(float) * n2);
-        std::memcpy(output[c] + n2, tail[c], sizeof(float) * NYQ_HALF_OV);
+        std::memcpy(output[c] + n2, ptail + c * NYQ_HALF_OV, sizeof(float) * NYQ_HALF_OV);
     }
-    (void)fin;
 }
 
 extern "C" void processMDCTCuda(const float *input, float *output, const float *trig, int N, int shift, int stride,
@@ -821,6 +838,8 @@ extern "C" void processMDCTCudaB1C2(const float *input[2], float *output[2], con
 }
 
 extern "C" void cleanupCudaBuffers(void) {
+    if (g_shim_pin) nyq_host_free(g_shim_pin);
+    g_shim_pin = nullptr;
     if (g_shim_ctx) nyq_ctx_destroy(g_shim_ctx);
     g_shim_ctx = nullptr;
     g_shim_trig = g_shim_window = nullptr;
