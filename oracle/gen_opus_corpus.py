@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""oracle/gen_opus_corpus.py -- TEST INFRASTRUCTURE.  Builds a small corpus of CELT-only Ogg Opus files with
+the REFERENCE's own encoder (opus_encode_float of the reference build in oracle/_ref/libref_decode.so,
+OPUS_APPLICATION_RESTRICTED_LOWDELAY = CELT only) over the parameter space the three bundled files do not
+reach: frame sizes 2.5 / 5 / 10 / 20 ms, mono and stereo, 12 ... 256 kbit/s, CBR / VBR, band-limited modes;
+and records, per file, what the reference decoder makes of it:
+  * the encoder's final range-coder state after every packet (OPUS_GET_FINAL_RANGE) -- the Opus conformance
+    hook: a bit-exact entropy decoder ends every frame in exactly that state;
+  * the reference's NyquistIO::Load output: length, sum, sum of squares and every 5th sample.
+Outputs: tests/golden/corpus/<name>.opus and tests/golden/corpus_digest.npz.  Run from the repo root in the
+build container (needs oracle/_ref, i.e. /root/reference); the generated files are data and are committed."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import oggopus  # noqa: E402
+
+R = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_decode.so"))
+R.opus_encoder_create.restype = C.c_void_p
+R.opus_encoder_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+R.opus_encode_float.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_char_p, C.c_int]
+R.opus_encoder_destroy.argtypes = [C.c_void_p]
+R.ref_decode_pcm.restype = C.c_long
+R.ref_decode_pcm.argtypes = [C.c_char_p, C.c_long, C.POINTER(C.c_float), C.c_long, C.POINTER(C.c_long)]
+
+RESTRICTED_LOWDELAY = 2051
+SET_BITRATE, SET_VBR, SET_BANDWIDTH, SET_COMPLEXITY, GET_LOOKAHEAD, GET_FINAL_RANGE, SET_VBR_CONSTRAINT = 4002, 4006, 4008, 4010, 4027, 4031, 4020
+BW = {"nb": 1101, "wb": 1103, "swb": 1104, "fb": 1105}
+
+
+def ctl_set(enc, req, val):
+    rc = R.opus_encoder_ctl(C.c_void_p(enc), C.c_int(req), C.c_int(val))
+    assert rc == 0, (req, val, rc)
+
+
+def ctl_get(enc, req, ctype=C.c_int):
+    v = ctype(0)
+    rc = R.opus_encoder_ctl(C.c_void_p(enc), C.c_int(req), C.byref(v))
+    assert rc == 0, (req, rc)
+    return v.value
+
+
+def signal(seconds, channels, seed):
+    """tones + a sweep + castanet-like clicks (transient frames) + a silent gap + a noise tail"""
+    rng = np.random.default_rng(seed)
+    n = int(48000 * seconds)
+    t = np.arange(n) / 48000.0
+    chans = []
+    for c in range(channels):
+        f0 = 220.0 * (1 + 0.5 * c)
+        x = 0.25 * np.sin(2 * np.pi * f0 * t) + 0.12 * np.sin(2 * np.pi * 3.01 * f0 * t + c)
+        x += 0.15 * np.sin(2 * np.pi * (300 + 5000 * t / seconds) * t)
+        for k in range(int(seconds * 6)):                      # clicks: sharp exponentially decaying bursts
+            p = int(rng.integers(0, n - 2000))
+            L = 1500
+            x[p:p + L] += 0.6 * rng.standard_normal(L) * np.exp(-np.arange(L) / 120.0)
+        g0, g1 = int(0.45 * n), int(0.55 * n)
+        x[g0:g1] = 0.0                                          # digital silence
+        x[int(0.8 * n):] += 0.05 * rng.standard_normal(n - int(0.8 * n))
+        chans.append(x)
+    return np.stack(chans, axis=1).astype(np.float32)          # [n][channels]
+
+
+def encode(name, channels, frame, bitrate, vbr, bw, complexity, seconds, seed):
+    err = C.c_int(0)
+    enc = R.opus_encoder_create(48000, channels, RESTRICTED_LOWDELAY, C.byref(err))
+    assert enc and err.value == 0
+    ctl_set(enc, SET_BITRATE, bitrate)
+    ctl_set(enc, SET_VBR, 1 if vbr else 0)
+    if vbr:
+        ctl_set(enc, SET_VBR_CONSTRAINT, 0)
+    ctl_set(enc, SET_COMPLEXITY, complexity)
+    if bw != "fb":
+        ctl_set(enc, SET_BANDWIDTH, BW[bw])
+    preskip = ctl_get(enc, GET_LOOKAHEAD)
+    pcm = signal(seconds, channels, seed)
+    total = pcm.shape[0]
+    nfr = (total + preskip + frame - 1) // frame               # flush the encoder's look-ahead
+    padded = np.zeros((nfr * frame, channels), np.float32)
+    padded[:total] = pcm
+    packets, ranges = [], []
+    buf = C.create_string_buffer(4000)
+    for i in range(nfr):
+        blk = np.ascontiguousarray(padded[i * frame:(i + 1) * frame])
+        nb = R.opus_encode_float(enc, blk.ctypes.data_as(C.POINTER(C.c_float)), frame, buf, 4000)
+        assert nb > 0, nb
+        packets.append(buf.raw[:nb])
+        ranges.append(ctl_get(enc, GET_FINAL_RANGE, C.c_uint))
+    R.opus_encoder_destroy(enc)
+    raw = oggopus.mux_family0(packets, channels, preskip, frame, total)
+    return raw, np.array(ranges, np.uint32)
+
+
+CORPUS = [
+    # name             ch frame  bitrate vbr   bw   cx  seconds
+    ("st_20ms_128k",    2, 960, 128000, True, "fb", 10, 1.2),
+    ("st_20ms_32k",     2, 960,  32000, True, "fb", 10, 1.2),
+    ("st_20ms_12k_cbr", 2, 960,  12000, False, "fb", 5, 1.0),
+    ("st_10ms_96k",     2, 480,  96000, True, "fb", 10, 1.0),
+    ("st_5ms_96k",      2, 240,  96000, True, "fb", 10, 0.8),
+    ("st_2p5ms_128k",   2, 120, 128000, True, "fb", 10, 0.6),
+    ("st_20ms_256k_cbr", 2, 960, 256000, False, "fb", 10, 1.0),
+    ("mono_20ms_64k",   1, 960,  64000, True, "fb", 10, 1.2),
+    ("mono_20ms_16k",   1, 960,  16000, True, "fb", 10, 1.0),
+    ("mono_10ms_24k_cbr", 1, 480, 24000, False, "fb", 3, 1.0),
+    ("mono_5ms_64k",    1, 240,  64000, True, "fb", 10, 0.8),
+    ("mono_2p5ms_48k",  1, 120,  48000, True, "fb", 10, 0.6),
+    ("st_20ms_48k_swb", 2, 960,  48000, True, "swb", 10, 1.0),
+    ("st_20ms_32k_wb",  2, 960,  32000, True, "wb", 10, 1.0),
+    ("mono_20ms_16k_nb", 1, 960, 16000, True, "nb", 10, 1.0),
+    ("st_10ms_20k_cx0", 2, 480,  20000, True, "fb", 0, 1.0),
+]
+
+
+def main():
+    out_dir = os.path.join(ROOT, "tests", "golden", "corpus")
+    os.makedirs(out_dir, exist_ok=True)
+    dig = {}
+    for k, (name, ch, frame, br, vbr, bw, cx, secs) in enumerate(CORPUS):
+        raw, ranges = encode(name, ch, frame, br, vbr, bw, cx, secs, 1000 + k)
+        open(os.path.join(out_dir, name + ".opus"), "wb").write(raw)
+        info = (C.c_long * 3)()
+        n = R.ref_decode_pcm(raw, len(raw), None, 0, info)
+        assert n > 0, name
+        pcm = np.zeros(n, np.float32)
+        assert R.ref_decode_pcm(raw, len(raw), pcm.ctypes.data_as(C.POINTER(C.c_float)), n, info) == n
+        dig[name + "/ranges"] = ranges
+        dig[name + "/meta"] = np.array([ch, frame, n, len(raw)], np.int64)
+        dig[name + "/sum"] = np.array([pcm.astype(np.float64).sum(), (pcm.astype(np.float64) ** 2).sum()])
+        dig[name + "/every5"] = pcm[::5].copy()
+        print(f"{name}: {len(raw)} bytes, {len(ranges)} packets, {n} samples, rms {np.sqrt((pcm.astype(np.float64)**2).mean()):.4f}")
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "corpus_digest.npz"), **dig)
+
+
+if __name__ == "__main__":
+    main()

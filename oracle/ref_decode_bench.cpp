@@ -49,6 +49,23 @@ extern "C" double ref_decode_bench(const unsigned char *bytes, long size, long c
     return s;
 }
 
+// Whole-file decode through the reference's plugin surface, PCM handed back (tests compare against it).
+// info = {channels, sample rate, samples (interleaved count)}; returns the sample count or -1.
+extern "C" long ref_decode_pcm(const unsigned char *bytes, long size, float *out, long capacity, long *info) {
+    try {
+        const std::vector<uint8_t> file(bytes, bytes + size);
+        nqr::NyquistIO loader;
+        nqr::AudioData data;
+        loader.Load(&data, "opus", file);
+        if (info) { info[0] = data.channelCount; info[1] = data.sampleRate; info[2] = (long)data.samples.size(); }
+        if (out && capacity >= (long)data.samples.size())
+            for (size_t i = 0; i < data.samples.size(); i++) out[i] = data.samples[i];
+        return (long)data.samples.size();
+    } catch (...) {
+        return -1;
+    }
+}
+
 #ifdef REF_DECODE_MAIN
 int main(int argc, char **argv) {
     if (argc < 4) { std::fprintf(stderr, "usage: ref_decode_bench file.opus count threads\n"); return 2; }

@@ -75,3 +75,28 @@ def mux_family1(streams, coupled, mapping, preskip, granules, serial=0x4E595131)
         pkt = b"".join(self_delimit(s[i]) for s in streams[:-1]) + streams[-1][i]
         out.append(page(serial, 2 + i, granules[i], pkt, 4 if i == n - 1 else 0))
     return b"".join(out)
+
+
+def mux_family0(packets, channels, preskip, frame_samples, total_samples, serial=0x4E595130, per_page=8):
+    """Single mono/stereo Opus stream (channel mapping family 0).  `total_samples` = input samples per
+    channel: the last page's granule position trims the encoder's padding (RFC 7845 section 4.4)."""
+    head = b"OpusHead" + bytes([1, channels]) + struct.pack("<HIh", preskip, 48000, 0) + bytes([0])
+    tags = b"OpusTags" + struct.pack("<I", 8) + b"nyq-test" + struct.pack("<I", 0)
+    out = [page(serial, 0, 0, head, 2), page(serial, 1, 0, tags, 0)]
+    seq, done, i, n = 2, 0, 0, len(packets)
+    while i < n:
+        group = packets[i:i + per_page]
+        i += len(group)
+        done += len(group) * frame_samples
+        last = i >= n
+        gran = min(done, preskip + total_samples) if last else done
+        lac, body = [], b""
+        for pk in group:
+            lac += [255] * (len(pk) // 255) + [len(pk) % 255]
+            body += pk
+        assert len(lac) <= 255
+        hdr = b"OggS" + bytes([0, 4 if last else 0]) + struct.pack("<qIII", gran, serial, seq, 0) + bytes([len(lac)]) + bytes(lac)
+        crc = ogg_crc(hdr + body)
+        out.append(hdr[:22] + struct.pack("<I", crc) + hdr[26:] + body)
+        seq += 1
+    return b"".join(out)
