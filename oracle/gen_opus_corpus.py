@@ -11,6 +11,7 @@ Outputs: tests/golden/corpus/<name>.opus and tests/golden/corpus_digest.npz.  Ru
 build container (needs oracle/_ref, i.e. /root/reference); the generated files are data and are committed."""
 import ctypes as C
 import os
+import struct
 import sys
 
 import numpy as np
@@ -95,6 +96,52 @@ def encode(name, channels, frame, bitrate, vbr, bw, complexity, seconds, seed):
     return raw, np.array(ranges, np.uint32)
 
 
+def encode_surround(name, channels, frame, bitrate, seconds, seed):
+    """channel mapping family 1 through the reference's surround encoder (opus_multistream_encoder.c): 5.1 =
+    4 streams (2 coupled), 7.1 = 5 streams (3 coupled) -- the shape of BASELINE config 5's 8-channel file."""
+    R.opus_multistream_surround_encoder_create.restype = C.c_void_p
+    R.opus_multistream_surround_encoder_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                                           C.c_char_p, C.c_int, C.POINTER(C.c_int)]
+    R.opus_multistream_encode_float.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_char_p, C.c_int]
+    R.opus_multistream_encoder_destroy.argtypes = [C.c_void_p]
+    streams, coupled, err = C.c_int(0), C.c_int(0), C.c_int(0)
+    mapping = C.create_string_buffer(256)
+    enc = R.opus_multistream_surround_encoder_create(48000, channels, 1, C.byref(streams), C.byref(coupled), mapping,
+                                                     RESTRICTED_LOWDELAY, C.byref(err))
+    assert enc and err.value == 0, err.value
+
+    def mctl_set(req, val):
+        assert R.opus_multistream_encoder_ctl(C.c_void_p(enc), C.c_int(req), C.c_int(val)) == 0
+
+    mctl_set(SET_BITRATE, bitrate)
+    look = C.c_int(0)
+    assert R.opus_multistream_encoder_ctl(C.c_void_p(enc), C.c_int(GET_LOOKAHEAD), C.byref(look)) == 0
+    preskip = look.value
+    pcm = signal(seconds, channels, seed)
+    pcm[:, 3 if channels > 3 else 0] *= 0.3                     # the LFE channel: quieter
+    total = pcm.shape[0]
+    nfr = (total + preskip + frame - 1) // frame
+    padded = np.zeros((nfr * frame, channels), np.float32)
+    padded[:total] = pcm
+    packets = []
+    buf = C.create_string_buffer(20000)
+    for i in range(nfr):
+        blk = np.ascontiguousarray(padded[i * frame:(i + 1) * frame])
+        nb = R.opus_multistream_encode_float(enc, blk.ctypes.data_as(C.POINTER(C.c_float)), frame, buf, 20000)
+        assert nb > 0, nb
+        packets.append(buf.raw[:nb])
+    R.opus_multistream_encoder_destroy(enc)
+    head = (b"OpusHead" + bytes([1, channels]) + struct.pack("<HIh", preskip, 48000, 0) + bytes([1, streams.value, coupled.value])
+            + mapping.raw[:channels])
+    raw = oggopus.mux_packets(head, packets, preskip, frame, total, per_page=2)
+    return raw, streams.value, coupled.value
+
+
+SURROUND = [
+    ("surround71_20ms_320k", 8, 960, 320000, 1.0),
+    ("surround51_10ms_192k", 6, 480, 192000, 0.8),
+]
+
 CORPUS = [
     # name             ch frame  bitrate vbr   bw   cx  seconds
     ("st_20ms_128k",    2, 960, 128000, True, "fb", 10, 1.2),
@@ -133,6 +180,18 @@ def main():
         dig[name + "/sum"] = np.array([pcm.astype(np.float64).sum(), (pcm.astype(np.float64) ** 2).sum()])
         dig[name + "/every5"] = pcm[::5].copy()
         print(f"{name}: {len(raw)} bytes, {len(ranges)} packets, {n} samples, rms {np.sqrt((pcm.astype(np.float64)**2).mean()):.4f}")
+    for k, (name, ch, frame, br, secs) in enumerate(SURROUND):
+        raw, nstreams, ncoupled = encode_surround(name, ch, frame, br, secs, 2000 + k)
+        open(os.path.join(out_dir, name + ".opus"), "wb").write(raw)
+        info = (C.c_long * 3)()
+        n = R.ref_decode_pcm(raw, len(raw), None, 0, info)
+        assert n > 0, name
+        pcm = np.zeros(n, np.float32)
+        assert R.ref_decode_pcm(raw, len(raw), pcm.ctypes.data_as(C.POINTER(C.c_float)), n, info) == n
+        dig[name + "/meta"] = np.array([ch, frame, n, len(raw), nstreams, ncoupled], np.int64)
+        dig[name + "/sum"] = np.array([pcm.astype(np.float64).sum(), (pcm.astype(np.float64) ** 2).sum()])
+        dig[name + "/every5"] = pcm[::5].copy()
+        print(f"{name}: {len(raw)} bytes, {nstreams} streams ({ncoupled} coupled), {n} samples, rms {np.sqrt((pcm.astype(np.float64)**2).mean()):.4f}")
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "corpus_digest.npz"), **dig)
 
 

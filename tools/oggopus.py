@@ -81,6 +81,11 @@ def mux_family0(packets, channels, preskip, frame_samples, total_samples, serial
     """Single mono/stereo Opus stream (channel mapping family 0).  `total_samples` = input samples per
     channel: the last page's granule position trims the encoder's padding (RFC 7845 section 4.4)."""
     head = b"OpusHead" + bytes([1, channels]) + struct.pack("<HIh", preskip, 48000, 0) + bytes([0])
+    return mux_packets(head, packets, preskip, frame_samples, total_samples, serial, per_page)
+
+
+def mux_packets(head, packets, preskip, frame_samples, total_samples, serial=0x4E595130, per_page=8):
+    """Ogg pages around ready-made Opus packets (any mapping family: `head` is the OpusHead packet)."""
     tags = b"OpusTags" + struct.pack("<I", 8) + b"nyq-test" + struct.pack("<I", 0)
     out = [page(serial, 0, 0, head, 2), page(serial, 1, 0, tags, 0)]
     seq, done, i, n = 2, 0, 0, len(packets)
