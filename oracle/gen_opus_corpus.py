@@ -66,9 +66,9 @@ def signal(seconds, channels, seed):
     return np.stack(chans, axis=1).astype(np.float32)          # [n][channels]
 
 
-def encode(name, channels, frame, bitrate, vbr, bw, complexity, seconds, seed):
+def encode(name, channels, frame, bitrate, vbr, bw, complexity, seconds, seed, application=RESTRICTED_LOWDELAY):
     err = C.c_int(0)
-    enc = R.opus_encoder_create(48000, channels, RESTRICTED_LOWDELAY, C.byref(err))
+    enc = R.opus_encoder_create(48000, channels, application, C.byref(err))
     assert enc and err.value == 0
     ctl_set(enc, SET_BITRATE, bitrate)
     ctl_set(enc, SET_VBR, 1 if vbr else 0)
@@ -180,6 +180,9 @@ def main():
         dig[name + "/sum"] = np.array([pcm.astype(np.float64).sum(), (pcm.astype(np.float64) ** 2).sum()])
         dig[name + "/every5"] = pcm[::5].copy()
         print(f"{name}: {len(raw)} bytes, {len(ranges)} packets, {n} samples, rms {np.sqrt((pcm.astype(np.float64)**2).mean()):.4f}")
+    # a SILK stream (VOIP application at 12 kbit/s): NOT decodable by this library by design -- the error path
+    raw, _ = encode("silk_voip_12k", 1, 960, 12000, True, "fb", 5, 0.4, 3000, application=2048)
+    open(os.path.join(out_dir, "unsupported_silk_voip_12k.opus"), "wb").write(raw)
     for k, (name, ch, frame, br, secs) in enumerate(SURROUND):
         raw, nstreams, ncoupled = encode_surround(name, ch, frame, br, secs, 2000 + k)
         open(os.path.join(out_dir, name + ".opus"), "wb").write(raw)

@@ -16,7 +16,8 @@ import pytest
 from conftest import GOLDEN, ROOT, rel_rms
 from test_host_decoder import entropy_decode, load_host
 
-NAMES = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GOLDEN, "corpus", "*.opus")))
+NAMES = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GOLDEN, "corpus", "*.opus"))
+               if not os.path.basename(p).startswith("unsupported_"))
 FAMILY0 = [n for n in NAMES if not n.startswith("surround")]   # mono / stereo: one elementary stream
 
 
@@ -85,3 +86,20 @@ def test_plugin_surface_decodes_corpus_like_the_reference(host, digest, name):
         assert R.ref_decode_pcm(raw, len(raw), full.ctypes.data_as(C.c_void_p), nsamp, None) == nsamp
         assert rel_rms(got, full) <= 1e-5
         assert np.abs(got - full).max() <= 4e-6
+
+
+def test_silk_stream_is_refused_not_misdecoded(host):
+    """SILK / hybrid packets are outside the CELT path this library accelerates: the entropy stage reports
+    them (TOC configuration < 16) instead of producing audio."""
+    raw = open(os.path.join(GOLDEN, "corpus", "unsupported_silk_voip_12k.opus"), "rb").read()
+    rc = entropy_decode(host, raw, max_frames=8, channels=1, n=960)[0]
+    assert rc == -11
+
+
+@pytest.mark.gpu
+def test_batch_with_a_silk_stream_fails_only_that_stream(host):
+    raw_bad = open(os.path.join(GOLDEN, "corpus", "unsupported_silk_voip_12k.opus"), "rb").read()
+    info = np.zeros(8, np.int64)
+    assert host.nyqh_nyquistio_load_buffer(raw_bad, len(raw_bad), None, 0, info) == -1     # std::runtime_error
+    raw_ok = open(os.path.join(GOLDEN, "corpus", "mono_20ms_64k.opus"), "rb").read()
+    assert host.nyqh_nyquistio_load_buffer(raw_ok, len(raw_ok), None, 0, info) == 57600
