@@ -132,7 +132,7 @@ int nyq_celt_post_dev(nyq_ctx *ctx, int LM, const float *d_pcm, const int *d_pf_
                       size_t nstreams, size_t nframes, int channels);
 
 /* libvorbis' mdct_backward (third_party/libvorbis/src/mdct.c:397-491) on `batch` rows: n/2 coefficients
- * in, n samples out per row, n a power of two in 64..4096 (the Vorbis block sizes; 8192 is not built).
+ * in, n samples out per row, n a power of two in 64..8192 (every Vorbis block size).
  * d_in [batch][n/2], d_out [batch][n].  out[i] = sum_k in[k] cos(2 pi/n (i + 1/2 + n/4)(k + 1/2)):
  * no window, no overlap-add (libvorbis does those in block.c). */
 int nyq_vorbis_imdct_batch_dev(nyq_ctx *ctx, int n, const float *d_in, float *d_out, size_t batch);

@@ -33,46 +33,55 @@ NYQ_HD cpx csub(cpx a, cpx b) { return {a.re - b.re, a.im - b.im}; }
 NYQ_HD cpx cmul_i(cpx a) { return {-a.im, a.re}; }
 NYQ_HD cpx cmul_ni(cpx a) { return {a.im, -a.re}; }
 
-// cos(2 pi m / 32), m = 0..8 (first octant + quarter), double literals rounded once to float.
+// cos(2 pi m / 64), m = 0..16 (first quarter turn), double literals rounded once to float.
 // All power-of-two twiddles are read out of this table by symmetry.
-NYQ_HD constexpr double cos32_q(int m) {
-    constexpr double c[9] = {1.0,
-                             0.98078528040323044912618223613424,
-                             0.92387953251128675612818318939679,
-                             0.83146961230254523707878837761791,
-                             0.70710678118654752440084436210485,
-                             0.55557023301960222474283081394853,
-                             0.38268343236508977172845998403040,
-                             0.19509032201612826784828486847702,
-                             0.0};
+NYQ_HD constexpr double cos64_q(int m) {
+    constexpr double c[17] = {1.0,
+                              0.99518472667219688624483695310948,
+                              0.98078528040323044912618223613424,
+                              0.95694033573220886493579788698027,
+                              0.92387953251128675612818318939679,
+                              0.88192126434835502971275686366039,
+                              0.83146961230254523707878837761791,
+                              0.77301045336273696081090660975847,
+                              0.70710678118654752440084436210485,
+                              0.63439328416364549821517161322549,
+                              0.55557023301960222474283081394853,
+                              0.47139673682599764855638762590525,
+                              0.38268343236508977172845998403040,
+                              0.29028467725446236763619237581740,
+                              0.19509032201612826784828486847702,
+                              0.09801714032956060199419556388864,
+                              0.0};
     return c[m];
 }
-// cos(2 pi m / 32) for any m
-NYQ_HD constexpr double cos32(int m) {
-    m %= 32;
-    if (m < 0) m += 32;
-    if (m > 16) m = 32 - m;      // cos is even about pi
-    return m <= 8 ? cos32_q(m) : -cos32_q(16 - m);
+// cos(2 pi m / 64) for any m
+NYQ_HD constexpr double cos64(int m) {
+    m %= 64;
+    if (m < 0) m += 64;
+    if (m > 32) m = 64 - m;      // cos is even about pi
+    return m <= 16 ? cos64_q(m) : -cos64_q(32 - m);
 }
-NYQ_HD constexpr double sin32(int m) { return cos32(m - 8); }
+NYQ_HD constexpr double sin64(int m) { return cos64(m - 16); }
 
-// a * e^{+2 pi i m / N} for N in {4,8,16,32}, m a compile-time constant.
+// a * e^{+2 pi i m / N} for N in {4,8,16,32,64}, m a compile-time constant.
 // Trivial rotations cost nothing, odd multiples of 1/8 turn cost 2 adds + 2 muls.
 template <int N, int M>
 NYQ_HD cpx rot(cpx a) {
-    constexpr int m32 = ((M % N) + N) % N * (32 / N);   // position on the 32-gon
-    if constexpr (m32 == 0) return a;
-    else if constexpr (m32 == 8) return cmul_i(a);
-    else if constexpr (m32 == 16) return {-a.re, -a.im};
-    else if constexpr (m32 == 24) return cmul_ni(a);
-    else if constexpr (m32 % 8 == 4) {
-        constexpr float h = (float)cos32_q(4);
-        if constexpr (m32 == 4) return {(a.re - a.im) * h, (a.re + a.im) * h};
-        else if constexpr (m32 == 12) return {-(a.re + a.im) * h, (a.re - a.im) * h};
-        else if constexpr (m32 == 20) return {(a.im - a.re) * h, -(a.re + a.im) * h};
+    static_assert(64 % N == 0, "power-of-two twiddles up to the 64-gon");
+    constexpr int m64 = ((M % N) + N) % N * (64 / N);   // position on the 64-gon
+    if constexpr (m64 == 0) return a;
+    else if constexpr (m64 == 16) return cmul_i(a);
+    else if constexpr (m64 == 32) return {-a.re, -a.im};
+    else if constexpr (m64 == 48) return cmul_ni(a);
+    else if constexpr (m64 % 16 == 8) {
+        constexpr float h = (float)cos64_q(8);
+        if constexpr (m64 == 8) return {(a.re - a.im) * h, (a.re + a.im) * h};
+        else if constexpr (m64 == 24) return {-(a.re + a.im) * h, (a.re - a.im) * h};
+        else if constexpr (m64 == 40) return {(a.im - a.re) * h, -(a.re + a.im) * h};
         else return {(a.re + a.im) * h, (a.im - a.re) * h};
     } else {
-        constexpr float c = (float)cos32(m32), s = (float)sin32(m32);
+        constexpr float c = (float)cos64(m64), s = (float)sin64(m64);
         return {a.re * c - a.im * s, a.re * s + a.im * c};
     }
 }
@@ -186,6 +195,10 @@ struct Dft<16> {
 template <>
 struct Dft<32> {
     static NYQ_HD void run(cpx (&v)[32]) { CtDft<4, 8>::run(v); }
+};
+template <>
+struct Dft<64> {   // Vorbis n = 8192 only (n/4 = 2048 = 32 x 64)
+    static NYQ_HD void run(cpx (&v)[64]) { CtDft<8, 8>::run(v); }
 };
 
 constexpr int inv_mod(int a, int m) {

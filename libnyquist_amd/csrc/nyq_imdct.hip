@@ -47,9 +47,9 @@ struct nyq_ctx {
     int res_synth_long[4] = {0, 0, 0, 0};
     int res_synth_short = 0;
     int res_post[4] = {0, 0, 0, 0};
-    int res_vorbis[11] = {0};
+    int res_vorbis[12] = {0};
     float *d_vtab = nullptr;             // Vorbis rotation + twiddle tables of every block size, one allocation
-    size_t vrot_off[11] = {0}, vtw_off[11] = {0};   // float offsets by log2(n/4)
+    size_t vrot_off[12] = {0}, vtw_off[12] = {0};   // float offsets by log2(n/4)
     std::string err;
     char devname[256];
 };
@@ -92,7 +92,7 @@ static int upload_tables(nyq_ctx *ctx) {
 // per block size n = 4 << m: rot[i] = (cos, sin)(2 pi (i + 1/8)/n) and twid[k] = (cos, sin)(2 pi k/(n/4)).
 static int build_vorbis_tables(nyq_ctx *ctx) {
     std::vector<float> h;
-    for (int m = 4; m <= 10; m++) {
+    for (int m = 4; m <= 11; m++) {
         const int n4 = 1 << m, n = 4 * n4;
         ctx->vrot_off[m] = h.size();
         for (int i = 0; i < n4; i++) {
@@ -468,9 +468,9 @@ static int launch_vorbis(nyq_ctx *ctx, const float *d_in, float *d_out, size_t b
 extern "C" int nyq_vorbis_imdct_batch_dev(nyq_ctx *ctx, int n, const float *d_in, float *d_out, size_t batch) {
     if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_vorbis_imdct_batch_dev: ctx is NULL");
     int m = -1;
-    for (int k = 4; k <= 10; k++)
+    for (int k = 4; k <= 11; k++)
         if (n == (4 << k)) m = k;
-    if (m < 0) return fail(ctx, NYQ_ERR_INVALID, "nyq_vorbis_imdct_batch_dev: n must be a power of two in 64..4096");
+    if (m < 0) return fail(ctx, NYQ_ERR_INVALID, "nyq_vorbis_imdct_batch_dev: n must be a power of two in 64..8192");
     if (batch == 0) return NYQ_OK;
     if (!d_in || !d_out || d_in == d_out) return fail(ctx, NYQ_ERR_INVALID, "nyq_vorbis_imdct_batch_dev: NULL or aliased buffers");
     if (!aligned16(d_in) || !aligned16(d_out))
@@ -482,14 +482,15 @@ extern "C" int nyq_vorbis_imdct_batch_dev(nyq_ctx *ctx, int n, const float *d_in
     case 7: return launch_vorbis<7>(ctx, d_in, d_out, batch);
     case 8: return launch_vorbis<8>(ctx, d_in, d_out, batch);
     case 9: return launch_vorbis<9>(ctx, d_in, d_out, batch);
-    default: return launch_vorbis<10>(ctx, d_in, d_out, batch);
+    case 10: return launch_vorbis<10>(ctx, d_in, d_out, batch);
+    default: return launch_vorbis<11>(ctx, d_in, d_out, batch);
     }
 }
 
 extern "C" int nyq_vorbis_imdct_batch(nyq_ctx *ctx, int n, const float *in, float *out, size_t batch) {
     if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_vorbis_imdct_batch: ctx is NULL");
     if (batch == 0) return NYQ_OK;
-    if (!in || !out || n < 64 || n > 4096) return fail(ctx, NYQ_ERR_INVALID, "nyq_vorbis_imdct_batch: bad argument");
+    if (!in || !out || n < 64 || n > 8192) return fail(ctx, NYQ_ERR_INVALID, "nyq_vorbis_imdct_batch: bad argument");
     NYQ_HIP(ctx, hipSetDevice(ctx->device));
     const size_t n_in = round16f(batch * (size_t)(n / 2)), n_out = round16f(batch * (size_t)n);
     int rc = need_scratch(ctx, (n_in + n_out) * sizeof(float));

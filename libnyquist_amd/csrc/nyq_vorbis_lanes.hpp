@@ -1,7 +1,7 @@
 // nyq_vorbis_lanes.hpp -- lane program of the batched Vorbis inverse MDCT.
 //
 // libvorbis' mdct_backward (third_party/libvorbis/src/mdct.c:397-491; tables mdct_init :52-91) maps
-// n/2 coefficients to n samples, n a power of two (Vorbis block sizes 64..8192):
+// n/2 coefficients to n samples, n a power of two (Vorbis block sizes 64..8192, all built):
 //     out[i] = sum_k X[k] cos(2 pi / n (i + 1/2 + n/4)(k + 1/2)),   i = 0 .. n-1
 // which is the same transform as CELT's with exact rotations, the middle half
 // raw[j] = out[n/4 + j] being what the N/4-point complex FFT produces and the outer quarters its
@@ -22,13 +22,15 @@ namespace nyq {
 
 template <int LOGN4>
 struct VGeo {
-    static_assert(LOGN4 >= 4 && LOGN4 <= 10, "Vorbis block sizes 64 .. 4096 (n/4 = 16 .. 1024)");
+    static_assert(LOGN4 >= 4 && LOGN4 <= 11, "Vorbis block sizes 64 .. 8192 (n/4 = 16 .. 2048)");
     static constexpr int N4 = 1 << LOGN4;              // complex points
     static constexpr int N2 = 2 * N4;                  // coefficients per row
     static constexpr int N = 4 * N4;                   // samples per row
     static constexpr int R1 = 1 << (LOGN4 / 2);        // pass-2 radix
     static constexpr int R2 = N4 / R1;                 // pass-1 radix (R2 >= R1)
-    static constexpr int G = (kWave / R1) > 4 ? (kWave / R1) : 4;   // rows per group
+    // rows per group: enough for the radix-R1 pass to fill the wavefront, at least 4 -- except n = 8192, where
+    // two rows already are 32 KB of LDS and 16 stage tasks (32 float4 registers) per lane
+    static constexpr int G = LOGN4 == 11 ? 2 : (kWave / R1) > 4 ? (kWave / R1) : 4;
     static constexpr int NT = N4 / 4;                  // stage tasks per row
     static constexpr int TASKS = G * NT;               // per group
     static constexpr int TPL = (TASKS + kWave - 1) / kWave;         // tasks per lane

@@ -25,7 +25,7 @@ Writes DATA only (inputs + expected outputs):
                                       same frames the post-filter parameters and state, the filtered
                                       history, the de-emphasis memory and the FINAL decoded PCM
                                       (AudioData::samples) -- the whole freq[] -> PCM chain
-  ref_vorbis.npz                      libvorbis mdct_backward (mdct.c compiled standalone), block sizes 64..4096
+  ref_vorbis.npz                      libvorbis mdct_backward (mdct.c compiled standalone), block sizes 64..8192
   short.opus, short_opus_digest.npz   the bundled test file itself plus per-frame digests of the
                                       reference decoder's freq[] for all 220 frames, its post-filter
                                       parameters and its complete decoded PCM (end-to-end check of
@@ -292,7 +292,7 @@ def main():
     from oracle.pyoracle import VorbisRef
     vr = VorbisRef()
     vb = {}
-    for n in (64, 128, 256, 512, 1024, 2048, 4096):
+    for n in (64, 128, 256, 512, 1024, 2048, 4096, 8192):
         xv = np.concatenate([rng.uniform(-1, 1, (1, n // 2)), rng.standard_normal((1, n // 2)) * 30,
                              np.eye(1, n // 2, 3) * 100.0]).astype(np.float32)
         vb[f"x{n}"] = xv

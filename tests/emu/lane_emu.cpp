@@ -222,6 +222,7 @@ extern "C" int emu_vorbis_imdct(int n, const float *in, float *out, long nrows, 
     case 1024: emu_vorbis<8>(in, out, nrows, rot, twid); return 0;
     case 2048: emu_vorbis<9>(in, out, nrows, rot, twid); return 0;
     case 4096: emu_vorbis<10>(in, out, nrows, rot, twid); return 0;
+    case 8192: emu_vorbis<11>(in, out, nrows, rot, twid); return 0;
     }
     return -1;
 }
@@ -230,7 +231,7 @@ extern "C" int emu_vorbis_imdct(int n, const float *in, float *out, long nrows, 
 extern "C" int emu_dft(int r, float *io) {
     switch (r) {
 #define CASE(R) case R: { cpx v[R]; std::memcpy(v, io, sizeof v); Dft<R>::run(v); std::memcpy(io, v, sizeof v); return 0; }
-        CASE(2) CASE(3) CASE(4) CASE(5) CASE(8) CASE(15) CASE(16) CASE(32)
+        CASE(2) CASE(3) CASE(4) CASE(5) CASE(8) CASE(15) CASE(16) CASE(32) CASE(64)
 #undef CASE
     }
     return -1;

@@ -23,7 +23,7 @@ def emu():
     return L
 
 
-@pytest.mark.parametrize("r", [2, 3, 4, 5, 8, 15, 16, 32])
+@pytest.mark.parametrize("r", [2, 3, 4, 5, 8, 15, 16, 32, 64])
 def test_register_dft(emu, r):
     rng = np.random.default_rng(r)
     x = rng.standard_normal(2 * r).astype(np.float32)

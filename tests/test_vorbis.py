@@ -1,4 +1,4 @@
-"""Vorbis inverse MDCT: libvorbis' mdct_backward for block sizes 64..4096.
+"""Vorbis inverse MDCT: libvorbis' mdct_backward for block sizes 64..8192.
 CPU tier: the closed-form oracle against outputs of libvorbis' own mdct.c (compiled standalone,
 fixtures ref_vorbis.npz), and the HIP lane program replayed on the CPU.  GPU tier: the kernel
 through the C ABI."""
@@ -11,7 +11,7 @@ import pytest
 
 from conftest import GOLDEN, ROOT, rel_rms
 
-SIZES = [64, 128, 256, 512, 1024, 2048, 4096]
+SIZES = [64, 128, 256, 512, 1024, 2048, 4096, 8192]
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 
 

@@ -48,7 +48,7 @@ for nfft, rows in () if ONLY and ONLY != 'ifft' else ((60, 1 << 22), (480, 1 << 
     ms = timeit(lambda: ctx.ifft_batch_dev(nfft, x.data_ptr(), y.data_ptr(), rows))
     res.append(dict(op=f"ifft_batch_dev nfft {nfft}", rows=rows, ms=ms, alg_GBps=rows * nfft * 16 / ms / 1e6, rows_per_s=rows / ms * 1e3))
     del x, y
-for n, rows in () if ONLY and ONLY != 'vorbis' else ((2048, 1 << 19), (256, 1 << 22), (4096, 1 << 18), (64, 1 << 23)):
+for n, rows in () if ONLY and ONLY != 'vorbis' else ((2048, 1 << 19), (256, 1 << 22), (4096, 1 << 18), (64, 1 << 23), (8192, 1 << 17)):
     x = torch.rand((rows, n // 2), generator=g, device=dev)
     y = torch.empty((rows, n), device=dev)
     ms = timeit(lambda: ctx.vorbis_imdct_batch_dev(n, x.data_ptr(), y.data_ptr(), rows))
