@@ -564,6 +564,17 @@ static int need_copy_streams(nyq_ctx *ctx, size_t nevents) {
     return NYQ_OK;
 }
 
+// Whatever way a pipelined host-pointer call returns (an error half way included), no copy that still
+// reads or writes the CALLER's buffers may be left in flight.
+struct DrainOnExit {
+    nyq_ctx *c;
+    ~DrainOnExit() {
+        if (c->s_h2d) (void)hipStreamSynchronize(c->s_h2d);
+        (void)hipStreamSynchronize(c->stream);
+        if (c->s_d2h) (void)hipStreamSynchronize(c->s_d2h);
+    }
+};
+
 // Host rows -> device -> host, cut into pieces of whole chains so that the upload of piece k+1, the kernel
 // of piece k and the download of piece k-1 run at the same time (three streams, events between them).
 constexpr size_t kHostPieceBytes = (size_t)32 << 20;   // of input per piece
@@ -587,6 +598,7 @@ static int imdct_host(nyq_ctx *ctx, int shift, const float *in, const float *car
     const size_t npieces = (nchains + per - 1) / per;
     rc = need_copy_streams(ctx, 2 * npieces + 1);
     if (rc != NYQ_OK) return rc;
+    DrainOnExit drain{ctx};
     // the copy streams start after whatever the caller queued on the compute stream before this call
     hipEvent_t ev0 = ctx->ev_pool[2 * npieces];
     NYQ_HIP(ctx, hipEventRecord(ev0, ctx->stream));
@@ -707,6 +719,7 @@ extern "C" int nyq_celt_frames_to_pcm(nyq_ctx *ctx, int LM, const float *freq, c
     const size_t npieces = (nstreams + per - 1) / per;
     rc = need_copy_streams(ctx, 2 * npieces + 1);
     if (rc != NYQ_OK) return rc;
+    DrainOnExit drain{ctx};
     hipEvent_t ev0 = ctx->ev_pool[2 * npieces];
     NYQ_HIP(ctx, hipEventRecord(ev0, ctx->stream));
     NYQ_HIP(ctx, hipStreamWaitEvent(ctx->s_h2d, ev0, 0));
