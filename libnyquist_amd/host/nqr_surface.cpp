@@ -2,6 +2,8 @@
 // src/OpusDecoder.cpp:39-183), backed by the batched MI355X decode path.
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <iostream>
 
 #include "batch_decoder.hpp"
@@ -71,21 +73,64 @@ void nqr::OpusDecoder::LoadFromPath(AudioData *data, const std::string &path) {
     LoadFromBuffer(data, fileBuffer.buffer);
 }
 
+// Decoders (two GPU contexts and the page-locked staging memory each) are kept between calls: a lease takes
+// an idle one of the device or makes one, and hands it back afterwards.  Concurrent Loads from several
+// threads therefore each work on their own decoder; at most two idle ones are kept per device.  The pool is
+// never destroyed (no HIP call from a static destructor after the runtime has shut down).
+namespace {
+struct DecoderPool {
+    std::mutex mu;
+    std::map<int, std::vector<nyq_host::BatchOpusDecoder *>> idle;
+};
+DecoderPool &decoderPool() {
+    static DecoderPool *p = new DecoderPool;
+    return *p;
+}
+struct DecoderLease {
+    int device;
+    nyq_host::BatchOpusDecoder *dec = nullptr;
+    explicit DecoderLease(int d) : device(d) {
+        {
+            std::lock_guard<std::mutex> lk(decoderPool().mu);
+            auto &v = decoderPool().idle[d];
+            if (!v.empty()) {
+                dec = v.back();
+                v.pop_back();
+            }
+        }
+        if (!dec) dec = new nyq_host::BatchOpusDecoder(d);
+    }
+    ~DecoderLease() {
+        {
+            std::lock_guard<std::mutex> lk(decoderPool().mu);
+            auto &v = decoderPool().idle[device];
+            if (v.size() < 2) {
+                v.push_back(dec);
+                dec = nullptr;
+            }
+        }
+        delete dec;
+    }
+    DecoderLease(const DecoderLease &) = delete;
+    DecoderLease &operator=(const DecoderLease &) = delete;
+};
+}  // namespace
+
 void nqr::OpusDecoder::LoadFromBuffer(AudioData *data, const std::vector<uint8_t> &memory) {
-    nyq_host::BatchOpusDecoder dec(deviceFromEnv());
+    DecoderLease lease(deviceFromEnv());
     std::vector<nyq_host::DecodedStream> out;
-    dec.decode({&memory}, out, nullptr, 1);
+    lease.dec->decode({&memory}, out, nullptr, 1);
     fill(data, out[0]);
 }
 
 std::vector<std::string> nqr::OpusDecoder::GetSupportedFileExtensions() { return {"opus"}; }
 
 void nqr::BatchLoad(std::vector<AudioData> &out, const std::vector<std::vector<uint8_t>> &buffers, int device) {
-    nyq_host::BatchOpusDecoder dec(device);
+    DecoderLease lease(device);
     std::vector<const std::vector<uint8_t> *> files;
     for (const auto &b : buffers) files.push_back(&b);
     std::vector<nyq_host::DecodedStream> dec_out;
-    dec.decode(files, dec_out);
+    lease.dec->decode(files, dec_out);
     out.resize(buffers.size());
     for (size_t i = 0; i < buffers.size(); i++) fill(&out[i], dec_out[i]);
 }
