@@ -31,9 +31,13 @@ namespace nyq {
 //   WPB       waves per workgroup (each wave is autonomous; WPB only sets the LDS granule)
 //   PREFETCH  issue the next group's global loads right after pre-rotation of the current one
 //   NT        bit 0: non-temporal loads, bit 1: non-temporal stores
-template <int WPB_, bool PREFETCH_, int NT_, bool CHUNKED_ = false>
+template <int WPB_, bool PREFETCH_, int NT_, int MAP_ = 0>
 struct KCfg {
-    static constexpr bool CHUNKED = CHUNKED_;   // contiguous run of groups per wave instead of grid-stride
+    // which groups a wave takes: 0 grid-stride over all waves (neighbouring groups on neighbouring XCDs),
+    // 1 one contiguous run per wave, 2 one contiguous eighth of the batch per XCD (workgroups are dealt
+    // round-robin to the 8 XCDs), grid-stride inside it.  Measured with tools/kbench: see DESIGN.md 4.1.
+    static constexpr int MAP = MAP_;
+    static constexpr bool CHUNKED = MAP_ == 1;
     static constexpr int WPB = WPB_;
     static constexpr bool PREFETCH = PREFETCH_;
     static constexpr int NT_LD = NT_ & 1;
@@ -114,9 +118,17 @@ __global__ __launch_bounds__(kWave *Cfg::WPB) void imdct_rows_kernel(
     const long wid = (long)blockIdx.x * Cfg::WPB + wv;
     // grid-stride: wave w takes groups w, w+W, ...; chunked: wave w takes one contiguous run
     const long per = (ngroups_all + nwaves_all - 1) / nwaves_all;
-    const long nwaves = Cfg::CHUNKED ? 1 : nwaves_all;
+    long nwaves = Cfg::CHUNKED ? 1 : nwaves_all;
     long gi = Cfg::CHUNKED ? wid * per : wid;
-    const long ngroups = Cfg::CHUNKED ? (gi + per < ngroups_all ? gi + per : ngroups_all) : ngroups_all;
+    long ngroups = Cfg::CHUNKED ? (gi + per < ngroups_all ? gi + per : ngroups_all) : ngroups_all;
+    if constexpr (Cfg::MAP == 2) {
+        const long xcd = blockIdx.x & 7, bx = blockIdx.x >> 3;
+        const long blocks_here = ((long)gridDim.x + 7 - xcd) / 8;
+        const long per_x = (ngroups_all + 7) / 8;
+        gi = xcd * per_x + bx * Cfg::WPB + wv;
+        nwaves = blocks_here * Cfg::WPB;
+        ngroups = (xcd + 1) * per_x < ngroups_all ? (xcd + 1) * per_x : ngroups_all;
+    }
     StageRegs<N2R> R;
     if constexpr (Cfg::PREFETCH) {
         // Software pipeline over this wave's groups: the float4 loads of group g+1 are issued
