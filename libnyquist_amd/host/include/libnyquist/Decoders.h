@@ -1,70 +1,76 @@
-// libnyquist/Decoders.h -- the decoder plugin surface (reference: include/libnyquist/Decoders.h:37-91).
+// libnyquist/Decoders.h -- the decoder plugin surface of the MI355X build.
 //
-// BaseDecoder, NyquistIO and OpusDecoder keep the reference's signatures and exception types.  What
-// differs is behind OpusDecoder: packets are entropy-decoded on the CPU into freq[] for the WHOLE
-// file (nyq_host::CeltDecoder), then the inverse MDCT, post-filter and de-emphasis of every frame run
-// as batches on the MI355X through libnyq_imdct.so -- the two-pass frame loop that replaces
-// src/OpusDecoder.cpp:95-122.  nqr::BatchLoad() decodes many files in one GPU batch.
-#ifndef AUDIO_DECODER_H
-#define AUDIO_DECODER_H
+// A program written against dafx/libnyquist includes this header under the same name and keeps compiling:
+// the public names, signatures and exception types are the reference's (include/libnyquist/Decoders.h:37-91).
+// Everything else -- layout, private members, how decoders are registered -- is this build's own.  Behind
+// nqr::OpusDecoder the packets of the WHOLE file are entropy-decoded on the CPU (nyq_host::CeltDecoder) and
+// the inverse MDCT, post-filter and de-emphasis of all frames run as batches on the GPU (libnyq_imdct.so):
+// the frame loop that replaces src/OpusDecoder.cpp:95-122.  nqr::BatchLoad() is new.
+#pragma once
 
-#include "Common.h"
-#include <utility>
 #include <map>
 #include <memory>
-#include <exception>
 #include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
 
-namespace nqr
-{
-    struct BaseDecoder
-    {
-        virtual void LoadFromPath(nqr::AudioData * data, const std::string & path) = 0;
-        virtual void LoadFromBuffer(nqr::AudioData * data, const std::vector<uint8_t> & memory) = 0;
-        virtual std::vector<std::string> GetSupportedFileExtensions() = 0;
-        virtual ~BaseDecoder() {}
-    };
+#include "Common.h"
 
-    typedef std::pair< std::string, std::shared_ptr<nqr::BaseDecoder> > DecoderPair;
+namespace nqr {
 
-    class NyquistIO
-    {
-        std::string ParsePathForExtension(const std::string & path) const;
-        std::shared_ptr<nqr::BaseDecoder> GetDecoderForExtension(const std::string & ext);
-        void BuildDecoderTable();
-        void AddDecoderToTable(std::shared_ptr<nqr::BaseDecoder> decoder);
-        std::map< std::string, std::shared_ptr<BaseDecoder> > decoderTable;
+// ---- what the loaders throw ------------------------------------------------------------------------
+struct UnsupportedExtensionEx : public std::runtime_error {
+    UnsupportedExtensionEx() : std::runtime_error("Unsupported file extension") {}
+};
+struct LoadPathNotImplEx : public std::runtime_error {
+    LoadPathNotImplEx() : std::runtime_error("Loading from path not implemented") {}
+};
+struct LoadBufferNotImplEx : public std::runtime_error {
+    LoadBufferNotImplEx() : std::runtime_error("Loading from buffer not implemented") {}
+};
 
-        NO_MOVE(NyquistIO);
+// ---- one decoder per container / codec ---------------------------------------------------------------
+struct BaseDecoder {
+    virtual ~BaseDecoder() = default;
+    virtual std::vector<std::string> GetSupportedFileExtensions() = 0;
+    virtual void LoadFromPath(AudioData *data, const std::string &path) = 0;
+    virtual void LoadFromBuffer(AudioData *data, const std::vector<uint8_t> &memory) = 0;
+};
 
-    public:
+using DecoderPair = std::pair<std::string, std::shared_ptr<BaseDecoder>>;
 
-        NyquistIO();
-        ~NyquistIO();
-        void Load(AudioData * data, const std::string & path);
-        void Load(AudioData * data, const std::vector<uint8_t> & buffer);
-        void Load(AudioData * data, const std::string & extension, const std::vector<uint8_t> & buffer);
-        bool IsFileSupported(const std::string & path) const;
-    };
+// Ogg Opus (CELT-only packets; mono, stereo and multistream files): CPU entropy stage + GPU synthesis
+struct OpusDecoder final : public BaseDecoder {
+    std::vector<std::string> GetSupportedFileExtensions() override;
+    void LoadFromPath(AudioData *data, const std::string &path) override;
+    void LoadFromBuffer(AudioData *data, const std::vector<uint8_t> &memory) override;
+};
 
-    struct UnsupportedExtensionEx : public std::runtime_error { UnsupportedExtensionEx() : std::runtime_error("Unsupported file extension") {} };
-    struct LoadPathNotImplEx : public std::runtime_error { LoadPathNotImplEx() : std::runtime_error("Loading from path not implemented") {} };
-    struct LoadBufferNotImplEx : public std::runtime_error { LoadBufferNotImplEx() : std::runtime_error("Loading from buffer not implemented") {} };
+// ---- the front door ------------------------------------------------------------------------------
+class NyquistIO {
+public:
+    NyquistIO();
+    ~NyquistIO();
+    NyquistIO(const NyquistIO &) = delete;
+    NyquistIO &operator=(const NyquistIO &) = delete;
 
-    struct OpusDecoder final : public nqr::BaseDecoder
-    {
-        OpusDecoder() = default;
-        virtual ~OpusDecoder() override {}
-        virtual void LoadFromPath(nqr::AudioData * data, const std::string & path) override final;
-        virtual void LoadFromBuffer(nqr::AudioData * data, const std::vector<uint8_t> & memory) override final;
-        virtual std::vector<std::string> GetSupportedFileExtensions() override final;
-    };
+    bool IsFileSupported(const std::string &path) const;
+    void Load(AudioData *data, const std::string &path);                         // by file name extension
+    void Load(AudioData *data, const std::vector<uint8_t> &buffer);              // by content sniffing
+    void Load(AudioData *data, const std::string &extension, const std::vector<uint8_t> &buffer);
 
-    // Not in the reference: decode many Ogg Opus files as ONE GPU batch (one entropy-decoding thread per
-    // host core, then a single nyq_celt_frames_to_pcm call per group of equally shaped streams).
-    // out[i] is filled exactly as NyquistIO::Load would fill it for buffers[i].
-    void BatchLoad(std::vector<AudioData> & out, const std::vector< std::vector<uint8_t> > & buffers, int device = 0);
+private:
+    static std::string extensionOf(const std::string &path);
+    void registerDecoder(const std::shared_ptr<BaseDecoder> &decoder);
+    std::shared_ptr<BaseDecoder> decoderFor(const std::string &extension) const;   // null if none
 
-} // end namespace nqr
+    std::map<std::string, std::shared_ptr<BaseDecoder>> byExtension_;
+};
 
-#endif
+// Not in the reference: many Ogg Opus files decoded as ONE batch -- one entropy-decoding thread per host core
+// feeding GPU pieces as they complete.  out[i] is filled exactly as NyquistIO::Load would fill it for
+// buffers[i]; a file that fails makes the call throw after the others have been decoded.
+void BatchLoad(std::vector<AudioData> &out, const std::vector<std::vector<uint8_t>> &buffers, int device = 0);
+
+}  // namespace nqr

@@ -135,13 +135,29 @@ void nqr::BatchLoad(std::vector<AudioData> &out, const std::vector<std::vector<u
     for (size_t i = 0; i < buffers.size(); i++) fill(&out[i], dec_out[i]);
 }
 
-NyquistIO::NyquistIO() { BuildDecoderTable(); }
+NyquistIO::NyquistIO() { registerDecoder(std::make_shared<OpusDecoder>()); }
 NyquistIO::~NyquistIO() {}
 
+std::string NyquistIO::extensionOf(const std::string &path) {
+    const size_t dot = path.rfind('.');
+    return dot == std::string::npos ? std::string() : path.substr(dot + 1);
+}
+
+void NyquistIO::registerDecoder(const std::shared_ptr<BaseDecoder> &decoder) {
+    for (const std::string &ext : decoder->GetSupportedFileExtensions())
+        if (!byExtension_.emplace(ext, decoder).second) throw std::runtime_error("decoder already exists for extension");
+}
+
+std::shared_ptr<BaseDecoder> NyquistIO::decoderFor(const std::string &extension) const {
+    const auto it = byExtension_.find(extension);
+    return it == byExtension_.end() ? nullptr : it->second;
+}
+
+bool NyquistIO::IsFileSupported(const std::string &path) const { return decoderFor(extensionOf(path)) != nullptr; }
+
 void NyquistIO::Load(AudioData *data, const std::string &path) {
-    if (!IsFileSupported(path)) throw UnsupportedExtensionEx();
-    if (!decoderTable.size()) throw std::runtime_error("No available decoders.");
-    auto decoder = GetDecoderForExtension(ParsePathForExtension(path));
+    const auto decoder = decoderFor(extensionOf(path));
+    if (!decoder) throw UnsupportedExtensionEx();           // src/Common.cpp:49
     try {
         decoder->LoadFromPath(data, path);
     } catch (const std::exception &e) {
@@ -161,8 +177,8 @@ void NyquistIO::Load(AudioData *data, const std::vector<uint8_t> &buffer) {
 }
 
 void NyquistIO::Load(AudioData *data, const std::string &extension, const std::vector<uint8_t> &buffer) {
-    if (decoderTable.find(extension) == decoderTable.end()) throw UnsupportedExtensionEx();
-    auto decoder = GetDecoderForExtension(extension);
+    const auto decoder = decoderFor(extension);
+    if (!decoder) throw UnsupportedExtensionEx();
     try {
         decoder->LoadFromBuffer(data, buffer);
     } catch (const std::exception &e) {
@@ -170,26 +186,3 @@ void NyquistIO::Load(AudioData *data, const std::string &extension, const std::v
         throw;
     }
 }
-
-bool NyquistIO::IsFileSupported(const std::string &path) const {
-    return decoderTable.find(ParsePathForExtension(path)) != decoderTable.end();
-}
-
-std::string NyquistIO::ParsePathForExtension(const std::string &path) const {
-    const size_t dot = path.find_last_of(".");
-    return dot != std::string::npos ? path.substr(dot + 1) : std::string("");
-}
-
-std::shared_ptr<BaseDecoder> NyquistIO::GetDecoderForExtension(const std::string &ext) {
-    if (!decoderTable.size()) throw std::runtime_error("No available decoders.");
-    return decoderTable[ext];
-}
-
-void NyquistIO::AddDecoderToTable(std::shared_ptr<nqr::BaseDecoder> decoder) {
-    for (const auto &ext : decoder->GetSupportedFileExtensions()) {
-        if (decoderTable.count(ext) >= 1) throw std::runtime_error("decoder already exists for extension");
-        decoderTable.insert(DecoderPair(ext, decoder));
-    }
-}
-
-void NyquistIO::BuildDecoderTable() { AddDecoderToTable(std::make_shared<OpusDecoder>()); }
