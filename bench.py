@@ -380,7 +380,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "nfft480_imdct_per_sec",
+            "metric": "N=480 IMDCTs/sec (batched)",
             "value": value,
             "unit": "IMDCT/s",
             "n_gpus": world,
