@@ -18,6 +18,13 @@ Rank 0 prints ONE JSON line; see README/DESIGN.md for the fields.  `roofline.ach
 stream); `cpu_baseline` = the reference's own clt_mdct_backward (oracle/_ref, kind
 "reference") or this repo's C restatement (kind "port") timed on this host's cores over a
 bounded sample of the same rows.
+
+Secondary keys on the same line (rank 0; the last two at N = 1 only, never part of `value`):
+  opus_frame_synthesis  nyq_celt_synth_dev + nyq_celt_post_dev on 1024 streams x 256 stereo frames
+  host_boundary         nyq_imdct_batch on pinned HOST buffers (PCIe both ways) and the per-call latency of
+                        the reference's own offload interface (processMDCTCuda)
+  opus_file_decode      256 Ogg Opus files through the plugin surface next to the reference's NyquistIO::Load
+                        on the same host threads (that leg's cpu_baseline)
 """
 import argparse
 import ctypes
