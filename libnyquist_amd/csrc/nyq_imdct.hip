@@ -46,7 +46,7 @@ struct nyq_ctx {
     int res_ifft[4] = {0, 0, 0, 0};
     int res_synth_long[4] = {0, 0, 0, 0};
     int res_synth_short = 0;
-    int res_post[4] = {0, 0, 0, 0};
+    int res_post[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
     int res_vorbis[12] = {0};
     float *d_vtab = nullptr;             // Vorbis rotation + twiddle tables of every block size, one allocation
     size_t vrot_off[12] = {0}, vtw_off[12] = {0};   // float offsets by log2(n/4)
@@ -384,21 +384,23 @@ extern "C" int nyq_imdct_chain_dev(nyq_ctx *ctx, int shift, const float *d_in, c
 }
 
 // ---- post-filter + de-emphasis + interleave ---------------------------------------------
-constexpr int kPostWavesPerBlock = 4;
-
-template <int LM>
+template <int LM, int NC>
 static int launch_post(nyq_ctx *ctx, const PostArgs &A) {
-    const size_t nsc = (size_t)A.nstreams * (size_t)A.channels;
-    if (ctx->res_post[LM] == 0) {
+    // 12 KB of LDS per channel a wave owns: two waves per block when a wave owns two channels, so that three
+    // blocks (six waves) fit a CU either way
+    constexpr int kPostWavesPerBlock = NC == 2 ? 2 : 4;
+    const size_t nunits = (size_t)A.nstreams * (size_t)(A.channels / NC);
+    int &res = ctx->res_post[LM][NC - 1];
+    if (res == 0) {
         int per_cu = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, celt_post_kernel<LM, kPostWavesPerBlock>,
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, celt_post_kernel<LM, kPostWavesPerBlock, NC>,
                                                                     kWave * kPostWavesPerBlock, 0);
         if (e != hipSuccess || per_cu < 1) per_cu = 1;
-        ctx->res_post[LM] = per_cu * ctx->cus;
+        res = per_cu * ctx->cus;
     }
-    const size_t need = (nsc + kPostWavesPerBlock - 1) / kPostWavesPerBlock;
-    const unsigned grid = (unsigned)(need < (size_t)ctx->res_post[LM] ? need : (size_t)ctx->res_post[LM]);
-    hipLaunchKernelGGL((celt_post_kernel<LM, kPostWavesPerBlock>), dim3(grid), dim3(kWave * kPostWavesPerBlock), 0,
+    const size_t need = (nunits + kPostWavesPerBlock - 1) / kPostWavesPerBlock;
+    const unsigned grid = (unsigned)(need < (size_t)res ? need : (size_t)res);
+    hipLaunchKernelGGL((celt_post_kernel<LM, kPostWavesPerBlock, NC>), dim3(grid), dim3(kWave * kPostWavesPerBlock), 0,
                        ctx->stream, A, ctx->d_window);
     NYQ_HIP(ctx, hipGetLastError());
     return NYQ_OK;
@@ -431,11 +433,25 @@ extern "C" int nyq_celt_post_dev(nyq_ctx *ctx, int LM, const float *d_pcm, const
     A.channels = channels;
     if (((uintptr_t)d_pcm | (uintptr_t)d_out) & 15)
         return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_post_dev: pcm and out must be 16-byte aligned");
+    // a stereo stream is one wave's work (both channels in lock step); any other channel count: one wave per channel
+    // One wave per (stream, channel) is the default also for stereo: real streams keep the post-filter on in
+    // 60-80 % of the frames with short periods, and there the comb recursion is bound by instruction issue, which
+    // more waves hide better.  NYQ_POST_STEREO_PAIRS=1 lets one wave own both channels of a stereo
+    // stream instead (full 16-byte interleaved stores: faster when hardly any frame is filtered).
+    const char *pairs = std::getenv("NYQ_POST_STEREO_PAIRS");
+    if (channels == 2 && pairs && pairs[0] == '1') {
+        switch (LM) {
+            case 0: return launch_post<0, 2>(ctx, A);
+            case 1: return launch_post<1, 2>(ctx, A);
+            case 2: return launch_post<2, 2>(ctx, A);
+            default: return launch_post<3, 2>(ctx, A);
+        }
+    }
     switch (LM) {
-        case 0: return launch_post<0>(ctx, A);
-        case 1: return launch_post<1>(ctx, A);
-        case 2: return launch_post<2>(ctx, A);
-        default: return launch_post<3>(ctx, A);
+        case 0: return launch_post<0, 1>(ctx, A);
+        case 1: return launch_post<1, 1>(ctx, A);
+        case 2: return launch_post<2, 1>(ctx, A);
+        default: return launch_post<3, 1>(ctx, A);
     }
 }
 

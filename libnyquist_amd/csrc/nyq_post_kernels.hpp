@@ -5,8 +5,11 @@
 // downsample 1), writing the interleaved [-1,1) float layout of nqr::AudioData::samples
 // (include/libnyquist/Common.h:350-364).
 //
-// Both filters are recursive along time, so one wavefront owns one (stream, channel) and walks its
-// frames in order; parallelism inside the wave comes from the filters' structure:
+// Both filters are recursive along time, so one wavefront owns one (stream, channel) -- or, for stereo, BOTH
+// channels of a stream, whose filters share every parameter and therefore run in lock step: each step then
+// carries two independent dependency chains (twice the work per LDS round trip) and the interleaved output
+// leaves in full 16-byte stores -- and walks its frames in order; parallelism inside the wave comes from the
+// filters' structure:
 //   * comb filter: y[i] depends on y[i-T-2 .. i-T+2] with T >= 15 (COMBFILTER_MINPERIOD), so T-2
 //     consecutive outputs are independent.  A wave step produces up to 256 of them, four adjacent
 //     outputs per lane (their 8 taps come from three aligned 16-byte LDS reads), out of a 2048-sample
@@ -77,23 +80,83 @@ __device__ __forceinline__ void pick8(const f4 &q0, const f4 &q1, const f4 &q2, 
     for (int i = 0; i < 8; i++) x[i] = e[A + i];
 }
 
-// x[0..8) = ring[r .. r+8) (mod 2048) for an arbitrary r whose alignment r & 3 is the same in every lane
-__device__ __forceinline__ void taps8(const float *ring, int r, float (&x)[8]) {
+// x[c][0..8) = ring_c[r .. r+8) (mod 2048) for an arbitrary r whose alignment r & 3 is the same in every lane
+// (and in every channel: the channels of a stream share the pitch period)
+template <int NC>
+__device__ __forceinline__ void taps8(const float *ring, int r, float (&x)[NC][8]) {
     const int a = __builtin_amdgcn_readfirstlane(r) & 3;
     const int rb = r - a;
-    const f4 q0 = lds4(ring, rb & (kPostRing - 1));
-    const f4 q1 = lds4(ring, (rb + 4) & (kPostRing - 1));
-    const f4 q2 = lds4(ring, (rb + 8) & (kPostRing - 1));
+    f4 q0[NC], q1[NC], q2[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const float *rc = ring + c * kPostRing;
+        q0[c] = lds4(rc, rb & (kPostRing - 1));
+        q1[c] = lds4(rc, (rb + 4) & (kPostRing - 1));
+        q2[c] = lds4(rc, (rb + 8) & (kPostRing - 1));
+    }
     switch (a) {
-        case 0: pick8<0>(q0, q1, q2, x); break;
-        case 1: pick8<1>(q0, q1, q2, x); break;
-        case 2: pick8<2>(q0, q1, q2, x); break;
-        default: pick8<3>(q0, q1, q2, x); break;
+        case 0:
+#pragma unroll
+            for (int c = 0; c < NC; c++) pick8<0>(q0[c], q1[c], q2[c], x[c]);
+            break;
+        case 1:
+#pragma unroll
+            for (int c = 0; c < NC; c++) pick8<1>(q0[c], q1[c], q2[c], x[c]);
+            break;
+        case 2:
+#pragma unroll
+            for (int c = 0; c < NC; c++) pick8<2>(q0[c], q1[c], q2[c], x[c]);
+            break;
+        default:
+#pragma unroll
+            for (int c = 0; c < NC; c++) pick8<3>(q0[c], q1[c], q2[c], x[c]);
+            break;
+    }
+}
+
+// The constant part of a comb_filter() call for one tap alignment AL: outputs [kOverlap, n) of the rings, w1 per
+// step (four adjacent ones per lane, lanes 0 .. w1/4-1), taps from three aligned 16-byte reads per channel.
+template <int NC, int AL>
+__device__ __forceinline__ void comb_const_loop(float *ring, int lane, int r0, int n, int T1, float g10, float g11,
+                                                float g12, int w1) {
+    const int o = 4 * lane;
+    int idx = (r0 + kOverlap + o) & (kPostRing - 1);           // this lane's outputs of the current step
+    int rb = (idx - T1 - 2 - AL) & (kPostRing - 1);            // aligned start of their taps
+    for (int base = kOverlap; base < n; base += w1) {
+        if (o < w1 && base + o < n) {
+            f4 cen[NC], q0[NC], q1[NC], q2[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const float *rc = ring + c * kPostRing;
+                q0[c] = lds4(rc, rb);
+                q1[c] = lds4(rc, (rb + 4) & (kPostRing - 1));
+                q2[c] = lds4(rc, (rb + 8) & (kPostRing - 1));
+                cen[c] = lds4(rc, idx);
+            }
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                float x[8];
+                pick8<AL>(q0[c], q1[c], q2[c], x);
+                float y[4] = {cen[c].x, cen[c].y, cen[c].z, cen[c].w};
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    y[u] += g10 * x[u + 2];
+                    y[u] += g11 * (x[u + 3] + x[u + 1]);
+                    y[u] += g12 * (x[u + 4] + x[u]);
+                }
+                sts4(ring + c * kPostRing, idx, f4{y[0], y[1], y[2], y[3]});
+            }
+        }
+        idx = (idx + w1) & (kPostRing - 1);
+        rb = (rb + w1) & (kPostRing - 1);
+        NYQ_POST_SYNC();
     }
 }
 
 // One comb_filter() call (celt.c:114-172) on the n ring samples that start at ring index r0 (a multiple
-// of 4): cross-fade from (T0,g0,tapset0) to (T1,g1,tapset1) over the first 120 samples, constant after.
+// of 4) of each of the NC channel rings (kPostRing floats apart): cross-fade from (T0,g0,tapset0) to
+// (T1,g1,tapset1) over the first 120 samples, constant after.
+template <int NC>
 __device__ __forceinline__ void comb_call(float *ring, int lane, int r0, int n, int T0, int T1, float g0, float g1,
                                           int ts0, int ts1, const float *win2) {
     if (g0 == 0.f && g1 == 0.f) return;                       // celt.c:126-132 (in place: nothing to do)
@@ -107,78 +170,144 @@ __device__ __forceinline__ void comb_call(float *ring, int lane, int r0, int n, 
     int tmin = 4 * kWave + 2;
     if (g0 != 0.f && T0 < tmin) tmin = T0;
     if (g1 != 0.f && T1 < tmin) tmin = T1;
-    const int w = (tmin - 2) & ~3;                             // T >= 15: w >= 12
+    if (tmin - 2 <= kWave) {
+        // short periods: one output per lane, scalar tap reads, no alignment cases
+        const int w = tmin - 2;                                // T >= 15: w >= 13
+        for (int base = 0; base < kOverlap; base += w) {
+            const int i = base + lane;
+            if (lane < w && i < kOverlap) {
+                const int idx = (r0 + i) & (kPostRing - 1);
+                const float f = win2[i], nf = 1.0f - f;
+                const int t0i = idx - T0 - 2, t1i = idx - T1 - 2;
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    float *rc = ring + c * kPostRing;
+                    float y = rc[idx];
+                    if (g0 != 0.f) {
+                        const float x0 = rc[t0i & (kPostRing - 1)], x1 = rc[(t0i + 1) & (kPostRing - 1)],
+                                    x2 = rc[(t0i + 2) & (kPostRing - 1)], x3 = rc[(t0i + 3) & (kPostRing - 1)],
+                                    x4 = rc[(t0i + 4) & (kPostRing - 1)];
+                        y += (nf * g00) * x2;
+                        y += (nf * g01) * (x3 + x1);
+                        y += (nf * g02) * (x4 + x0);
+                    }
+                    if (g1 != 0.f) {
+                        const float x0 = rc[t1i & (kPostRing - 1)], x1 = rc[(t1i + 1) & (kPostRing - 1)],
+                                    x2 = rc[(t1i + 2) & (kPostRing - 1)], x3 = rc[(t1i + 3) & (kPostRing - 1)],
+                                    x4 = rc[(t1i + 4) & (kPostRing - 1)];
+                        y += (f * g10) * x2;
+                        y += (f * g11) * (x3 + x1);
+                        y += (f * g12) * (x4 + x0);
+                    }
+                    rc[idx] = y;
+                }
+            }
+            NYQ_POST_SYNC();
+        }
+    } else {
+    const int w = (tmin - 2) & ~3;
     for (int base = 0; base < kOverlap; base += w) {
         if (o < w && base + o < kOverlap) {
             const int idx = (r0 + base + o) & (kPostRing - 1);
-            const f4 cen = lds4(ring, idx);
             const f4 fw = lds4(win2, base + o);
-            float y[4] = {cen.x, cen.y, cen.z, cen.w};
             const float f[4] = {fw.x, fw.y, fw.z, fw.w};
-            if (g0 != 0.f) {
-                float x[8];
-                taps8(ring, idx - T0 - 2, x);
+            float y[NC][4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const float nf = 1.0f - f[u];
-                    y[u] += (nf * g00) * x[u + 2];
-                    y[u] += (nf * g01) * (x[u + 3] + x[u + 1]);
-                    y[u] += (nf * g02) * (x[u + 4] + x[u]);
-                }
+            for (int c = 0; c < NC; c++) {
+                const f4 cen = lds4(ring + c * kPostRing, idx);
+                y[c][0] = cen.x; y[c][1] = cen.y; y[c][2] = cen.z; y[c][3] = cen.w;
+            }
+            if (g0 != 0.f) {
+                float x[NC][8];
+                taps8<NC>(ring, idx - T0 - 2, x);
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const float nf = 1.0f - f[u];
+                        y[c][u] += (nf * g00) * x[c][u + 2];
+                        y[c][u] += (nf * g01) * (x[c][u + 3] + x[c][u + 1]);
+                        y[c][u] += (nf * g02) * (x[c][u + 4] + x[c][u]);
+                    }
             }
             if (g1 != 0.f) {
-                float x[8];
-                taps8(ring, idx - T1 - 2, x);
+                float x[NC][8];
+                taps8<NC>(ring, idx - T1 - 2, x);
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    y[u] += (f[u] * g10) * x[u + 2];
-                    y[u] += (f[u] * g11) * (x[u + 3] + x[u + 1]);
-                    y[u] += (f[u] * g12) * (x[u + 4] + x[u]);
-                }
+                for (int c = 0; c < NC; c++)
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        y[c][u] += (f[u] * g10) * x[c][u + 2];
+                        y[c][u] += (f[u] * g11) * (x[c][u + 3] + x[c][u + 1]);
+                        y[c][u] += (f[u] * g12) * (x[c][u + 4] + x[c][u]);
+                    }
             }
-            sts4(ring, idx, f4{y[0], y[1], y[2], y[3]});
+#pragma unroll
+            for (int c = 0; c < NC; c++) sts4(ring + c * kPostRing, idx, f4{y[c][0], y[c][1], y[c][2], y[c][3]});
         }
         NYQ_POST_SYNC();
     }
+    }
     if (g1 == 0.f) return;                                    // celt.c:163-169
-    const int w1 = (T1 - 2 < 4 * kWave ? T1 - 2 : 4 * kWave) & ~3;
-    for (int base = kOverlap; base < n; base += w1) {          // comb_filter_const, celt.c:87-110
-        if (o < w1 && base + o < n) {
-            const int idx = (r0 + base + o) & (kPostRing - 1);
-            const f4 cen = lds4(ring, idx);
-            float x[8];
-            taps8(ring, idx - T1 - 2, x);
-            float y[4] = {cen.x, cen.y, cen.z, cen.w};
+    // comb_filter_const (celt.c:87-110): the tap alignment (r0 + base + 4 lane - T1 - 2) & 3 is the same for every
+    // step (base and the step width are multiples of 4), so it selects one of four branch-free loops
+    if (T1 - 2 <= kWave) {
+        // short periods (the common case in real streams): T1-2 <= 64 outputs per step anyway, so one output
+        // per lane with five scalar tap reads is the leaner step
+        const int w = T1 - 2;
+        int idx = (r0 + kOverlap + lane) & (kPostRing - 1);
+        int tp = (idx - T1 - 2) & (kPostRing - 1);
+        for (int base = kOverlap; base < n; base += w) {
+            if (lane < w && base + lane < n) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                y[u] += g10 * x[u + 2];
-                y[u] += g11 * (x[u + 3] + x[u + 1]);
-                y[u] += g12 * (x[u + 4] + x[u]);
+                for (int c = 0; c < NC; c++) {
+                    float *rc = ring + c * kPostRing;
+                    const float x0 = rc[tp], x1 = rc[(tp + 1) & (kPostRing - 1)], x2 = rc[(tp + 2) & (kPostRing - 1)],
+                                x3 = rc[(tp + 3) & (kPostRing - 1)], x4 = rc[(tp + 4) & (kPostRing - 1)];
+                    float y = rc[idx];
+                    y += g10 * x2;
+                    y += g11 * (x3 + x1);
+                    y += g12 * (x4 + x0);
+                    rc[idx] = y;
+                }
             }
-            sts4(ring, idx, f4{y[0], y[1], y[2], y[3]});
+            idx = (idx + w) & (kPostRing - 1);
+            tp = (tp + w) & (kPostRing - 1);
+            NYQ_POST_SYNC();
         }
-        NYQ_POST_SYNC();
+        return;
+    }
+    const int w1 = (T1 - 2 < 4 * kWave ? T1 - 2 : 4 * kWave) & ~3;
+    switch ((r0 - T1 - 2) & 3) {
+        case 0: comb_const_loop<NC, 0>(ring, lane, r0, n, T1, g10, g11, g12, w1); break;
+        case 1: comb_const_loop<NC, 1>(ring, lane, r0, n, T1, g10, g11, g12, w1); break;
+        case 2: comb_const_loop<NC, 2>(ring, lane, r0, n, T1, g10, g11, g12, w1); break;
+        default: comb_const_loop<NC, 3>(ring, lane, r0, n, T1, g10, g11, g12, w1); break;
     }
 }
 
-template <int LM, int WPB>
+// NC = channels a wave owns: 2 for stereo streams (A.channels == 2), 1 otherwise (one wave per (stream, channel)).
+template <int LM, int WPB, int NC>
 __global__ __launch_bounds__(kWave *WPB) void celt_post_kernel(PostArgs A, const float *__restrict__ window) {
     constexpr int N = 120 << LM;                    // samples per frame and channel
-    constexpr int NV = N / 4;                       // float4 per frame
-    constexpr int NLD = (NV + kWave - 1) / kWave;   // float4 loads per lane and frame
-    constexpr int NST = (N + kWave - 1) / kWave;    // scalar stores per lane and frame
+    constexpr int NV = N / 4;                       // float4 per frame and channel
+    constexpr int NLD = (NV + kWave - 1) / kWave;   // float4 loads per lane, frame and channel
+    constexpr int NST = (N + kWave - 1) / kWave;    // scalar stores per lane and frame (NC == 1, interleaved output)
+    constexpr int NV2 = N * NC / 4;                 // float4 of one interleaved stereo frame (NC == 2)
+    constexpr int NLD2 = (NV2 + kWave - 1) / kWave;
     constexpr int CH = (N + kWave - 1) / kWave;     // de-emphasis: consecutive samples per lane (15, 8, 4, 2)
     constexpr int NL = N / CH;                      // lanes that own samples (64, 60, 60, 60)
     static_assert(NL * CH == N, "frame splits evenly over the lanes");
-    constexpr int kSlice = kPostRing + 960;
+    static_assert(NLD <= 4, "prefetch registers");
+    constexpr int kSlice = NC * (kPostRing + 960);
     __shared__ __attribute__((aligned(16))) float rings[WPB * kSlice];
     __shared__ __attribute__((aligned(16))) float win2[kOverlap];   // window^2 of the cross-fade (celt.c:147-158)
     for (int i = threadIdx.x; i < kOverlap; i += kWave * WPB) win2[i] = window[i] * window[i];
     __syncthreads();
     const int lane = threadIdx.x & (kWave - 1);
-    float *ring = rings + (threadIdx.x >> 6) * kSlice;
-    float *stage = ring + kPostRing;                 // de-emphasised frame, staged for coalesced stores
-    const long nsc = A.nstreams * A.channels;
+    float *ring = rings + (threadIdx.x >> 6) * kSlice;   // channel c: ring + c * kPostRing
+    float *stage = ring + NC * kPostRing;                // de-emphasised frame, channel c at stage + c * 960
+    const long nunits = A.nstreams * (A.channels / NC);  // waves' work items: streams (NC 2) or (stream, channel)s
     const long nwaves = (long)gridDim.x * WPB;
 
     // De-emphasis t[j] = a[j] + c t[j-1] over a frame of N = NL * CH samples: lane l < NL runs the recurrence
@@ -198,46 +327,52 @@ __global__ __launch_bounds__(kWave *WPB) void celt_post_kernel(PostArgs A, const
         if (lane & (1 << k)) pw *= cstep[k];
     const float pwEnd = __shfl(pw, NL - 1) * cch;                     // (c^CH)^NL
 
-    const long sc0 = (long)blockIdx.x * WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform
-    for (long sc = sc0; sc < nsc; sc += nwaves) {
-        const long s = sc / A.channels;
-        const int c = (int)(sc - s * A.channels);
+    const long u0 = (long)blockIdx.x * WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform
+    for (long unit = u0; unit < nunits; unit += nwaves) {
+        const long s = NC == 2 ? unit : unit / A.channels;
+        const int c0 = NC == 2 ? 0 : (int)(unit - s * A.channels);
+        const long sc0 = s * A.channels + c0;                  // first (stream, channel) of this wave
         // ring slots [960, 2048) <- filtered history that precedes frame 0 (times -1088 .. -1); time 0 = slot 0
-        for (int j = lane; j < kPostRing; j += kWave) {
-            float v = 0.f;
-            if (j >= kPostRing - kPostHist && A.hist) v = A.hist[sc * kPostHist + (j - (kPostRing - kPostHist))];
-            ring[j] = v;
-        }
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+            for (int j = lane; j < kPostRing; j += kWave) {
+                float v = 0.f;
+                if (j >= kPostRing - kPostHist && A.hist) v = A.hist[(sc0 + c) * kPostHist + (j - (kPostRing - kPostHist))];
+                ring[c * kPostRing + j] = v;
+            }
         int T_old = 0, T_cur = 0, ts_old = 0, ts_cur = 0;
         float g_old = 0.f, g_cur = 0.f;
         if (A.pf_state) {
             const float *ps = A.pf_state + 6 * s;
             T_old = (int)ps[0]; T_cur = (int)ps[1]; g_old = ps[2]; g_cur = ps[3]; ts_old = (int)ps[4]; ts_cur = (int)ps[5];
         }
-        float mem = A.deemph ? A.deemph[sc] : 0.f;
+        float mem[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) mem[c] = A.deemph ? A.deemph[sc0 + c] : 0.f;
         NYQ_POST_SYNC();
-        const vf4 *src = reinterpret_cast<const vf4 *>(A.pcm + sc * A.nframes * N);
+        const vf4 *src = reinterpret_cast<const vf4 *>(A.pcm + sc0 * A.nframes * N);   // channel c: + c * nframes * NV
+        const long cstride = A.nframes * NV;
         const int *ppitch = A.pf_pitch + s * A.nframes;
         const float *pgain = A.pf_gain + s * A.nframes;
         const int *ptap = A.pf_tapset + s * A.nframes;
-        // the prefetched frame lives in named registers (an indexed array here ends up in scratch memory)
-        vf4 nx0 = {0, 0, 0, 0}, nx1 = nx0, nx2 = nx0, nx3 = nx0;
+        // the prefetched frame lives in registers (native vector values: an array of 16-byte structs here ends
+        // up in scratch memory)
+        vf4 nx[NC][4];
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) nx[c][k] = vf4{0, 0, 0, 0};
         int T_nx = 0, ts_nx = 0;
         float g_nx = 0.f;
-#define NYQ_POST_LD(k, reg)                                                                   \
-    if (k < NLD) {                                                                            \
-        const int v = lane + k * kWave;                                                       \
-        reg = fr[v < NV ? v : NV - 1]; /* lanes past the frame re-read its last vector */     \
-    }
-#define NYQ_POST_ST(k, reg)                                                                   \
-    if (k < NLD) {                                                                            \
-        const int v = lane + k * kWave;                                                       \
-        if (v < NV) sts4(ring, (rpos + 4 * v) & (kPostRing - 1), reg);                        \
-    }
 #define NYQ_POST_FETCH(fidx)                                                                  \
     do {                                                                                      \
-        const vf4 *fr = src + (fidx) * NV;                                                    \
-        NYQ_POST_LD(0, nx0) NYQ_POST_LD(1, nx1) NYQ_POST_LD(2, nx2) NYQ_POST_LD(3, nx3)       \
+        _Pragma("unroll") for (int c = 0; c < NC; c++) {                                      \
+            const vf4 *fr = src + c * cstride + (fidx) * NV;                                  \
+            _Pragma("unroll") for (int k = 0; k < NLD; k++) {                                 \
+                const int v = lane + k * kWave;                                               \
+                nx[c][k] = fr[v < NV ? v : NV - 1]; /* lanes past the frame re-read its last vector */ \
+            }                                                                                 \
+        }                                                                                     \
         T_nx = ppitch[fidx];                                                                  \
         g_nx = pgain[fidx];                                                                   \
         ts_nx = ptap[fidx];                                                                   \
@@ -245,7 +380,11 @@ __global__ __launch_bounds__(kWave *WPB) void celt_post_kernel(PostArgs A, const
 #define NYQ_POST_TO_RING(rp)                                                                  \
     do {                                                                                      \
         const int rpos = (rp);                                                                \
-        NYQ_POST_ST(0, nx0) NYQ_POST_ST(1, nx1) NYQ_POST_ST(2, nx2) NYQ_POST_ST(3, nx3)       \
+        _Pragma("unroll") for (int c = 0; c < NC; c++)                                        \
+            _Pragma("unroll") for (int k = 0; k < NLD; k++) {                                 \
+                const int v = lane + k * kWave;                                               \
+                if (v < NV) sts4(ring + c * kPostRing, (rpos + 4 * v) & (kPostRing - 1), nx[c][k]); \
+            }                                                                                 \
     } while (0)
         int T_new = 0, ts_new = 0;
         float g_new = 0.f;
@@ -257,60 +396,75 @@ __global__ __launch_bounds__(kWave *WPB) void celt_post_kernel(PostArgs A, const
         }
         NYQ_POST_SYNC();
         int r0 = 0;                                            // ring index of the frame start
-        float *dst = A.out + (s * A.nframes * N) * A.channels + c;
+        float *dst = A.out + (s * A.nframes * N) * A.channels + c0;
         for (long f = 0; f < A.nframes; f++) {
             if (T_cur < kCombMinPeriod) T_cur = kCombMinPeriod;   // celt_decoder_clean.c:661-662
             if (T_old < kCombMinPeriod) T_old = kCombMinPeriod;
-            comb_call(ring, lane, r0, kOverlap, T_old, T_cur, g_old, g_cur, ts_old, ts_cur, win2);
+            comb_call<NC>(ring, lane, r0, kOverlap, T_old, T_cur, g_old, g_cur, ts_old, ts_cur, win2);
             if (LM != 0)
-                comb_call(ring, lane, r0 + kOverlap, N - kOverlap, T_cur, T_new, g_cur, g_new, ts_cur, ts_new, win2);
+                comb_call<NC>(ring, lane, r0 + kOverlap, N - kOverlap, T_cur, T_new, g_cur, g_new, ts_cur, ts_new, win2);
             // de-emphasis (celt_decoder_clean.c:243-248): tmp = x + m + VERY_SMALL; m = coef0*tmp; y = tmp/32768
             {
                 // all LDS reads first, the recurrence in registers, one write per sample
-                float loc[CH];
+                float loc[NC][CH];
                 const int li = lane < NL ? lane : 0;
                 const int p0 = r0 + li * CH;
-                if constexpr (CH % 4 == 0) {
 #pragma unroll
-                    for (int k = 0; k < CH; k += 4) {
-                        const f4 q = lds4(ring, (p0 + k) & (kPostRing - 1));
-                        loc[k] = q.x; loc[k + 1] = q.y; loc[k + 2] = q.z; loc[k + 3] = q.w;
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < CH; k++) loc[k] = ring[(p0 + k) & (kPostRing - 1)];
-                }
-                float acc = 0.f;
-#pragma unroll
-                for (int k = 0; k < CH; k++) {
-                    acc = (loc[k] + 1e-30f) + kPreemph * acc;
-                    loc[k] = acc;
-                }
-                if (lane >= NL) acc = 0.f;
-                float e = acc;                                    // e[l] = sum_{i<=l} (c^CH)^(l-i) acc[i]
-#pragma unroll
-                for (int k = 0; k < 6; k++) {
-                    const float up = __shfl_up(e, 1 << k);
-                    if (lane >= (1 << k)) e += cstep[k] * up;
-                }
-                // value entering lane l's chunk: c t[l CH - 1] = c e[l-1] + (c^CH)^l mem, with mem = c t[-1]
-                const float prevEnd = __shfl_up(e, 1);
-                float cp = lane == 0 ? mem : kPreemph * prevEnd + pw * mem;
-#pragma unroll
-                for (int k = 0; k < CH; k++) {
-                    loc[k] = (loc[k] + cp) * (1.f / 32768.f);     // + c^k * carry
-                    cp *= kPreemph;
-                }
-                if (lane < NL) {
+                for (int c = 0; c < NC; c++) {
+                    const float *rc = ring + c * kPostRing;
                     if constexpr (CH % 4 == 0) {
 #pragma unroll
-                        for (int k = 0; k < CH; k += 4) sts4(stage, lane * CH + k, f4{loc[k], loc[k + 1], loc[k + 2], loc[k + 3]});
+                        for (int k = 0; k < CH; k += 4) {
+                            const f4 q = lds4(rc, (p0 + k) & (kPostRing - 1));
+                            loc[c][k] = q.x; loc[c][k + 1] = q.y; loc[c][k + 2] = q.z; loc[c][k + 3] = q.w;
+                        }
                     } else {
 #pragma unroll
-                        for (int k = 0; k < CH; k++) stage[lane * CH + k] = loc[k];
+                        for (int k = 0; k < CH; k++) loc[c][k] = rc[(p0 + k) & (kPostRing - 1)];
                     }
                 }
-                mem = kPreemph * __shfl(e, NL - 1) + pwEnd * mem; // c t[N-1]
+                float e[NC];                                      // e[l] = sum_{i<=l} (c^CH)^(l-i) acc[i]
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < CH; k++) {
+                        acc = (loc[c][k] + 1e-30f) + kPreemph * acc;
+                        loc[c][k] = acc;
+                    }
+                    e[c] = lane < NL ? acc : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        const float up = __shfl_up(e[c], 1 << k);
+                        if (lane >= (1 << k)) e[c] += cstep[k] * up;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    // value entering lane l's chunk: c t[l CH - 1] = c e[l-1] + (c^CH)^l mem, with mem = c t[-1]
+                    const float prevEnd = __shfl_up(e[c], 1);
+                    float cp = lane == 0 ? mem[c] : kPreemph * prevEnd + pw * mem[c];
+#pragma unroll
+                    for (int k = 0; k < CH; k++) {
+                        loc[c][k] = (loc[c][k] + cp) * (1.f / 32768.f);     // + c^k * carry
+                        cp *= kPreemph;
+                    }
+                    if (lane < NL) {
+                        float *sg = stage + c * 960;
+                        if constexpr (CH % 4 == 0) {
+#pragma unroll
+                            for (int k = 0; k < CH; k += 4)
+                                sts4(sg, lane * CH + k, f4{loc[c][k], loc[c][k + 1], loc[c][k + 2], loc[c][k + 3]});
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < CH; k++) sg[lane * CH + k] = loc[c][k];
+                        }
+                    }
+                    mem[c] = kPreemph * __shfl(e[c], NL - 1) + pwEnd * mem[c]; // c t[N-1]
+                }
             }
             T_old = T_cur; g_old = g_cur; ts_old = ts_cur;       // :672-677
             T_cur = T_new; g_cur = g_new; ts_cur = ts_new;
@@ -323,7 +477,19 @@ __global__ __launch_bounds__(kWave *WPB) void celt_post_kernel(PostArgs A, const
                 T_new = T_nx; g_new = g_nx; ts_new = ts_nx;
                 if (f + 2 < A.nframes) NYQ_POST_FETCH(f + 2);
             }
-            if (A.channels == 1) {
+            if constexpr (NC == 2) {
+                // interleave the two planes on the way out: float4 v = {L[2v], R[2v], L[2v+1], R[2v+1]}
+                vf4 *d4 = reinterpret_cast<vf4 *>(dst);
+#pragma unroll
+                for (int k = 0; k < NLD2; k++) {
+                    const int v = lane + k * kWave;
+                    if (v < NV2) {
+                        const float2 l = *reinterpret_cast<const float2 *>(stage + 2 * v);
+                        const float2 r = *reinterpret_cast<const float2 *>(stage + 960 + 2 * v);
+                        d4[v] = vf4{l.x, r.x, l.y, r.y};
+                    }
+                }
+            } else if (A.channels == 1) {
                 vf4 *d4 = reinterpret_cast<vf4 *>(dst);
 #pragma unroll
                 for (int k = 0; k < NLD; k++) {
@@ -343,11 +509,16 @@ __global__ __launch_bounds__(kWave *WPB) void celt_post_kernel(PostArgs A, const
         }
         // hand the state to the next call: the last 1088 filtered samples end at ring index r0
         if (A.hist) {
-            for (int j = lane; j < kPostHist; j += kWave)
-                A.hist[sc * kPostHist + j] = ring[(r0 - kPostHist + j) & (kPostRing - 1)];
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+                for (int j = lane; j < kPostHist; j += kWave)
+                    A.hist[(sc0 + c) * kPostHist + j] = ring[c * kPostRing + ((r0 - kPostHist + j) & (kPostRing - 1))];
         }
-        if (A.deemph && lane == 0) A.deemph[sc] = mem;
-        if (A.pf_state_out && c == 0 && lane == 0) {
+        if (A.deemph && lane == 0) {
+#pragma unroll
+            for (int c = 0; c < NC; c++) A.deemph[sc0 + c] = mem[c];
+        }
+        if (A.pf_state_out && c0 == 0 && lane == 0) {
             float *ps = A.pf_state_out + 6 * s;
             ps[0] = (float)T_old; ps[1] = (float)T_cur; ps[2] = g_old; ps[3] = g_cur; ps[4] = (float)ts_old; ps[5] = (float)ts_cur;
         }
@@ -355,8 +526,6 @@ __global__ __launch_bounds__(kWave *WPB) void celt_post_kernel(PostArgs A, const
     }
 }
 
-#undef NYQ_POST_LD
-#undef NYQ_POST_ST
 #undef NYQ_POST_FETCH
 #undef NYQ_POST_TO_RING
 

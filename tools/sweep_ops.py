@@ -59,12 +59,20 @@ pcm = torch.randn((ns * ch, nf * 960), generator=g, device=dev) * 300
 out = torch.empty((ns, nf * 960, ch), device=dev)
 pt = torch.randint(0, 3, (ns, nf), generator=g, device=dev, dtype=torch.int32)
 for label, lo, hi, gmax in () if ONLY and ONLY != 'post' else (("pitch 15..1000, gain 0..0.75", 15, 1000, 9), ("no post-filter (gain 0)", 15, 1000, 1),
-                             ("pitch 300..1000", 300, 1000, 9), ("pitch 15..60", 15, 60, 9)):
+                             ("pitch 300..1000", 300, 1000, 9), ("pitch 15..60", 15, 60, 9),
+                             ("real-stream mix: 70 % filtered, pitch 15..80", 15, 80, -70)):
     pp = torch.randint(lo, hi, (ns, nf), generator=g, device=dev, dtype=torch.int32)
-    pg = (torch.randint(0, gmax, (ns, nf), generator=g, device=dev) * 0.09375).float()
-    ms = timeit(lambda: ctx.celt_post_dev(3, pcm.data_ptr(), pp.data_ptr(), pg.data_ptr(), pt.data_ptr(), 0, 0, 0, 0, out.data_ptr(), ns, nf, ch), 5)
-    res.append(dict(op=f"celt_post_dev 1024 streams x 256 frames x 2ch, {label}", rows=ns * nf * ch, ms=ms, alg_GBps=ns * nf * ch * 7680 / ms / 1e6,
-                    rows_per_s=ns * nf * ch / ms * 1e3))
+    if gmax < 0:      # filtered fraction in per cent, gains 0.09 .. 0.75
+        on = (torch.rand((ns, nf), generator=g, device=dev) < (-gmax / 100.0)).float()
+        pg = on * (torch.randint(1, 9, (ns, nf), generator=g, device=dev) * 0.09375).float()
+    else:
+        pg = (torch.randint(0, gmax, (ns, nf), generator=g, device=dev) * 0.09375).float()
+    for mode in ("0", "1"):      # one wave per channel (default) vs one wave per stereo pair, same process, same box
+        os.environ["NYQ_POST_STEREO_PAIRS"] = mode
+        ms = timeit(lambda: ctx.celt_post_dev(3, pcm.data_ptr(), pp.data_ptr(), pg.data_ptr(), pt.data_ptr(), 0, 0, 0, 0, out.data_ptr(), ns, nf, ch), 5)
+        res.append(dict(op=f"celt_post_dev 1024 streams x 256 frames x 2ch, {label}" + (" [stereo pairs]" if mode == "1" else ""),
+                        rows=ns * nf * ch, ms=ms, alg_GBps=ns * nf * ch * 7680 / ms / 1e6, rows_per_s=ns * nf * ch / ms * 1e3))
+    os.environ["NYQ_POST_STEREO_PAIRS"] = "0"
 if not ONLY or ONLY == 'post':
     ns1, ch1 = 2048, 1
     out1 = torch.empty((ns1, nf * 960, ch1), device=dev)
