@@ -434,12 +434,15 @@ extern "C" int nyq_celt_post_dev(nyq_ctx *ctx, int LM, const float *d_pcm, const
     if (((uintptr_t)d_pcm | (uintptr_t)d_out) & 15)
         return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_post_dev: pcm and out must be 16-byte aligned");
     // a stereo stream is one wave's work (both channels in lock step); any other channel count: one wave per channel
-    // One wave per (stream, channel) is the default also for stereo: real streams keep the post-filter on in
-    // 60-80 % of the frames with short periods, and there the comb recursion is bound by instruction issue, which
-    // more waves hide better.  NYQ_POST_STEREO_PAIRS=1 lets one wave own both channels of a stereo
-    // stream instead (full 16-byte interleaved stores: faster when hardly any frame is filtered).
-    const char *pairs = std::getenv("NYQ_POST_STEREO_PAIRS");
-    if (channels == 2 && pairs && pairs[0] == '1') {
+    // Stereo: one wave can own both channels of a stream (identical filter parameters, two dependency chains per
+    // step, full 16-byte interleaved stores) or one channel.  The comb recursion is bound by instruction issue, so
+    // what matters is how many waves a CU has to interleave: pairs win once there are enough streams to give every
+    // CU its six pair-waves (24 KB of LDS each), channel-waves win below that (same-process A/B).
+    // NYQ_POST_STEREO_PAIRS=0/1 overrides the choice for profiling.
+    bool pair_mode = channels == 2 && nstreams >= (size_t)5 * (size_t)ctx->cus;
+    if (const char *pairs = std::getenv("NYQ_POST_STEREO_PAIRS"))
+        if (channels == 2 && (pairs[0] == '0' || pairs[0] == '1')) pair_mode = pairs[0] == '1';
+    if (pair_mode) {
         switch (LM) {
             case 0: return launch_post<0, 2>(ctx, A);
             case 1: return launch_post<1, 2>(ctx, A);

@@ -54,7 +54,7 @@ for n, rows in () if ONLY and ONLY != 'vorbis' else ((2048, 1 << 19), (256, 1 <<
     ms = timeit(lambda: ctx.vorbis_imdct_batch_dev(n, x.data_ptr(), y.data_ptr(), rows))
     res.append(dict(op=f"vorbis_imdct_batch_dev n {n}", rows=rows, ms=ms, alg_GBps=rows * n * 6 / ms / 1e6, rows_per_s=rows / ms * 1e3))
     del x, y
-ns, nf, ch = 1024, int(os.environ.get("SWEEP_NF", "256")), 2
+ns, nf, ch = int(os.environ.get("SWEEP_NS", "1024")), int(os.environ.get("SWEEP_NF", "256")), 2
 pcm = torch.randn((ns * ch, nf * 960), generator=g, device=dev) * 300
 out = torch.empty((ns, nf * 960, ch), device=dev)
 pt = torch.randint(0, 3, (ns, nf), generator=g, device=dev, dtype=torch.int32)
@@ -70,9 +70,9 @@ for label, lo, hi, gmax in () if ONLY and ONLY != 'post' else (("pitch 15..1000,
     for mode in ("0", "1"):      # one wave per channel (default) vs one wave per stereo pair, same process, same box
         os.environ["NYQ_POST_STEREO_PAIRS"] = mode
         ms = timeit(lambda: ctx.celt_post_dev(3, pcm.data_ptr(), pp.data_ptr(), pg.data_ptr(), pt.data_ptr(), 0, 0, 0, 0, out.data_ptr(), ns, nf, ch), 5)
-        res.append(dict(op=f"celt_post_dev 1024 streams x 256 frames x 2ch, {label}" + (" [stereo pairs]" if mode == "1" else ""),
+        res.append(dict(op=f"celt_post_dev {ns} streams x {nf} frames x 2ch, {label}" + (" [stereo pairs]" if mode == "1" else ""),
                         rows=ns * nf * ch, ms=ms, alg_GBps=ns * nf * ch * 7680 / ms / 1e6, rows_per_s=ns * nf * ch / ms * 1e3))
-    os.environ["NYQ_POST_STEREO_PAIRS"] = "0"
+    del os.environ["NYQ_POST_STEREO_PAIRS"]
 if not ONLY or ONLY == 'post':
     ns1, ch1 = 2048, 1
     out1 = torch.empty((ns1, nf * 960, ch1), device=dev)
