@@ -12,8 +12,11 @@
 // filters' structure:
 //   * comb filter: y[i] depends on y[i-T-2 .. i-T+2] with T >= 15 (COMBFILTER_MINPERIOD), so T-2
 //     consecutive outputs are independent.  A wave step produces up to 256 of them, four adjacent
-//     outputs per lane (their 8 taps come from three aligned 16-byte LDS reads), out of a 2048-sample
-//     LDS ring that holds the filtered history (= DECODE_BUFFER_SIZE, the reference's decode_mem depth);
+//     outputs per lane (their 8 taps come from three aligned 16-byte LDS reads), out of a 2048-sample LDS
+//     buffer per channel (= DECODE_BUFFER_SIZE, the reference's decode_mem depth) laid out LINEARLY as
+//     [1088 samples of filtered history | the frame]: every tap address is the output's address minus a
+//     wave-uniform constant (immediate offsets, no wrap arithmetic); after a frame the last 1088 samples are
+//     moved to the front (five 16-byte reads and writes per lane);
 //   * de-emphasis: y[j] = x[j] + c*y[j-1] is a first-order linear recurrence: each lane runs it over
 //     its own N/64 consecutive samples, one log-step wavefront scan (ratio c^(N/64)) links the lanes.
 // Global memory is touched only at the frame boundaries, ordered so that no wait is for a young
@@ -26,9 +29,10 @@
 
 namespace nyq {
 
-constexpr int kPostRing = 2048;         // DECODE_BUFFER_SIZE, celt_decoder_clean.c:59
-constexpr int kPostHist = 1088;         // history handed from call to call (>= COMBFILTER_MAXPERIOD + 2)
+constexpr int kPostRing = 2048;         // per-channel LDS buffer: DECODE_BUFFER_SIZE, celt_decoder_clean.c:59
+constexpr int kPostHist = 1088;         // history in front of the frame (>= COMBFILTER_MAXPERIOD + 2); also handed from call to call
 constexpr int kCombMinPeriod = 15;      // celt.h:188
+constexpr int kCombMaxPeriod = 1024;    // celt.h:187 (keeps every tap inside the buffer whatever the caller passes)
 constexpr float kPreemph = 0.85000610f; // mode->preemph[0], static_modes_float.h:581
 
 struct PostArgs {
@@ -80,7 +84,7 @@ __device__ __forceinline__ void pick8(const f4 &q0, const f4 &q1, const f4 &q2, 
     for (int i = 0; i < 8; i++) x[i] = e[A + i];
 }
 
-// x[c][0..8) = ring_c[r .. r+8) (mod 2048) for an arbitrary r whose alignment r & 3 is the same in every lane
+// x[c][0..8) = buf_c[r .. r+8) for an arbitrary r >= 0 whose alignment r & 3 is the same in every lane
 // (and in every channel: the channels of a stream share the pitch period)
 template <int NC>
 __device__ __forceinline__ void taps8(const float *ring, int r, float (&x)[NC][8]) {
@@ -90,9 +94,9 @@ __device__ __forceinline__ void taps8(const float *ring, int r, float (&x)[NC][8
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         const float *rc = ring + c * kPostRing;
-        q0[c] = lds4(rc, rb & (kPostRing - 1));
-        q1[c] = lds4(rc, (rb + 4) & (kPostRing - 1));
-        q2[c] = lds4(rc, (rb + 8) & (kPostRing - 1));
+        q0[c] = lds4(rc, rb);
+        q1[c] = lds4(rc, rb + 4);
+        q2[c] = lds4(rc, rb + 8);
     }
     switch (a) {
         case 0:
@@ -120,8 +124,8 @@ template <int NC, int AL>
 __device__ __forceinline__ void comb_const_loop(float *ring, int lane, int r0, int n, int T1, float g10, float g11,
                                                 float g12, int w1) {
     const int o = 4 * lane;
-    int idx = (r0 + kOverlap + o) & (kPostRing - 1);           // this lane's outputs of the current step
-    int rb = (idx - T1 - 2 - AL) & (kPostRing - 1);            // aligned start of their taps
+    int idx = r0 + kOverlap + o;                               // this lane's outputs of the current step
+    int rb = idx - T1 - 2 - AL;                                // aligned start of their taps
     for (int base = kOverlap; base < n; base += w1) {
         if (o < w1 && base + o < n) {
             f4 cen[NC], q0[NC], q1[NC], q2[NC];
@@ -129,8 +133,8 @@ __device__ __forceinline__ void comb_const_loop(float *ring, int lane, int r0, i
             for (int c = 0; c < NC; c++) {
                 const float *rc = ring + c * kPostRing;
                 q0[c] = lds4(rc, rb);
-                q1[c] = lds4(rc, (rb + 4) & (kPostRing - 1));
-                q2[c] = lds4(rc, (rb + 8) & (kPostRing - 1));
+                q1[c] = lds4(rc, rb + 4);
+                q2[c] = lds4(rc, rb + 8);
                 cen[c] = lds4(rc, idx);
             }
 #pragma unroll
@@ -147,14 +151,14 @@ __device__ __forceinline__ void comb_const_loop(float *ring, int lane, int r0, i
                 sts4(ring + c * kPostRing, idx, f4{y[0], y[1], y[2], y[3]});
             }
         }
-        idx = (idx + w1) & (kPostRing - 1);
-        rb = (rb + w1) & (kPostRing - 1);
+        idx += w1;
+        rb += w1;
         NYQ_POST_SYNC();
     }
 }
 
-// One comb_filter() call (celt.c:114-172) on the n ring samples that start at ring index r0 (a multiple
-// of 4) of each of the NC channel rings (kPostRing floats apart): cross-fade from (T0,g0,tapset0) to
+// One comb_filter() call (celt.c:114-172) on the n samples that start at index r0 (a multiple of 4, at least
+// kCombMaxPeriod + 2) of each of the NC channel buffers (kPostRing floats apart): cross-fade from (T0,g0,tapset0) to
 // (T1,g1,tapset1) over the first 120 samples, constant after.
 template <int NC>
 __device__ __forceinline__ void comb_call(float *ring, int lane, int r0, int n, int T0, int T1, float g0, float g1,
@@ -176,7 +180,7 @@ __device__ __forceinline__ void comb_call(float *ring, int lane, int r0, int n, 
         for (int base = 0; base < kOverlap; base += w) {
             const int i = base + lane;
             if (lane < w && i < kOverlap) {
-                const int idx = (r0 + i) & (kPostRing - 1);
+                const int idx = r0 + i;
                 const float f = win2[i], nf = 1.0f - f;
                 const int t0i = idx - T0 - 2, t1i = idx - T1 - 2;
 #pragma unroll
@@ -184,17 +188,13 @@ __device__ __forceinline__ void comb_call(float *ring, int lane, int r0, int n, 
                     float *rc = ring + c * kPostRing;
                     float y = rc[idx];
                     if (g0 != 0.f) {
-                        const float x0 = rc[t0i & (kPostRing - 1)], x1 = rc[(t0i + 1) & (kPostRing - 1)],
-                                    x2 = rc[(t0i + 2) & (kPostRing - 1)], x3 = rc[(t0i + 3) & (kPostRing - 1)],
-                                    x4 = rc[(t0i + 4) & (kPostRing - 1)];
+                        const float x0 = rc[t0i], x1 = rc[t0i + 1], x2 = rc[t0i + 2], x3 = rc[t0i + 3], x4 = rc[t0i + 4];
                         y += (nf * g00) * x2;
                         y += (nf * g01) * (x3 + x1);
                         y += (nf * g02) * (x4 + x0);
                     }
                     if (g1 != 0.f) {
-                        const float x0 = rc[t1i & (kPostRing - 1)], x1 = rc[(t1i + 1) & (kPostRing - 1)],
-                                    x2 = rc[(t1i + 2) & (kPostRing - 1)], x3 = rc[(t1i + 3) & (kPostRing - 1)],
-                                    x4 = rc[(t1i + 4) & (kPostRing - 1)];
+                        const float x0 = rc[t1i], x1 = rc[t1i + 1], x2 = rc[t1i + 2], x3 = rc[t1i + 3], x4 = rc[t1i + 4];
                         y += (f * g10) * x2;
                         y += (f * g11) * (x3 + x1);
                         y += (f * g12) * (x4 + x0);
@@ -208,7 +208,7 @@ __device__ __forceinline__ void comb_call(float *ring, int lane, int r0, int n, 
     const int w = (tmin - 2) & ~3;
     for (int base = 0; base < kOverlap; base += w) {
         if (o < w && base + o < kOverlap) {
-            const int idx = (r0 + base + o) & (kPostRing - 1);
+            const int idx = r0 + base + o;
             const f4 fw = lds4(win2, base + o);
             const float f[4] = {fw.x, fw.y, fw.z, fw.w};
             float y[NC][4];
@@ -255,15 +255,14 @@ __device__ __forceinline__ void comb_call(float *ring, int lane, int r0, int n, 
         // short periods (the common case in real streams): T1-2 <= 64 outputs per step anyway, so one output
         // per lane with five scalar tap reads is the leaner step
         const int w = T1 - 2;
-        int idx = (r0 + kOverlap + lane) & (kPostRing - 1);
-        int tp = (idx - T1 - 2) & (kPostRing - 1);
+        int idx = r0 + kOverlap + lane;
+        int tp = idx - T1 - 2;
         for (int base = kOverlap; base < n; base += w) {
             if (lane < w && base + lane < n) {
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
                     float *rc = ring + c * kPostRing;
-                    const float x0 = rc[tp], x1 = rc[(tp + 1) & (kPostRing - 1)], x2 = rc[(tp + 2) & (kPostRing - 1)],
-                                x3 = rc[(tp + 3) & (kPostRing - 1)], x4 = rc[(tp + 4) & (kPostRing - 1)];
+                    const float x0 = rc[tp], x1 = rc[tp + 1], x2 = rc[tp + 2], x3 = rc[tp + 3], x4 = rc[tp + 4];
                     float y = rc[idx];
                     y += g10 * x2;
                     y += g11 * (x3 + x1);
@@ -271,8 +270,8 @@ __device__ __forceinline__ void comb_call(float *ring, int lane, int r0, int n, 
                     rc[idx] = y;
                 }
             }
-            idx = (idx + w) & (kPostRing - 1);
-            tp = (tp + w) & (kPostRing - 1);
+            idx += w;
+            tp += w;
             NYQ_POST_SYNC();
         }
         return;
@@ -332,14 +331,11 @@ __global__ __launch_bounds__(kWave *WPB) void celt_post_kernel(PostArgs A, const
         const long s = NC == 2 ? unit : unit / A.channels;
         const int c0 = NC == 2 ? 0 : (int)(unit - s * A.channels);
         const long sc0 = s * A.channels + c0;                  // first (stream, channel) of this wave
-        // ring slots [960, 2048) <- filtered history that precedes frame 0 (times -1088 .. -1); time 0 = slot 0
+        // buffer [0, 1088) <- filtered history that precedes frame 0 (times -1088 .. -1); the frame sits at [1088, 1088 + N)
 #pragma unroll
         for (int c = 0; c < NC; c++)
-            for (int j = lane; j < kPostRing; j += kWave) {
-                float v = 0.f;
-                if (j >= kPostRing - kPostHist && A.hist) v = A.hist[(sc0 + c) * kPostHist + (j - (kPostRing - kPostHist))];
-                ring[c * kPostRing + j] = v;
-            }
+            for (int j = lane; j < kPostHist; j += kWave)
+                ring[c * kPostRing + j] = A.hist ? A.hist[(sc0 + c) * kPostHist + j] : 0.f;
         int T_old = 0, T_cur = 0, ts_old = 0, ts_cur = 0;
         float g_old = 0.f, g_cur = 0.f;
         if (A.pf_state) {
@@ -377,32 +373,34 @@ __global__ __launch_bounds__(kWave *WPB) void celt_post_kernel(PostArgs A, const
         g_nx = pgain[fidx];                                                                   \
         ts_nx = ptap[fidx];                                                                   \
     } while (0)
-#define NYQ_POST_TO_RING(rp)                                                                  \
+#define NYQ_POST_TO_RING()                                                                    \
     do {                                                                                      \
-        const int rpos = (rp);                                                                \
         _Pragma("unroll") for (int c = 0; c < NC; c++)                                        \
             _Pragma("unroll") for (int k = 0; k < NLD; k++) {                                 \
                 const int v = lane + k * kWave;                                               \
-                if (v < NV) sts4(ring + c * kPostRing, (rpos + 4 * v) & (kPostRing - 1), nx[c][k]); \
+                if (v < NV) sts4(ring + c * kPostRing, kPostHist + 4 * v, nx[c][k]);          \
             }                                                                                 \
     } while (0)
         int T_new = 0, ts_new = 0;
         float g_new = 0.f;
         if (A.nframes > 0) {
             NYQ_POST_FETCH(0);
-            NYQ_POST_TO_RING(0);
+            NYQ_POST_TO_RING();
             T_new = T_nx; g_new = g_nx; ts_new = ts_nx;
             if (A.nframes > 1) NYQ_POST_FETCH(1);
         }
         NYQ_POST_SYNC();
-        int r0 = 0;                                            // ring index of the frame start
+        constexpr int r0 = kPostHist;                          // buffer index of the frame start
         float *dst = A.out + (s * A.nframes * N) * A.channels + c0;
         for (long f = 0; f < A.nframes; f++) {
             if (T_cur < kCombMinPeriod) T_cur = kCombMinPeriod;   // celt_decoder_clean.c:661-662
             if (T_old < kCombMinPeriod) T_old = kCombMinPeriod;
+            if (T_cur > kCombMaxPeriod) T_cur = kCombMaxPeriod;   // (a decoder never produces more: keeps taps in the buffer)
+            if (T_old > kCombMaxPeriod) T_old = kCombMaxPeriod;
+            const int T_nw = T_new < kCombMinPeriod ? kCombMinPeriod : T_new > kCombMaxPeriod ? kCombMaxPeriod : T_new;
             comb_call<NC>(ring, lane, r0, kOverlap, T_old, T_cur, g_old, g_cur, ts_old, ts_cur, win2);
             if (LM != 0)
-                comb_call<NC>(ring, lane, r0 + kOverlap, N - kOverlap, T_cur, T_new, g_cur, g_new, ts_cur, ts_new, win2);
+                comb_call<NC>(ring, lane, r0 + kOverlap, N - kOverlap, T_cur, T_nw, g_cur, g_new, ts_cur, ts_new, win2);
             // de-emphasis (celt_decoder_clean.c:243-248): tmp = x + m + VERY_SMALL; m = coef0*tmp; y = tmp/32768
             {
                 // all LDS reads first, the recurrence in registers, one write per sample
@@ -415,12 +413,12 @@ __global__ __launch_bounds__(kWave *WPB) void celt_post_kernel(PostArgs A, const
                     if constexpr (CH % 4 == 0) {
 #pragma unroll
                         for (int k = 0; k < CH; k += 4) {
-                            const f4 q = lds4(rc, (p0 + k) & (kPostRing - 1));
+                            const f4 q = lds4(rc, p0 + k);
                             loc[c][k] = q.x; loc[c][k + 1] = q.y; loc[c][k + 2] = q.z; loc[c][k + 3] = q.w;
                         }
                     } else {
 #pragma unroll
-                        for (int k = 0; k < CH; k++) loc[c][k] = rc[(p0 + k) & (kPostRing - 1)];
+                        for (int k = 0; k < CH; k++) loc[c][k] = rc[p0 + k];
                     }
                 }
                 float e[NC];                                      // e[l] = sum_{i<=l} (c^CH)^(l-i) acc[i]
@@ -470,10 +468,30 @@ __global__ __launch_bounds__(kWave *WPB) void celt_post_kernel(PostArgs A, const
             T_cur = T_new; g_cur = g_new; ts_cur = ts_new;
             if (LM != 0) { T_old = T_cur; g_old = g_cur; ts_old = ts_cur; }   // :678-683
             NYQ_POST_SYNC();
-            // frame f+1 overwrites ring times [t0+N-2048, t0+2N-2048): older than anything its comb filter reads
-            const int r1 = (r0 + N) & (kPostRing - 1);
+            // the last 1088 samples of [history | frame] become the history of the next frame: [N, N + 1088) -> [0, 1088)
+            // (the ranges overlap: every lane reads its share first, writes after the barrier)
+            {
+                constexpr int HV = kPostHist / 4;                 // 272 float4 per channel
+                constexpr int HLD = (HV + kWave - 1) / kWave;     // 5 per lane
+                vf4 hv[NC][HLD];
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+#pragma unroll
+                    for (int k = 0; k < HLD; k++) {
+                        const int v = lane + k * kWave;
+                        hv[c][k] = *reinterpret_cast<const vf4 *>(ring + c * kPostRing + N + 4 * (v < HV ? v : HV - 1));
+                    }
+                NYQ_POST_SYNC();
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+#pragma unroll
+                    for (int k = 0; k < HLD; k++) {
+                        const int v = lane + k * kWave;
+                        if (v < HV) sts4(ring + c * kPostRing, 4 * v, hv[c][k]);
+                    }
+            }
             if (f + 1 < A.nframes) {
-                NYQ_POST_TO_RING(r1);
+                NYQ_POST_TO_RING();
                 T_new = T_nx; g_new = g_nx; ts_new = ts_nx;
                 if (f + 2 < A.nframes) NYQ_POST_FETCH(f + 2);
             }
@@ -504,15 +522,13 @@ __global__ __launch_bounds__(kWave *WPB) void celt_post_kernel(PostArgs A, const
                 }
             }
             dst += (long)N * A.channels;
-            r0 = r1;
             NYQ_POST_SYNC();
         }
-        // hand the state to the next call: the last 1088 filtered samples end at ring index r0
+        // hand the state to the next call: the history in front of the (next) frame
         if (A.hist) {
 #pragma unroll
             for (int c = 0; c < NC; c++)
-                for (int j = lane; j < kPostHist; j += kWave)
-                    A.hist[(sc0 + c) * kPostHist + j] = ring[c * kPostRing + ((r0 - kPostHist + j) & (kPostRing - 1))];
+                for (int j = lane; j < kPostHist; j += kWave) A.hist[(sc0 + c) * kPostHist + j] = ring[c * kPostRing + j];
         }
         if (A.deemph && lane == 0) {
 #pragma unroll
