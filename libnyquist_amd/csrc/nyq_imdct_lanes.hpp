@@ -75,8 +75,9 @@ struct Geo {
     static constexpr int NT = N4 / 4;                 // stage tasks per row (4 points each)
     static constexpr int SLOT = NT > 64 ? 128 : NT > 32 ? 64 : NT > 16 ? 32 : 16;
     // rows per wave-group: enough that the radix-15 pass (N2R lanes per row) fills the wavefront and that a
-    // group keeps >= 7.5 KB of loads in flight: 4, 4, 8, 16 rows for nfft 480, 240, 120, 60
-    static constexpr int G = N2R == 32 ? 4 : N2R == 16 ? 8 : 16;
+    // group keeps >= 7.5 KB of loads in flight: 4, 8, 8, 16 rows for nfft 480, 240, 120, 60 (16 rows at nfft 120 cost the
+    // frame-synthesis kernel its second wave per SIMD: 256 VGPRs)
+    static constexpr int G = N2R == 32 ? 4 : N2R == 4 ? 16 : 8;
     static constexpr int SUBS = G * SLOT / kWave;        // stage sub-iterations per group
     static constexpr int JSETS = SLOT > kWave ? SLOT / kWave : 1;
     static constexpr int S = (N4 % 32 <= 16) ? (N4 - N4 % 32 + 16) : (N4 - N4 % 32 + 48);

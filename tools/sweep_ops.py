@@ -54,6 +54,19 @@ for n, rows in () if ONLY and ONLY != 'vorbis' else ((2048, 1 << 19), (256, 1 <<
     ms = timeit(lambda: ctx.vorbis_imdct_batch_dev(n, x.data_ptr(), y.data_ptr(), rows))
     res.append(dict(op=f"vorbis_imdct_batch_dev n {n}", rows=rows, ms=ms, alg_GBps=rows * n * 6 / ms / 1e6, rows_per_s=rows / ms * 1e3))
     del x, y
+# frame synthesis (nyq_celt_synth_dev) for every frame size: the same 2 GB of coefficients as 2.5 / 5 / 10 / 20 ms frames
+for lm in () if ONLY and ONLY != 'synth' else (3, 2, 1, 0):
+    n = 120 << lm
+    sns, snf, sch = 1024, 256 << (3 - lm), 2
+    sfreq = torch.randn((sns, snf, sch, n), generator=g, device=dev) * 30.0
+    strans = (torch.rand((sns, snf), generator=g, device=dev) < 0.028).to(torch.uint8)
+    spcm = torch.empty((sns, sch, snf * n), device=dev)
+    sstate = torch.zeros((sns * sch, 60), device=dev)
+    swork = torch.empty(ctx.celt_synth_work_floats(sns, snf, sch), device=dev)
+    ms = timeit(lambda: ctx.celt_synth_dev(lm, sfreq.data_ptr(), strans.data_ptr(), spcm.data_ptr(), sstate.data_ptr(), swork.data_ptr(), sns, snf, sch), 5)
+    res.append(dict(op=f"celt_synth_dev LM {lm} ({n}-sample frames), {sns} streams x {snf} frames x {sch}ch, 2.8 % transient", rows=sns * snf * sch, ms=ms,
+                    alg_GBps=sns * snf * sch * n * 8 / ms / 1e6, rows_per_s=sns * snf * sch / ms * 1e3))
+    del sfreq, spcm, swork, strans, sstate
 ns, nf, ch = int(os.environ.get("SWEEP_NS", "1024")), int(os.environ.get("SWEEP_NF", "256")), 2
 pcm = torch.randn((ns * ch, nf * 960), generator=g, device=dev) * 300
 out = torch.empty((ns, nf * 960, ch), device=dev)
