@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <condition_variable>
 #include <cstdlib>
@@ -14,6 +15,8 @@
 #include <stdexcept>
 #include <thread>
 #include <tuple>
+
+#include <sched.h>
 
 #include "../../include/nyq_imdct.h"
 #include "celt_decoder.hpp"
@@ -171,6 +174,28 @@ constexpr size_t kPieceBytes = (size_t)24 << 20;   // of freq per piece
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// Host threads this process may really use: the affinity mask, clipped by the cgroup CPU quota (a container
+// that sees 256 CPUs but is allowed 16 must not start 256 decoding threads).
+int usableHostThreads() {
+    int n = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+    if (n <= 0) n = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {            // cgroup v2: "<quota|max> <period>"
+        char quota[32];
+        long period = 0;
+        if (std::fscanf(f, "%31s %ld", quota, &period) == 2 && period > 0 && std::strcmp(quota, "max") != 0)
+            n = std::min(n, std::max(1, (int)((std::atol(quota) + period / 2) / period)));
+        std::fclose(f);
+    } else {                                                              // cgroup v1
+        long q = -1, p = 0;
+        if (FILE *fq = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(fq, "%ld", &q) != 1) q = -1; std::fclose(fq); }
+        if (FILE *fp = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(fp, "%ld", &p) != 1) p = 0; std::fclose(fp); }
+        if (q > 0 && p > 0) n = std::min(n, std::max(1, (int)((q + p / 2) / p)));
+    }
+    return n;
+}
+
 template <class F>
 void parallelFor(size_t n, int threads, F &&body) {
     std::atomic<size_t> next{0};
@@ -223,7 +248,7 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
     const size_t nfiles = files.size();
     out.assign(nfiles, DecodedStream());
     std::vector<FileJob> jobs(nfiles);
-    if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (threads <= 0) threads = usableHostThreads();
     auto t0 = std::chrono::steady_clock::now();
     // pass 0: scan
     parallelFor(nfiles, threads, [&](size_t i) {
