@@ -192,10 +192,21 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+        backend = args.dist_backend
+        if backend == "nccl":
+            try:
+                dist.init_process_group("nccl", device_id=dev)
+            except Exception as e:      # the data path needs no collective: a CPU process group is enough for the barrier
+                print(f"bench.py: RCCL process group failed ({e!r}); using gloo for barrier / max-time", file=sys.stderr)
+                try:
+                    dist.destroy_process_group()
+                except Exception:
+                    pass
+                backend = "gloo"
+                dist.init_process_group("gloo")
         else:
             dist.init_process_group("gloo")
+        args.dist_backend = backend
     red_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")
 
     import libnyquist_amd as nyq
