@@ -19,14 +19,21 @@ int main(int argc, char **argv) {
         nqr::NyquistIO loader;
         nqr::AudioData data;
         loader.Load(&data, std::string(argv[1]));
-        float sum = 0;                                   // float accumulation like Main.cpp:137-143
-        for (float v : data.samples) sum += v;
+        float sum = 0;                                   // float accumulation, channel after channel, as Main.cpp:136-142
+        const size_t per = data.channelCount ? data.samples.size() / (size_t)data.channelCount : 0;
+        for (int c = 0; c < data.channelCount; c++)
+            for (size_t j = 0; j < per; j++) sum += data.samples[j * (size_t)data.channelCount + (size_t)c];
         std::printf("channels: %d rate: %d seconds: %.0f\n", data.channelCount, data.sampleRate, data.lengthSeconds);
         std::printf("len: %zu sum: %f\n", data.samples.size(), sum);
         struct { int sum; size_t size; const char *name; } known[] = {
             {403, 21472602, "sb-reverie.opus"}, {40, 127712488, "Rachel8ch.opus"}, {719, 21472602, "sb-reverie-60ms-frames.opus"}};
+        bool ok = false;
         for (auto &k : known)
-            if ((int)sum == k.sum && data.samples.size() == k.size) std::printf("matches the reference checksum of %s\n", k.name);
+            if ((int)sum == k.sum && data.samples.size() == k.size) {
+                std::printf("matches the reference checksum of %s\n", k.name);
+                ok = true;
+            }
+        if (!ok) std::printf("not one of the reference's three test files (Main.cpp:144-148 would say \"wrong results!\")\n");
         if (argc > 2) {
             FILE *f = std::fopen(argv[2], "wb");
             if (f) {

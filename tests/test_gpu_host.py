@@ -125,3 +125,25 @@ def test_corrupted_files_never_crash_the_batch_path(host):
         ok += n >= 0
         bad += n < 0
     assert ok > 0 and bad > 0          # both outcomes occur: the damage is neither always fatal nor always ignored
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,want_int_sum", [("sb-reverie.opus", 403), ("sb-reverie-60ms-frames.opus", 719)])
+def test_reference_ctest_criteria(host, name, want_int_sum):
+    """The reference's own integration tests (CMakeLists.txt:199-217 run examples/src/Main.cpp on these files):
+    pass iff samples.size() == 21472602 and (int) of the float sum, accumulated channel after channel, is 403
+    (20 ms packets) / 719 (60 ms packets) -- Main.cpp:136-148.  Same files, same criterion, through this build's
+    NyquistIO::Load (223.7 s of stereo audio: 11184 frames on the CPU entropy stage, then the GPU stages)."""
+    raw = open(os.path.join(GOLDEN, name), "rb").read()
+    info = np.zeros(8, np.int64)
+    n = host.nyqh_nyquistio_load_buffer(raw, len(raw), None, 0, info)
+    assert n == 21472602
+    out = np.zeros(n, np.float32)
+    assert host.nyqh_nyquistio_load_buffer(raw, len(raw), out.ctypes.data_as(C.c_void_p), n, info) == n
+    assert int(info[0]) == 2 and int(info[1]) == 48000
+    pcm = out.reshape(-1, 2)
+    s = np.float32(0)
+    for c in range(2):                                   # sequential float32 accumulation, channel-major
+        s = np.cumsum(np.concatenate([[s], pcm[:, c]]).astype(np.float32), dtype=np.float32)[-1]
+    assert int(s) == want_int_sum
+    assert np.isfinite(out).all() and np.abs(out).max() <= 1.5
