@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 from test_host_decoder import load_host
 
 pytestmark = pytest.mark.gpu
@@ -147,3 +147,13 @@ def test_reference_ctest_criteria(host, name, want_int_sum):
         s = np.cumsum(np.concatenate([[s], pcm[:, c]]).astype(np.float32), dtype=np.float32)[-1]
     assert int(s) == want_int_sum
     assert np.isfinite(out).all() and np.abs(out).max() <= 1.5
+    ref = os.path.join(ROOT, "oracle", "_ref", "libref_decode.so")
+    if os.path.exists(ref):                              # and sample for sample against the reference build
+        R = C.CDLL(ref)
+        R.ref_decode_pcm.restype = C.c_long
+        R.ref_decode_pcm.argtypes = [C.c_char_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p]
+        full = np.zeros(n, np.float32)
+        assert R.ref_decode_pcm(raw, len(raw), full.ctypes.data_as(C.c_void_p), n, None) == n
+        assert np.abs(out - full).max() <= 4e-6
+        d = out.astype(np.float64) - full
+        assert np.sqrt((d ** 2).mean()) <= 1e-5 * np.sqrt((full.astype(np.float64) ** 2).mean())
