@@ -165,6 +165,15 @@ int nyq_celt_frames_to_pcm(nyq_ctx *ctx, int LM, const float *freq, const unsign
                            const int *pf_pitch, const float *pf_gain, const int *pf_tapset,
                            float *out, float *state, size_t nstreams, size_t nframes, int channels);
 
+/* The same on a WINDOW of longer per-stream host arrays: consecutive streams are `frames_per_stream` (>= nframes)
+ * frames apart in freq / transient / pf_* / out, and the pointers address the window's first frame of the first
+ * stream.  With `state` carried from call to call this decodes long streams slice by slice, many streams at a
+ * time, in bounded device memory -- bit-identical to one call over the whole length. */
+int nyq_celt_frames_to_pcm_window(nyq_ctx *ctx, int LM, const float *freq, const unsigned char *transient,
+                                  const int *pf_pitch, const float *pf_gain, const int *pf_tapset,
+                                  float *out, float *state, size_t nstreams, size_t nframes, int channels,
+                                  size_t frames_per_stream);
+
 /* ---- the reference's operator boundary, kept verbatim ------------------- */
 /* cuda/mdct_cuda.hpp:89-91 (impl mdct_cuda.cu:314-392).  Host pointers, caller-owned.
  * N = mdct.n >> shift (already shifted, mdct.c:249-253); input element k at

@@ -22,7 +22,7 @@ EXPORTS = [
     "nyq_ctx_synchronize", "nyq_ctx_set_tables", "nyq_ctx_get_tables", "nyq_ctx_device_info",
     "nyq_ifft_batch_dev", "nyq_imdct_batch_dev", "nyq_imdct_chain_dev",
     "nyq_celt_synth_work_floats", "nyq_celt_synth_dev", "nyq_celt_synth", "nyq_celt_post_dev",
-    "nyq_celt_frames_to_pcm", "nyq_celt_state_floats", "nyq_vorbis_imdct_batch_dev", "nyq_vorbis_imdct_batch",
+    "nyq_celt_frames_to_pcm", "nyq_celt_frames_to_pcm_window", "nyq_celt_state_floats", "nyq_vorbis_imdct_batch_dev", "nyq_vorbis_imdct_batch",
     "nyq_ifft_batch", "nyq_imdct_batch", "nyq_imdct_chain", "nyq_host_alloc", "nyq_host_free",
     "processMDCTCuda", "processMDCTCudaB1C2", "cleanupCudaBuffers", "printCudaVersion",
 ]
@@ -108,6 +108,7 @@ def load(path=None):
     L.nyq_celt_synth.argtypes = [vp, i, fp, fp, fp, fp, sz, sz, i]
     L.nyq_celt_post_dev.argtypes = [vp, i, fp, fp, fp, fp, fp, fp, fp, fp, fp, sz, sz, i]
     L.nyq_celt_frames_to_pcm.argtypes = [vp, i, fp, fp, fp, fp, fp, fp, fp, sz, sz, i]
+    L.nyq_celt_frames_to_pcm_window.argtypes = [vp, i, fp, fp, fp, fp, fp, fp, fp, sz, sz, i, sz]
     L.nyq_celt_state_floats.argtypes = [sz, i]
     L.nyq_celt_state_floats.restype = sz
     L.nyq_vorbis_imdct_batch_dev.argtypes = [vp, i, fp, fp, sz]

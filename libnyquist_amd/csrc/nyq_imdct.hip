@@ -42,6 +42,7 @@ struct nyq_ctx {
     // copy engines of the host-buffer entry points: uploads and downloads run beside the kernels
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     std::vector<hipEvent_t> ev_pool;
+    hipEvent_t ev_block = nullptr;       // hipEventBlockingSync: host waits on it sleep instead of spinning
     int res_imdct[4] = {0, 0, 0, 0};   // resident blocks per kernel instance (occupancy query, cached)
     int res_ifft[4] = {0, 0, 0, 0};
     int res_synth_long[4] = {0, 0, 0, 0};
@@ -163,6 +164,7 @@ extern "C" void nyq_ctx_destroy(nyq_ctx *ctx) {
     if (ctx->s_h2d) { (void)hipStreamSynchronize(ctx->s_h2d); (void)hipStreamDestroy(ctx->s_h2d); }
     if (ctx->s_d2h) { (void)hipStreamSynchronize(ctx->s_d2h); (void)hipStreamDestroy(ctx->s_d2h); }
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->ev_block) (void)hipEventDestroy(ctx->ev_block);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_vtab) (void)hipFree(ctx->d_vtab);
     if (ctx->d_trig) (void)hipFree(ctx->d_trig);
@@ -572,6 +574,15 @@ extern "C" void nyq_host_free(void *p) {
     if (p) (void)hipHostFree(p);
 }
 
+// Wait for a stream without burning a host core: callers of the host-pointer entry points run next to CPU
+// threads that have real work (the entropy stage), and hipStreamSynchronize spins.
+static int wait_blocking(nyq_ctx *ctx, hipStream_t st) {
+    if (!ctx->ev_block) NYQ_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_block, hipEventBlockingSync | hipEventDisableTiming));
+    NYQ_HIP(ctx, hipEventRecord(ctx->ev_block, st));
+    NYQ_HIP(ctx, hipEventSynchronize(ctx->ev_block));
+    return NYQ_OK;
+}
+
 static int need_copy_streams(nyq_ctx *ctx, size_t nevents) {
     if (!ctx->s_h2d) NYQ_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_h2d, hipStreamNonBlocking));
     if (!ctx->s_d2h) NYQ_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_d2h, hipStreamNonBlocking));
@@ -652,8 +663,8 @@ static int imdct_host(nyq_ctx *ctx, int shift, const float *in, const float *car
             NYQ_HIP(ctx, hipMemcpyAsync(tail + c0 * NYQ_HALF_OV, (chain ? d_to : d_t) + c0 * NYQ_HALF_OV,
                                         nc * NYQ_HALF_OV * sizeof(float), hipMemcpyDeviceToHost, ctx->s_d2h));
     }
-    NYQ_HIP(ctx, hipStreamSynchronize(ctx->s_d2h));
-    NYQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = wait_blocking(ctx, ctx->s_d2h)) != NYQ_OK) return rc;
+    if ((rc = wait_blocking(ctx, ctx->stream)) != NYQ_OK) return rc;
     return NYQ_OK;
 }
 
@@ -706,9 +717,17 @@ extern "C" size_t nyq_celt_state_floats(size_t nstreams, int channels) {
     return nsc * (NYQ_HALF_OV + kPostHist + 1) + nstreams * 6;
 }
 
-extern "C" int nyq_celt_frames_to_pcm(nyq_ctx *ctx, int LM, const float *freq, const unsigned char *transient,
-                                      const int *pf_pitch, const float *pf_gain, const int *pf_tapset, float *out,
-                                      float *state, size_t nstreams, size_t nframes, int channels) {
+// Host arrays may be windows into longer per-stream arrays: consecutive streams are `hstride` frames apart
+// (hstride == nframes: dense).  The device side is always dense; the strided case moves its data with 2-D copies.
+static hipError_t copy_rows(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t rows,
+                            hipMemcpyKind kind, hipStream_t st) {
+    if (dpitch == width && spitch == width) return hipMemcpyAsync(dst, src, width * rows, kind, st);
+    return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, kind, st);
+}
+
+static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const unsigned char *transient,
+                              const int *pf_pitch, const float *pf_gain, const int *pf_tapset, float *out,
+                              float *state, size_t nstreams, size_t nframes, int channels, size_t hstride) {
     if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm: ctx is NULL");
     if (LM < 0 || LM > 3) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm: LM must be 0..3");
     if (channels < 1 || channels > 255) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm: channels must be 1..255");
@@ -734,6 +753,9 @@ extern "C" int nyq_celt_frames_to_pcm(nyq_ctx *ctx, int LM, const float *freq, c
     // pieces of whole streams: upload of piece k+1, kernels of piece k, download of piece k-1 at the same time
     const size_t stream_bytes = nframes * (size_t)channels * N * sizeof(float);
     size_t per = (kHostPieceBytes + stream_bytes - 1) / stream_bytes;
+    // the post-filter is one sequential wave per (stream, channel): a piece of a few LONG streams would run it as
+    // a handful of waves, piece after piece -- keep at least 32 streams together so they filter side by side
+    if (per < 32) per = 32;
     if ((nstreams + per - 1) / per > kHostMaxPieces) per = (nstreams + kHostMaxPieces - 1) / kHostMaxPieces;
     const size_t npieces = (nstreams + per - 1) / per;
     rc = need_copy_streams(ctx, 2 * npieces + 1);
@@ -751,11 +773,15 @@ extern "C" int nyq_celt_frames_to_pcm(nyq_ctx *ctx, int LM, const float *freq, c
         const size_t co = s0 * channels, cn = cnt * (size_t)channels;                         // (stream, channel) units
         hipEvent_t up = ctx->ev_pool[2 * k], done = ctx->ev_pool[2 * k + 1];
         hipStream_t hs = ctx->s_h2d, ds = ctx->s_d2h;
-        NYQ_HIP(ctx, hipMemcpyAsync(d_x + xo, freq + xo, xn * sizeof(float), hipMemcpyHostToDevice, hs));
-        if (transient) NYQ_HIP(ctx, hipMemcpyAsync(d_t + fo, transient + fo, fn, hipMemcpyHostToDevice, hs));
-        NYQ_HIP(ctx, hipMemcpyAsync(d_pg + fo, pf_gain + fo, fn * sizeof(float), hipMemcpyHostToDevice, hs));
-        NYQ_HIP(ctx, hipMemcpyAsync(d_pp + fo, pf_pitch + fo, fn * sizeof(int), hipMemcpyHostToDevice, hs));
-        NYQ_HIP(ctx, hipMemcpyAsync(d_pt + fo, pf_tapset + fo, fn * sizeof(int), hipMemcpyHostToDevice, hs));
+        const size_t hx = s0 * hstride * channels * N, hf = s0 * hstride;            // host offsets of stream s0
+        const size_t xw = nframes * channels * N * sizeof(float), xp = hstride * channels * N * sizeof(float);
+        (void)xn;
+        (void)fn;
+        NYQ_HIP(ctx, copy_rows(d_x + xo, xw, freq + hx, xp, xw, cnt, hipMemcpyHostToDevice, hs));
+        if (transient) NYQ_HIP(ctx, copy_rows(d_t + fo, nframes, transient + hf, hstride, nframes, cnt, hipMemcpyHostToDevice, hs));
+        NYQ_HIP(ctx, copy_rows(d_pg + fo, nframes * 4, pf_gain + hf, hstride * 4, nframes * 4, cnt, hipMemcpyHostToDevice, hs));
+        NYQ_HIP(ctx, copy_rows(d_pp + fo, nframes * 4, pf_pitch + hf, hstride * 4, nframes * 4, cnt, hipMemcpyHostToDevice, hs));
+        NYQ_HIP(ctx, copy_rows(d_pt + fo, nframes * 4, pf_tapset + hf, hstride * 4, nframes * 4, cnt, hipMemcpyHostToDevice, hs));
         if (state) {
             NYQ_HIP(ctx, hipMemcpyAsync(d_ov + co * NYQ_HALF_OV, h_ov + co * NYQ_HALF_OV, cn * NYQ_HALF_OV * sizeof(float), hipMemcpyHostToDevice, hs));
             NYQ_HIP(ctx, hipMemcpyAsync(d_hi + co * kPostHist, h_hi + co * kPostHist, cn * kPostHist * sizeof(float), hipMemcpyHostToDevice, hs));
@@ -778,7 +804,7 @@ extern "C" int nyq_celt_frames_to_pcm(nyq_ctx *ctx, int LM, const float *freq, c
         }
         NYQ_HIP(ctx, hipEventRecord(done, ctx->stream));
         NYQ_HIP(ctx, hipStreamWaitEvent(ds, done, 0));
-        NYQ_HIP(ctx, hipMemcpyAsync(out + xo, d_out + xo, xn * sizeof(float), hipMemcpyDeviceToHost, ds));
+        NYQ_HIP(ctx, copy_rows(out + hx, xp, d_out + xo, xw, xw, cnt, hipMemcpyDeviceToHost, ds));
         if (state) {
             NYQ_HIP(ctx, hipMemcpyAsync(h_ov + co * NYQ_HALF_OV, d_ov + co * NYQ_HALF_OV, cn * NYQ_HALF_OV * sizeof(float), hipMemcpyDeviceToHost, ds));
             NYQ_HIP(ctx, hipMemcpyAsync(h_hi + co * kPostHist, d_hi + co * kPostHist, cn * kPostHist * sizeof(float), hipMemcpyDeviceToHost, ds));
@@ -786,9 +812,25 @@ extern "C" int nyq_celt_frames_to_pcm(nyq_ctx *ctx, int LM, const float *freq, c
             NYQ_HIP(ctx, hipMemcpyAsync(h_pf + s0 * 6, d_pfo + s0 * 6, cnt * 6 * sizeof(float), hipMemcpyDeviceToHost, ds));
         }
     }
-    NYQ_HIP(ctx, hipStreamSynchronize(ctx->s_d2h));
-    NYQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = wait_blocking(ctx, ctx->s_d2h)) != NYQ_OK) return rc;
+    if ((rc = wait_blocking(ctx, ctx->stream)) != NYQ_OK) return rc;
     return NYQ_OK;
+}
+
+extern "C" int nyq_celt_frames_to_pcm(nyq_ctx *ctx, int LM, const float *freq, const unsigned char *transient,
+                                      const int *pf_pitch, const float *pf_gain, const int *pf_tapset, float *out,
+                                      float *state, size_t nstreams, size_t nframes, int channels) {
+    return frames_to_pcm_core(ctx, LM, freq, transient, pf_pitch, pf_gain, pf_tapset, out, state, nstreams, nframes, channels, nframes);
+}
+
+extern "C" int nyq_celt_frames_to_pcm_window(nyq_ctx *ctx, int LM, const float *freq, const unsigned char *transient,
+                                             const int *pf_pitch, const float *pf_gain, const int *pf_tapset, float *out,
+                                             float *state, size_t nstreams, size_t nframes, int channels,
+                                             size_t frames_per_stream) {
+    if (ctx && frames_per_stream < nframes)
+        return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm_window: frames_per_stream is smaller than nframes");
+    return frames_to_pcm_core(ctx, LM, freq, transient, pf_pitch, pf_gain, pf_tapset, out, state, nstreams, nframes, channels,
+                              frames_per_stream);
 }
 
 // ---- the reference's operator names (cuda/mdct_cuda.hpp:79-103) --------------------

@@ -212,20 +212,19 @@ void parallelFor(size_t n, int threads, F &&body) {
 }  // namespace
 
 BatchOpusDecoder::BatchOpusDecoder(int device) {
-    for (int k = 0; k < 2; k++) {      // two contexts: one piece uploads while the previous one downloads
+    for (int k = 0; k < kFeeders; k++) {
         nyq_ctx *c = nullptr;
         if (nyq_ctx_create(&c, device) != NYQ_OK) {
-            if (ctx_) nyq_ctx_destroy((nyq_ctx *)ctx_);
+            for (int j = 0; j < k; j++) nyq_ctx_destroy((nyq_ctx *)ctx_[j]);
             throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(nullptr));
         }
-        (k == 0 ? ctx_ : ctx2_) = c;
+        ctx_[k] = c;
     }
 }
 
 BatchOpusDecoder::~BatchOpusDecoder() {
     if (arena_) (pinned_ ? nyq_host_free(arena_) : std::free(arena_));
-    nyq_ctx_destroy((nyq_ctx *)ctx2_);
-    nyq_ctx_destroy((nyq_ctx *)ctx_);
+    for (int k = kFeeders - 1; k >= 0; k--) nyq_ctx_destroy((nyq_ctx *)ctx_[k]);
 }
 
 // page-locked staging memory, kept from call to call (grow only); pageable memory if pinning fails
@@ -258,10 +257,51 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
             jobs[i].error = e.what();
         }
     });
+    // Memory bound: the page-locked group buffers hold freq[] and PCM of every stream of a batch, so a big job
+    // (BASELINE config 4: 1000 streams of a 224 s file = 86 GB of coefficients) runs as consecutive sub-batches
+    // of at most NYQ_BATCH_BYTES (default 6 GiB) of staging memory; files keep their order.
+    size_t budget = (size_t)6 << 30;
+    if (const char *e = std::getenv("NYQ_BATCH_BYTES")) {
+        const long long v = std::atoll(e);
+        if (v > 0) budget = (size_t)v;
+    }
+    std::vector<std::vector<size_t>> batches(1);
+    {
+        std::map<std::pair<int, int>, std::pair<size_t, size_t>> shape;   // (channels, LM) -> (streams, longest)
+        auto estimate = [&]() {
+            size_t bytes = 0;
+            for (const auto &kv : shape)
+                bytes += kv.second.first * kv.second.second * (size_t)kv.first.first * ((size_t)120 << kv.first.second) * 2 * sizeof(float);
+            return bytes;
+        };
+        for (size_t i = 0; i < nfiles; i++) {
+            if (!jobs[i].error.empty()) continue;
+            auto before = shape;
+            for (const auto &sub : jobs[i].subs) {
+                auto &e = shape[{sub.channels, sub.plan[0].LM}];
+                e.first++;
+                e.second = std::max(e.second, (size_t)sub.plan[0].nframes);
+            }
+            if (estimate() > budget && !batches.back().empty()) {
+                batches.emplace_back();
+                shape.clear();
+                for (const auto &sub : jobs[i].subs) {
+                    auto &e = shape[{sub.channels, sub.plan[0].LM}];
+                    e.first++;
+                    e.second = std::max(e.second, (size_t)sub.plan[0].nframes);
+                }
+            }
+            batches.back().push_back(i);
+        }
+    }
+    double cpuSecs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), tailSecs = 0, busySecs = 0;
+    std::atomic<long> totalFrames{0};
+    for (const std::vector<size_t> &members : batches) {
+    const auto tb = std::chrono::steady_clock::now();
     // the GPU batch is over ELEMENTARY streams: flatten (file, stream) pairs
     std::vector<StreamFrames *> sfp;
     std::vector<size_t> firstSub(nfiles, 0);
-    for (size_t i = 0; i < nfiles; i++) {
+    for (size_t i : members) {
         firstSub[i] = sfp.size();
         if (jobs[i].error.empty())
             for (auto &sub : jobs[i].subs) sfp.push_back(&sub);
@@ -312,7 +352,9 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
         std::memset(g.pp, 0, q * 4);
         std::memset(g.pt, 0, q * 4);
         std::memset(g.tr, 0, q);
-        const size_t per = std::max<size_t>(1, kPieceBytes / std::max<size_t>(1, g.maxF * g.ch * g.N * sizeof(float)));
+        // ~24 MB of freq per piece, but never fewer streams than decoding threads: long streams finish in rounds
+        // of `threads` files, and the GPU's post-filter (one sequential wave per channel) wants them together
+        const size_t per = std::max<size_t>((size_t)std::max(1, threads), kPieceBytes / std::max<size_t>(1, g.maxF * g.ch * g.N * sizeof(float)));
         for (size_t k0 = 0; k0 < g.ns; k0 += per) {
             pieces.emplace_back();
             Piece &p = pieces.back();
@@ -347,10 +389,9 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
     size_t handedOut = 0;
     std::string gpuError;
     std::vector<std::vector<float>> stateOf(n);           // decoder state of streams that continue (nstreams = 1 layout)
-    std::atomic<long> totalFrames{0};
-    double gpuBusy[2] = {0, 0};
+    double gpuBusy[kFeeders] = {0};
     auto feeder = [&](int which) {
-        nyq_ctx *ctx = (nyq_ctx *)(which == 0 ? ctx_ : ctx2_);
+        nyq_ctx *ctx = (nyq_ctx *)ctx_[which];
         for (;;) {
             size_t pi;
             {
@@ -399,8 +440,10 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
             gpuBusy[which] += std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
         }
     };
-    std::thread feed0(feeder, 0), feed1(feeder, 1);
-    parallelFor(nfiles, threads, [&](size_t i) {
+    std::vector<std::thread> feeders;
+    for (int k = 0; k < kFeeders; k++) feeders.emplace_back(feeder, k);
+    parallelFor(members.size(), threads, [&](size_t mi) {
+        const size_t i = members[mi];
         FileJob &job = jobs[i];
         if (!job.error.empty()) return;
         try {
@@ -429,16 +472,15 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
             }
         }
     });
-    auto t1 = std::chrono::steady_clock::now();
+    const auto t1 = std::chrono::steady_clock::now();
     {
         std::lock_guard<std::mutex> lk(mu);   // nothing to decode at all: let the feeders leave
         if (pieces.empty()) handedOut = 0;
     }
     cv.notify_all();
-    feed0.join();
-    feed1.join();
+    for (auto &t : feeders) t.join();
     if (!gpuError.empty()) throw std::runtime_error(gpuError);
-    nyq_ctx *ctx = (nyq_ctx *)ctx_;
+    nyq_ctx *ctx = (nyq_ctx *)ctx_[0];
     // Later segments (a stream that changes its frame size, typically a short closing frame): round r takes
     // segment r of every stream that has one, batched over the streams of equal shape (channels, frame size,
     // frame count -- no padding, so the decoder state that comes back is exact) with their states gathered
@@ -489,7 +531,8 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
     }
     // pass 3: channel mapping (opus_multistream_decoder.c:305-331), then trimming (opusfile: skip pre_skip
     // samples, stop at the last page's granule position) and the header gain
-    parallelFor(nfiles, threads, [&](size_t i) {
+    parallelFor(members.size(), threads, [&](size_t mi) {
+        const size_t i = members[mi];
         if (!jobs[i].error.empty()) return;
         const FileJob &job = jobs[i];
         const OpusHead &head = job.f.head;
@@ -538,13 +581,17 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
             }
         }
     });
-    auto t2 = std::chrono::steady_clock::now();
+    const auto t2b = std::chrono::steady_clock::now();
+    cpuSecs += std::chrono::duration<double>(t1 - tb).count();
+    tailSecs += std::chrono::duration<double>(t2b - t1).count();
+    for (int k = 0; k < kFeeders; k++) busySecs += gpuBusy[k];
+    }   // sub-batches
     for (size_t i = 0; i < nfiles; i++)
         if (!jobs[i].error.empty()) out[i].error = jobs[i].error;
     if (stats) {
-        stats->cpuSeconds = std::chrono::duration<double>(t1 - t0).count();
-        stats->gpuSeconds = std::chrono::duration<double>(t2 - t1).count();
-        stats->gpuBusySeconds = gpuBusy[0] + gpuBusy[1];
+        stats->cpuSeconds = cpuSecs;
+        stats->gpuSeconds = tailSecs;
+        stats->gpuBusySeconds = busySecs;
         stats->frames = totalFrames;
         stats->threads = threads;
     }

@@ -2,8 +2,9 @@
 //   pass 0 (CPU): Ogg demux + packet framing -> how many frames of which size every stream holds; streams
 //           of one shape form a group with page-locked freq/PCM buffers, cut into pieces of ~24 MB
 //   pass 1 (CPU, bit-serial, one thread per file): CeltDecoder -> freq[] written in place into the group
-//   pass 2 (MI355X, overlapping pass 1): as soon as the streams of a piece are decoded, one of two feeder
-//           threads (one GPU context each: a piece uploads while the previous one downloads) runs
+//   pass 2 (MI355X, overlapping pass 1): as soon as the streams of a piece are decoded, one of six feeder
+//           threads (one GPU context each: pieces upload, compute and download side by side -- the post-filter
+//           of a piece with few long streams is a handful of sequential waves, so several must be in flight) runs
 //           nyq_celt_frames_to_pcm = inverse MDCTs + TDAC chaining + post-filter + de-emphasis + interleave
 //   pass 3 (CPU threads): channel mapping, pre-skip / end trimming (RFC 7845 section 4), header gain.
 // Replaces the per-packet loop of src/OpusDecoder.cpp:95-122 (op_read_float).
@@ -45,7 +46,8 @@ public:
 
 private:
     void *arena(size_t bytes);
-    void *ctx_ = nullptr, *ctx2_ = nullptr;   // nyq_ctx*
+    static constexpr int kFeeders = 6;        // GPU contexts / feeder threads: pieces in flight at once
+    void *ctx_[kFeeders] = {nullptr};         // nyq_ctx*
     void *arena_ = nullptr;            // staging memory of the groups, kept between calls
     size_t arenaBytes_ = 0;
     bool pinned_ = false;

@@ -528,3 +528,45 @@ def test_frames_to_pcm_pipelined_pieces_equal_single_calls(ctx, oracle):
     ctx.celt_frames_to_pcm(3, freq[k:k + 1], tr[k:k + 1], pp[k:k + 1], pg[k:k + 1], pt[k:k + 1], ch, state=st1)
     second = ctx.celt_frames_to_pcm(3, freq[k + 1:k + 2], tr[k + 1:k + 2], pp[k + 1:k + 2], pg[k + 1:k + 2], pt[k + 1:k + 2], ch, state=st1)
     assert rel_rms(second[0], both[0, nf * n:]) <= 1e-6
+
+
+def test_frames_to_pcm_window_slices_equal_one_call(ctx, oracle):
+    """nyq_celt_frames_to_pcm_window on consecutive time slices of per-stream arrays, decoder state carried from
+    slice to slice, reproduces one call over the whole length: bit for bit (PCM and final state) when the slice
+    boundaries fall on multiples of 64 frames -- the in-wave carry chains of the synthesis kernels restart at the
+    same frames either way -- and to within an ulp of the TDAC mirror for any other slicing.  This is how the
+    batch decoder walks long streams in bounded memory."""
+    import ctypes as C
+    ctx.set_tables(*oracle.tables()[:2])
+    rng = np.random.default_rng(11)
+    ns, nf, ch, n = 20, 200, 2, 960
+    freq = (rng.standard_normal((ns, nf, ch, n)) * 30).astype(np.float32)
+    tr = (rng.random((ns, nf)) < 0.1).astype(np.uint8)
+    pp = rng.integers(15, 1000, (ns, nf)).astype(np.int32)
+    pg = (rng.integers(0, 9, (ns, nf)) * 0.09375).astype(np.float32)
+    pt = rng.integers(0, 3, (ns, nf)).astype(np.int32)
+    nst = int(ctx.lib.nyq_celt_state_floats(ns, ch))
+    st_all = np.zeros(nst, np.float32)
+    want = ctx.celt_frames_to_pcm(3, freq, tr, pp, pg, pt, ch, state=st_all)
+    p = lambda a, off: C.c_void_p(a.ctypes.data + off)
+
+    def sliced(lengths):
+        out = np.zeros((ns, nf * n, ch), np.float32)
+        st = np.zeros(nst, np.float32)
+        f0 = 0
+        for length in lengths:
+            rc = ctx.lib.nyq_celt_frames_to_pcm_window(ctx.h, 3, p(freq, f0 * ch * n * 4), p(tr, f0), p(pp, f0 * 4), p(pg, f0 * 4),
+                                                       p(pt, f0 * 4), p(out, f0 * n * ch * 4), p(st, 0), ns, length, ch, nf)
+            assert rc == 0
+            f0 += length
+        assert f0 == nf
+        return out, st
+
+    out, st = sliced((64, 128, 8))
+    assert np.array_equal(out, want) and np.array_equal(st, st_all)
+    out, st = sliced((32, 1, 40, 27, 100))                # ragged: chains restart elsewhere
+    assert np.abs(out - want).max() <= 2e-6 and rel_rms(out, want) <= 1e-6
+    assert rel_rms(st, st_all) <= 1e-5
+    with pytest.raises(Exception):
+        ctx._ck(ctx.lib.nyq_celt_frames_to_pcm_window(ctx.h, 3, p(freq, 0), p(tr, 0), p(pp, 0), p(pg, 0), p(pt, 0), p(out, 0), p(st, 0),
+                                                      ns, 64, ch, 32))
