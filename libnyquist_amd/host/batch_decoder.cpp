@@ -56,6 +56,10 @@ struct StreamFrames {
     float *pg0 = nullptr;
     long nframes = 0, transientCount = 0;
     int64_t samples = 0;                // decoded samples per channel over all segments
+    // progress of pass 1 on the first segment, published every `sliceLen` frames so that the GPU can start on
+    // time slices of long streams while the rest is still being entropy-decoded
+    std::atomic<long> *progress = nullptr;
+    long sliceLen = 0;
 };
 
 // one input file: its demultiplexed packets, header and elementary streams (one for mapping family 0)
@@ -99,7 +103,8 @@ void scanFile(const std::vector<uint8_t> &file, FileJob &job) {
 
 // pass 1: the bit-serial half of every frame (range decoder ... denormalisation), first segments straight
 // into the group buffers the GPU reads
-void entropyDecode(FileJob &job) {
+template <class OnSlice>
+void entropyDecode(FileJob &job, OnSlice &&onSlice) {
     const int S = job.f.head.streamCount;
     std::vector<CeltDecoder> decs;
     decs.reserve(S);
@@ -144,6 +149,10 @@ void entropyDecode(FileJob &job) {
                 (L ? L->pfTapset.data() : s.pt0)[i] = info.pfTapset;
                 (L ? L->pfGain.data() : s.pg0)[i] = info.pfGain;
                 s.transientCount += info.transient;
+                if (!L && s.sliceLen > 0 && (i + 1) % s.sliceLen == 0) {   // a whole time slice of this stream is ready
+                    s.progress->store(i + 1, std::memory_order_release);
+                    onSlice(s);
+                }
             }
             p += used;
             rem -= used;
@@ -161,16 +170,18 @@ struct Group {
     uint8_t *tr = nullptr;
 };
 
-// a run of slots of one group: the unit handed to the GPU as soon as its streams are decoded
+// a run of slots of one group, walked by the GPU in time slices of `sliceLen` frames: slice s goes out as soon as
+// every stream of the piece has been decoded that far (decoder state carried from slice to slice on the host)
 struct Piece {
     size_t group = 0, k0 = 0, k1 = 0;
-    std::atomic<int> remaining{0};
-    bool anyMore = false;               // some stream continues with another segment: fetch decoder state
-    Piece() = default;
-    Piece(const Piece &o) : group(o.group), k0(o.k0), k1(o.k1), remaining(o.remaining.load()), anyMore(o.anyMore) {}
+    size_t sliceLen = 0, nslices = 1, nextSlice = 0;   // nextSlice / inFlight: guarded by the scheduler's mutex
+    bool inFlight = false;
+    bool anyMore = false;               // some stream continues with another segment: keep the decoder state
+    std::vector<float> state;           // nyq_celt_state_floats(k1 - k0, channels), zero = fresh decoder
 };
 
-constexpr size_t kPieceBytes = (size_t)24 << 20;   // of freq per piece
+constexpr size_t kPieceBytes = (size_t)24 << 20;   // of freq per piece (short streams)
+constexpr size_t kSliceBytes = (size_t)32 << 20;   // of freq per time slice of a piece (long streams)
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -361,9 +372,16 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
             p.group = gi;
             p.k0 = k0;
             p.k1 = std::min(g.ns, k0 + per);
-            p.remaining = (int)(p.k1 - p.k0);
+            // time slices: multiples of 64 frames (the synthesis kernels' in-wave carry chains then restart at the
+            // same frames as in one call over the whole length: bit-identical results whatever the slicing)
+            const size_t frame_bytes = (p.k1 - p.k0) * g.ch * g.N * sizeof(float);
+            p.sliceLen = g.maxF;
+            if (g.maxF * frame_bytes > (kSliceBytes * 3) / 2) p.sliceLen = std::max<size_t>(64, (kSliceBytes / frame_bytes) & ~(size_t)63);
+            p.nslices = (g.maxF + p.sliceLen - 1) / p.sliceLen;
         }
     }
+    std::vector<std::atomic<long>> progress(n);
+    for (auto &pr : progress) pr.store(0, std::memory_order_relaxed);
     {   // slots -> pieces, destination pointers
         size_t pi = 0;
         for (size_t gi = 0; gi < groups.size(); gi++) {
@@ -377,42 +395,126 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
                 s.pp0 = g.pp + k * g.maxF;
                 s.pt0 = g.pt + k * g.maxF;
                 s.pg0 = g.pg + k * g.maxF;
+                s.progress = &progress[g.ids[k]];
+                s.sliceLen = pieces[pi].nslices > 1 ? (long)pieces[pi].sliceLen : 0;
                 if (s.plan.size() > 1) pieces[pi].anyMore = true;
             }
         }
     }
-    // pass 1 (CPU threads) and pass 2 (two feeder threads, one GPU context each) run at the same time: a
-    // piece goes to the GPU when the last of its streams has been decoded
+    std::vector<std::vector<float>> laterPcm(n);          // segments 1.. of the streams that have them
+    std::vector<char> finished(nfiles, 0);                // pass 3 done (each file is finished by exactly one thread)
+    std::vector<std::atomic<int>> subsLeft(nfiles);       // elementary streams of the file still on their way through the GPU
+    std::vector<size_t> fileOf(n);
+    for (size_t i : members) {
+        subsLeft[i].store(jobs[i].error.empty() ? (int)jobs[i].subs.size() : 0, std::memory_order_relaxed);
+        if (jobs[i].error.empty())
+            for (size_t k = 0; k < jobs[i].subs.size(); k++) fileOf[firstSub[i] + k] = i;
+    }
+    // pass 3: channel mapping (opus_multistream_decoder.c:305-331), then trimming (opusfile: skip pre_skip
+    // samples, stop at the last page's granule position) and the header gain
+    auto finishFile = [&](size_t i) {
+        finished[i] = 1;
+        const FileJob &job = jobs[i];
+        const OpusHead &head = job.f.head;
+        DecodedStream &d = out[i];
+        const int ch = head.channels;
+        d.channels = ch;
+        d.preSkip = head.preSkip;
+        const int64_t decoded = job.subs[0].samples;
+        for (const auto &sub : job.subs) {
+            d.frames += sub.nframes;
+            d.transientFrames += sub.transientCount;
+        }
+        const int64_t endSample = job.f.lastGranule >= 0 ? std::min<int64_t>(decoded, job.f.lastGranule) : decoded;
+        int64_t total = endSample - head.preSkip;
+        if (total < 0) total = 0;
+        d.totalSamples = total;
+        const bool contiguous = ch <= 2 && job.subs.size() == 1 && job.subs[0].channels == ch && head.outputGainQ8 == 0 &&
+                                head.mapping[0] == 0 && (ch == 1 || head.mapping[1] == 1) &&
+                                head.preSkip + total <= (int64_t)job.subs[0].plan[0].nframes * (int64_t)((size_t)120 << job.subs[0].plan[0].LM);
+        if (!contiguous) d.pcm.resize((size_t)total * ch);
+        const float gain = head.outputGainQ8 == 0 ? 1.f   // OPUS_SET_GAIN, opus_decoder_clean.c:700-712
+                                                   : (float)std::exp(0.6931471805599453094 * (6.48814081e-4 * head.outputGainQ8));
+        for (int c = 0; c < ch; c++) {
+            const int idx = head.mapping[c];
+            float *dst = d.pcm.data() + c;
+            if (idx == 255) {                              // silent channel
+                for (int64_t t = 0; t < total; t++) dst[t * ch] = 0.f;
+                continue;
+            }
+            int sub, sc;
+            if (idx < 2 * head.coupledCount) { sub = idx / 2; sc = idx & 1; }
+            else { sub = idx - head.coupledCount; sc = 0; }
+            const size_t flat = firstSub[i] + (size_t)sub;
+            const StreamFrames &s = sf[flat];
+            const Group &g = groups[s.group];
+            const int sch = s.channels;
+            // samples [0, n0) come from the group output, the rest from the later segments
+            const int64_t n0 = (int64_t)s.plan[0].nframes * (int64_t)g.N;
+            const float *src0 = g.out + s.slot * g.maxF * g.N * sch;
+            const float *src1 = laterPcm[flat].data();
+            const int64_t a = head.preSkip, b = head.preSkip + total;
+            if (ch == sch && ch <= 2 && sub == 0 && gain == 1.f && idx == c && b <= n0) {
+                if (c == 0) d.pcm.assign(src0 + a * sch, src0 + a * sch + (size_t)total * ch);   // whole frames at once, no zero-fill first
+                continue;
+            }
+            for (int64_t t = a; t < b; t++) {
+                const float v = t < n0 ? src0[t * sch + sc] : src1[(t - n0) * sch + sc];
+                dst[(t - a) * ch] = gain == 1.f ? v : v * gain;
+            }
+        }
+    };
+
+    // pass 1 (CPU threads) and pass 2 (feeder threads, one GPU context each) run at the same time: time slice s of a
+    // piece goes to the GPU when every stream of the piece has been decoded that far; slices of one piece go in
+    // order (the decoder state of the piece travels with them), different pieces side by side
     std::mutex mu;
     std::condition_variable cv;
     std::deque<size_t> ready;
-    size_t handedOut = 0;
+    size_t finishedPieces = 0;
     std::string gpuError;
     std::vector<std::vector<float>> stateOf(n);           // decoder state of streams that continue (nstreams = 1 layout)
     double gpuBusy[kFeeders] = {0};
+    for (Piece &p : pieces)
+        if (p.nslices > 1 || p.anyMore) p.state.assign(nyq_celt_state_floats(p.k1 - p.k0, groups[p.group].ch), 0.f);
+    auto offer = [&](size_t pi) {                         // call with `mu` held
+        Piece &p = pieces[pi];
+        if (p.inFlight || p.nextSlice >= p.nslices) return;
+        const Group &g = groups[p.group];
+        const long target = (long)std::min((p.nextSlice + 1) * p.sliceLen, g.maxF);
+        for (size_t k = p.k0; k < p.k1; k++)
+            if (progress[g.ids[k]].load(std::memory_order_acquire) < target) return;
+        p.inFlight = true;
+        ready.push_back(pi);
+        cv.notify_one();
+    };
     auto feeder = [&](int which) {
         nyq_ctx *ctx = (nyq_ctx *)ctx_[which];
         for (;;) {
             size_t pi;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return !ready.empty() || handedOut == pieces.size(); });
+                cv.wait(lk, [&] { return !ready.empty() || finishedPieces == pieces.size(); });
                 if (ready.empty()) return;
                 pi = ready.front();
                 ready.pop_front();
             }
-            const Piece &p = pieces[pi];
+            Piece &p = pieces[pi];
             const Group &g = groups[p.group];
-            const size_t ns = p.k1 - p.k0, nsc = ns * g.ch, so = p.k0 * g.maxF;
-            std::vector<float> state(p.anyMore ? nyq_celt_state_floats(ns, g.ch) : 0, 0.f);
+            const size_t ns = p.k1 - p.k0, nsc = ns * g.ch;
+            const size_t f0 = p.nextSlice * p.sliceLen, len = std::min(p.sliceLen, g.maxF - f0);
+            const size_t so = p.k0 * g.maxF + f0;         // first stream of the piece, first frame of the slice
+            const bool last = p.nextSlice + 1 == p.nslices;
             auto c0 = std::chrono::steady_clock::now();
             try {
-                if (nyq_celt_frames_to_pcm(ctx, g.LM, g.freq + so * g.ch * g.N, g.tr + so, g.pp + so, g.pg + so, g.pt + so,
-                                           g.out + so * g.ch * g.N, p.anyMore ? state.data() : nullptr, ns, g.maxF, g.ch) != NYQ_OK)
+                if (nyq_celt_frames_to_pcm_window(ctx, g.LM, g.freq + so * g.ch * g.N, g.tr + so, g.pp + so, g.pg + so, g.pt + so,
+                                                  g.out + so * g.ch * g.N, p.state.empty() ? nullptr : p.state.data(), ns, len, g.ch,
+                                                  g.maxF) != NYQ_OK)
                     throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(ctx));
-                // the group state is exact only for streams whose first segment fills the whole padded length;
+                // the piece's state is exact only for streams whose first segment fills the whole padded length;
                 // a shorter stream that continues with another segment is given its own call
-                for (size_t k = p.k0; p.anyMore && k < p.k1; k++) {
+                const std::vector<float> &state = p.state;
+                for (size_t k = p.k0; last && p.anyMore && k < p.k1; k++) {
                     const size_t i = g.ids[k];
                     StreamFrames &s = sf[i];
                     if (s.plan.size() < 2) continue;
@@ -438,6 +540,34 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
                 if (gpuError.empty()) gpuError = e.what();
             }
             gpuBusy[which] += std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
+            if (last) {
+                // pass 3 right here for every file all of whose streams are through (and that has no later segment):
+                // the copy into the caller's vector overlaps the entropy stage of the files still being decoded
+                for (size_t k = p.k0; k < p.k1; k++) {
+                    const size_t i = fileOf[g.ids[k]];
+                    if (subsLeft[i].fetch_sub(1, std::memory_order_acq_rel) != 1 || !jobs[i].error.empty()) continue;
+                    bool simple = true;
+                    for (const auto &sub : jobs[i].subs) simple = simple && sub.plan.size() == 1;
+                    if (simple) {
+                        try {
+                            finishFile(i);
+                        } catch (const std::exception &e) {
+                            std::lock_guard<std::mutex> lk(mu);
+                            if (gpuError.empty()) gpuError = e.what();
+                        }
+                    }
+                }
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                p.nextSlice++;
+                p.inFlight = false;
+                if (p.nextSlice == p.nslices) {
+                    if (++finishedPieces == pieces.size()) cv.notify_all();
+                } else {
+                    offer(pi);
+                }
+            }
         }
     };
     std::vector<std::thread> feeders;
@@ -447,7 +577,10 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
         FileJob &job = jobs[i];
         if (!job.error.empty()) return;
         try {
-            entropyDecode(job);
+            entropyDecode(job, [&](StreamFrames &s) {
+                std::lock_guard<std::mutex> lk(mu);
+                offer(s.piece);
+            });
         } catch (const std::exception &e) {
             job.error = e.what();
         }
@@ -462,21 +595,14 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
                 std::memset(s.pg0, 0, g.maxF * 4);
             }
             totalFrames += s.plan[0].nframes;
-            if (--pieces[s.piece].remaining == 0) {
-                {
-                    std::lock_guard<std::mutex> lk(mu);
-                    ready.push_back(s.piece);
-                    handedOut++;
-                }
-                cv.notify_all();
+            s.progress->store((long)g.maxF, std::memory_order_release);   // decoded and padded to the group's length
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                offer(s.piece);
             }
         }
     });
     const auto t1 = std::chrono::steady_clock::now();
-    {
-        std::lock_guard<std::mutex> lk(mu);   // nothing to decode at all: let the feeders leave
-        if (pieces.empty()) handedOut = 0;
-    }
     cv.notify_all();
     for (auto &t : feeders) t.join();
     if (!gpuError.empty()) throw std::runtime_error(gpuError);
@@ -485,7 +611,6 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
     // segment r of every stream that has one, batched over the streams of equal shape (channels, frame size,
     // frame count -- no padding, so the decoder state that comes back is exact) with their states gathered
     // into the batch layout and scattered back.
-    std::vector<std::vector<float>> laterPcm(n);
     for (size_t r = 1;; r++) {
         std::map<std::tuple<int, int, long>, std::vector<size_t>> shapes;
         for (size_t i = 0; i < n; i++)
@@ -529,57 +654,11 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
             }
         }
     }
-    // pass 3: channel mapping (opus_multistream_decoder.c:305-331), then trimming (opusfile: skip pre_skip
-    // samples, stop at the last page's granule position) and the header gain
+    // pass 3 for the files that could not be finished as their pieces completed (later segments, or a stream of the
+    // file in a piece that ended after the file's other streams)
     parallelFor(members.size(), threads, [&](size_t mi) {
         const size_t i = members[mi];
-        if (!jobs[i].error.empty()) return;
-        const FileJob &job = jobs[i];
-        const OpusHead &head = job.f.head;
-        DecodedStream &d = out[i];
-        const int ch = head.channels;
-        d.channels = ch;
-        d.preSkip = head.preSkip;
-        const int64_t decoded = job.subs[0].samples;
-        for (const auto &sub : job.subs) {
-            d.frames += sub.nframes;
-            d.transientFrames += sub.transientCount;
-        }
-        const int64_t endSample = job.f.lastGranule >= 0 ? std::min<int64_t>(decoded, job.f.lastGranule) : decoded;
-        int64_t total = endSample - head.preSkip;
-        if (total < 0) total = 0;
-        d.totalSamples = total;
-        d.pcm.resize((size_t)total * ch);
-        const float gain = head.outputGainQ8 == 0 ? 1.f   // OPUS_SET_GAIN, opus_decoder_clean.c:700-712
-                                                   : (float)std::exp(0.6931471805599453094 * (6.48814081e-4 * head.outputGainQ8));
-        for (int c = 0; c < ch; c++) {
-            const int idx = head.mapping[c];
-            float *dst = d.pcm.data() + c;
-            if (idx == 255) {                              // silent channel
-                for (int64_t t = 0; t < total; t++) dst[t * ch] = 0.f;
-                continue;
-            }
-            int sub, sc;
-            if (idx < 2 * head.coupledCount) { sub = idx / 2; sc = idx & 1; }
-            else { sub = idx - head.coupledCount; sc = 0; }
-            const size_t flat = firstSub[i] + (size_t)sub;
-            const StreamFrames &s = sf[flat];
-            const Group &g = groups[s.group];
-            const int sch = s.channels;
-            // samples [0, n0) come from the group output, the rest from the later segments
-            const int64_t n0 = (int64_t)s.plan[0].nframes * (int64_t)g.N;
-            const float *src0 = g.out + s.slot * g.maxF * g.N * sch;
-            const float *src1 = laterPcm[flat].data();
-            const int64_t a = head.preSkip, b = head.preSkip + total;
-            if (ch == sch && ch <= 2 && sub == 0 && gain == 1.f && idx == c && b <= n0) {
-                if (c == 0) std::memcpy(d.pcm.data(), src0 + a * sch, (size_t)total * ch * sizeof(float));   // whole frames at once
-                continue;
-            }
-            for (int64_t t = a; t < b; t++) {
-                const float v = t < n0 ? src0[t * sch + sc] : src1[(t - n0) * sch + sc];
-                dst[(t - a) * ch] = gain == 1.f ? v : v * gain;
-            }
-        }
+        if (jobs[i].error.empty() && !finished[i]) finishFile(i);
     });
     const auto t2b = std::chrono::steady_clock::now();
     cpuSecs += std::chrono::duration<double>(t1 - tb).count();
