@@ -29,7 +29,7 @@ struct DecodedStream {
 struct BatchStats {
     double cpuSeconds = 0;             // wall time of pass 1
     double gpuSeconds = 0;             // wall time after pass 1: GPU work not hidden behind it, and pass 3
-    double gpuBusySeconds = 0;         // time the two feeder threads spent inside GPU calls (PCIe included)
+    double gpuBusySeconds = 0;         // time the feeder threads spent inside GPU calls (PCIe included), summed
     long frames = 0;                   // channel-independent frame count over all streams
     int threads = 0;
 };
