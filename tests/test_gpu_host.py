@@ -157,3 +157,21 @@ def test_reference_ctest_criteria(host, name, want_int_sum):
         assert np.abs(out - full).max() <= 4e-6
         d = out.astype(np.float64) - full
         assert np.sqrt((d ** 2).mean()) <= 1e-5 * np.sqrt((full.astype(np.float64) ** 2).mean())
+
+
+@pytest.mark.gpu
+def test_long_streams_sliced_differently_decode_bit_identically(host):
+    """A 224 s stream is walked by the GPU in time slices whose length depends on how many streams share a piece
+    (one file alone: slices of 4352 frames; three files on two threads: pieces of two streams, 2176 frames).  The
+    slices end on multiples of 64 frames, so the synthesis kernels chain the same frames in-wave either way and
+    the decoded audio must not depend on the batch it was decoded in."""
+    raw = open(os.path.join(GOLDEN, "sb-reverie.opus"), "rb").read()
+    n = 21472602
+    info = np.zeros(8, np.int64)
+    alone = np.zeros(n, np.float32)
+    assert host.nyqh_nyquistio_load_buffer(raw, len(raw), alone.ctypes.data_as(C.c_void_p), n, info) == n
+    first, last = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    stats = np.zeros(4, np.float64)
+    got = host.nyqh_batch_decode(raw, len(raw), 3, 2, first.ctypes.data_as(C.c_void_p), last.ctypes.data_as(C.c_void_p), n, stats)
+    assert got == n and stats[2] == 3 * 11184
+    assert np.array_equal(first, alone) and np.array_equal(last, alone)
