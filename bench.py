@@ -75,19 +75,19 @@ def cpu_share():
     return n
 
 
-def opus_file_decode_leg(count=256):
-    """File-level decode of `count` copies of tests/golden/short.opus (220 stereo 20 ms CELT frames + one
-    closing 2.5 ms frame each, 123 kbit/s) as ONE batch through libnyquist_host (CPU entropy stage in
+def opus_file_decode_leg(count=256, fname="short.opus", n=421930):
+    """File-level decode of `count` copies of tests/golden/<fname> (short.opus: 220 stereo 20 ms CELT frames + one
+    closing 2.5 ms frame, 123 kbit/s; sb-reverie.opus: 11184 frames = 224 s, BASELINE config 4's file) as ONE
+    batch through libnyquist_host (CPU entropy stage in
     threads, IMDCT/post-filter pieces on the GPU behind it, PCIe included), and the same files through the
     reference's own NyquistIO::Load on the same number of host threads (oracle/_ref/libref_decode.so: the
     cpu_baseline of this leg)."""
     threads = cpu_share()
-    raw = open(os.path.join(ROOT, "tests", "golden", "short.opus"), "rb").read()
+    raw = open(os.path.join(ROOT, "tests", "golden", fname), "rb").read()
     H = ctypes.CDLL(os.path.join(ROOT, "libnyquist_amd", "libnyquist_host.so"))
     H.nyqh_batch_decode.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                     ctypes.c_long, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")]
     H.nyqh_batch_decode.restype = ctypes.c_long
-    n = 421930
     first = np.zeros(n, np.float32)
     stats = np.zeros(4, np.float64)
     H.nyqh_batch_decode(raw, len(raw), count, threads, first.ctypes.data_as(ctypes.c_void_p), None, n, stats)   # contexts, pinned staging
@@ -95,7 +95,7 @@ def opus_file_decode_leg(count=256):
     if got != n:
         raise RuntimeError(f"nyqh_batch_decode returned {got}")
     cpu_s, tail_s, frames, thr = stats
-    leg = {"files": count, "frames": int(frames), "host_threads": int(thr), "seconds": cpu_s + tail_s,
+    leg = {"file": fname, "files": count, "frames": int(frames), "host_threads": int(thr), "seconds": cpu_s + tail_s,
            "files_per_sec": count / (cpu_s + tail_s), "frames_per_sec": frames / (cpu_s + tail_s),
            "cpu_entropy_stage_s": cpu_s, "not_hidden_gpu_and_trim_s": tail_s,
            "x_realtime": count * (n / 2 / 48000.0) / (cpu_s + tail_s), "checksum_file0": float(first.astype(np.float64).sum())}
@@ -110,7 +110,7 @@ def opus_file_decode_leg(count=256):
         secs = R.ref_decode_bench(raw, len(raw), count, threads, ctypes.byref(ns), ctypes.byref(ck))
         leg["cpu_baseline"] = {"kind": "reference", "cores": threads, "seconds": secs, "files_per_sec": count / secs,
                                "samples_per_file": int(ns.value), "checksum_file0": ck.value,
-                               "sample": f"{count} in-memory copies of short.opus through the reference's NyquistIO::Load, {threads} threads"}
+                               "sample": f"{count} in-memory copies of {fname} through the reference's NyquistIO::Load, {threads} threads"}
         leg["vs_cpu_baseline"] = secs / (cpu_s + tail_s)
     return leg
 
@@ -364,8 +364,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_host_leg:
         try:
             file_leg = opus_file_decode_leg()
+            # BASELINE config 4's file (224 s per stream): the GPU walks it in time slices behind the entropy stage
+            file_leg["long_streams"] = opus_file_decode_leg(32, "sb-reverie.opus", 21472602)
         except Exception as e:
-            file_leg = {"error": repr(e)}
+            file_leg = {"error": repr(e)} if file_leg is None else dict(file_leg, long_streams_error=repr(e))
 
     if world > 1:
         t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
