@@ -412,6 +412,23 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
     }
     // pass 3: channel mapping (opus_multistream_decoder.c:305-331), then trimming (opusfile: skip pre_skip
     // samples, stop at the last page's granule position) and the header gain
+    // Files whose output is the group output verbatim (one mono/stereo stream, one segment, identity mapping, unit
+    // gain) are copied out slice by slice as the GPU delivers them; `window[i]` = [first, last) sample of the stream
+    // that belongs to the file after pre-skip / end trimming.
+    std::vector<char> streamed(nfiles, 0);
+    std::vector<std::pair<int64_t, int64_t>> window(nfiles);
+    for (size_t i : members) {
+        if (!jobs[i].error.empty()) continue;
+        const FileJob &job = jobs[i];
+        const OpusHead &head = job.f.head;
+        const int ch = head.channels;
+        const int64_t decoded = job.subs[0].samples;
+        const int64_t endSample = job.f.lastGranule >= 0 ? std::min<int64_t>(decoded, job.f.lastGranule) : decoded;
+        const int64_t total = std::max<int64_t>(0, endSample - head.preSkip);
+        window[i] = {head.preSkip, head.preSkip + total};
+        streamed[i] = ch <= 2 && job.subs.size() == 1 && job.subs[0].plan.size() == 1 && job.subs[0].channels == ch &&
+                      head.outputGainQ8 == 0 && head.mapping[0] == 0 && (ch == 1 || head.mapping[1] == 1);
+    }
     auto finishFile = [&](size_t i) {
         finished[i] = 1;
         const FileJob &job = jobs[i];
@@ -429,10 +446,8 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
         int64_t total = endSample - head.preSkip;
         if (total < 0) total = 0;
         d.totalSamples = total;
-        const bool contiguous = ch <= 2 && job.subs.size() == 1 && job.subs[0].channels == ch && head.outputGainQ8 == 0 &&
-                                head.mapping[0] == 0 && (ch == 1 || head.mapping[1] == 1) &&
-                                head.preSkip + total <= (int64_t)job.subs[0].plan[0].nframes * (int64_t)((size_t)120 << job.subs[0].plan[0].LM);
-        if (!contiguous) d.pcm.resize((size_t)total * ch);
+        if (streamed[i]) return;                           // its samples went out slice by slice
+        d.pcm.resize((size_t)total * ch);
         const float gain = head.outputGainQ8 == 0 ? 1.f   // OPUS_SET_GAIN, opus_decoder_clean.c:700-712
                                                    : (float)std::exp(0.6931471805599453094 * (6.48814081e-4 * head.outputGainQ8));
         for (int c = 0; c < ch; c++) {
@@ -454,10 +469,6 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
             const float *src0 = g.out + s.slot * g.maxF * g.N * sch;
             const float *src1 = laterPcm[flat].data();
             const int64_t a = head.preSkip, b = head.preSkip + total;
-            if (ch == sch && ch <= 2 && sub == 0 && gain == 1.f && idx == c && b <= n0) {
-                if (c == 0) d.pcm.assign(src0 + a * sch, src0 + a * sch + (size_t)total * ch);   // whole frames at once, no zero-fill first
-                continue;
-            }
             for (int64_t t = a; t < b; t++) {
                 const float v = t < n0 ? src0[t * sch + sc] : src1[(t - n0) * sch + sc];
                 dst[(t - a) * ch] = gain == 1.f ? v : v * gain;
@@ -511,6 +522,18 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
                                                   g.out + so * g.ch * g.N, p.state.empty() ? nullptr : p.state.data(), ns, len, g.ch,
                                                   g.maxF) != NYQ_OK)
                     throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(ctx));
+                // hand the slice's samples to the files that take them verbatim
+                for (size_t k = p.k0; k < p.k1; k++) {
+                    const size_t i = fileOf[g.ids[k]];
+                    if (!streamed[i]) continue;
+                    const int64_t lo = std::max<int64_t>(window[i].first, (int64_t)(f0 * g.N));
+                    const int64_t hi = std::min<int64_t>(window[i].second, (int64_t)((f0 + len) * g.N));
+                    if (hi <= lo) continue;
+                    std::vector<float> &pcm = out[i].pcm;
+                    if (pcm.empty()) pcm.reserve((size_t)(window[i].second - window[i].first) * g.ch);
+                    const float *src = g.out + k * g.maxF * g.N * g.ch;
+                    pcm.insert(pcm.end(), src + lo * g.ch, src + hi * g.ch);
+                }
                 // the piece's state is exact only for streams whose first segment fills the whole padded length;
                 // a shorter stream that continues with another segment is given its own call
                 const std::vector<float> &state = p.state;
@@ -666,7 +689,10 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
     for (int k = 0; k < kFeeders; k++) busySecs += gpuBusy[k];
     }   // sub-batches
     for (size_t i = 0; i < nfiles; i++)
-        if (!jobs[i].error.empty()) out[i].error = jobs[i].error;
+        if (!jobs[i].error.empty()) {
+            out[i].error = jobs[i].error;
+            out[i].pcm.clear();                            // no partial audio of a file that failed half way
+        }
     if (stats) {
         stats->cpuSeconds = cpuSecs;
         stats->gpuSeconds = tailSecs;
