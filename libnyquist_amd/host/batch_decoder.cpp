@@ -174,7 +174,8 @@ struct Group {
 // every stream of the piece has been decoded that far (decoder state carried from slice to slice on the host)
 struct Piece {
     size_t group = 0, k0 = 0, k1 = 0;
-    size_t sliceLen = 0, nslices = 1, nextSlice = 0;   // nextSlice / inFlight: guarded by the scheduler's mutex
+    size_t sliceLen = 0, nslices = 1, nextSlice = 0;   // nextSlice / inFlight / appendTurn: guarded by the scheduler's mutex
+    size_t appendTurn = 0;              // slices hand their samples to the files in order
     bool inFlight = false;
     bool anyMore = false;               // some stream continues with another segment: keep the decoder state
     std::vector<float> state;           // nyq_celt_state_floats(k1 - k0, channels), zero = fresh decoder
@@ -480,7 +481,7 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
     // piece goes to the GPU when every stream of the piece has been decoded that far; slices of one piece go in
     // order (the decoder state of the piece travels with them), different pieces side by side
     std::mutex mu;
-    std::condition_variable cv;
+    std::condition_variable cv, cvAppend;
     std::deque<size_t> ready;
     size_t finishedPieces = 0;
     std::string gpuError;
@@ -515,13 +516,28 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
             const size_t ns = p.k1 - p.k0, nsc = ns * g.ch;
             const size_t f0 = p.nextSlice * p.sliceLen, len = std::min(p.sliceLen, g.maxF - f0);
             const size_t so = p.k0 * g.maxF + f0;         // first stream of the piece, first frame of the slice
-            const bool last = p.nextSlice + 1 == p.nslices;
+            const size_t myslice = p.nextSlice;
+            const bool last = myslice + 1 == p.nslices;
+            bool released = false;
             auto c0 = std::chrono::steady_clock::now();
             try {
                 if (nyq_celt_frames_to_pcm_window(ctx, g.LM, g.freq + so * g.ch * g.N, g.tr + so, g.pp + so, g.pg + so, g.pt + so,
                                                   g.out + so * g.ch * g.N, p.state.empty() ? nullptr : p.state.data(), ns, len, g.ch,
                                                   g.maxF) != NYQ_OK)
                     throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(ctx));
+                // the GPU part of the slice is done: the piece's next slice may start (its kernels only need the
+                // state, which is back on the host) while this thread copies samples out
+                if (!last) {
+                    std::lock_guard<std::mutex> lk(mu);
+                    p.nextSlice++;
+                    p.inFlight = false;
+                    released = true;
+                    offer(pi);
+                }
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cvAppend.wait(lk, [&] { return p.appendTurn == myslice; });
+                }
                 // hand the slice's samples to the files that take them verbatim
                 for (size_t k = p.k0; k < p.k1; k++) {
                     const size_t i = fileOf[g.ids[k]];
@@ -534,6 +550,11 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
                     const float *src = g.out + k * g.maxF * g.N * g.ch;
                     pcm.insert(pcm.end(), src + lo * g.ch, src + hi * g.ch);
                 }
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    p.appendTurn = myslice + 1;
+                }
+                cvAppend.notify_all();
                 // the piece's state is exact only for streams whose first segment fills the whole padded length;
                 // a shorter stream that continues with another segment is given its own call
                 const std::vector<float> &state = p.state;
@@ -582,13 +603,20 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
                 }
             }
             {
-                std::lock_guard<std::mutex> lk(mu);
-                p.nextSlice++;
-                p.inFlight = false;
-                if (p.nextSlice == p.nslices) {
-                    if (++finishedPieces == pieces.size()) cv.notify_all();
-                } else {
-                    offer(pi);
+                std::unique_lock<std::mutex> lk(mu);
+                cvAppend.wait(lk, [&] { return p.appendTurn >= myslice; });   // (earlier slices always get there)
+                if (p.appendTurn == myslice) {              // an error above skipped the hand-over: do not block later slices
+                    p.appendTurn = myslice + 1;
+                    cvAppend.notify_all();
+                }
+                if (!released) {
+                    p.nextSlice++;
+                    p.inFlight = false;
+                    if (p.nextSlice == p.nslices) {
+                        if (++finishedPieces == pieces.size()) cv.notify_all();
+                    } else {
+                        offer(pi);
+                    }
                 }
             }
         }
