@@ -137,6 +137,36 @@ def encode_surround(name, channels, frame, bitrate, seconds, seed):
     return raw, streams.value, coupled.value
 
 
+def encode_two_sizes(seconds, seed, bitrate=64000):
+    """stereo, 20 ms frames and then ONE closing 10 ms frame: long enough (10 s) for the batch decoder to walk
+    it in time slices when 16 copies share a piece, with a later segment of another frame size on top"""
+    err = C.c_int(0)
+    enc = R.opus_encoder_create(48000, 2, RESTRICTED_LOWDELAY, C.byref(err))
+    assert enc and err.value == 0
+    ctl_set(enc, SET_BITRATE, bitrate)
+    preskip = ctl_get(enc, GET_LOOKAHEAD)
+    pcm = signal(seconds, 2, seed)
+    total = pcm.shape[0]
+    n20 = (total + preskip) // 960                               # whole 20 ms frames, then 10 ms ones for the rest
+    rest = total + preskip - n20 * 960
+    n10 = (rest + 479) // 480
+    padded = np.zeros((n20 * 960 + n10 * 480, 2), np.float32)
+    padded[:total] = pcm
+    packets, sizes = [], []
+    buf = C.create_string_buffer(4000)
+    pos = 0
+    for frame in [960] * n20 + [480] * n10:
+        blk = np.ascontiguousarray(padded[pos:pos + frame])
+        nb = R.opus_encode_float(enc, blk.ctypes.data_as(C.POINTER(C.c_float)), frame, buf, 4000)
+        assert nb > 0
+        packets.append(buf.raw[:nb])
+        sizes.append(frame)
+        pos += frame
+    R.opus_encoder_destroy(enc)
+    head = b"OpusHead" + bytes([1, 2]) + struct.pack("<HIh", preskip, 48000, 0) + bytes([0])
+    return oggopus.mux_packets_sized(head, packets, sizes, preskip, total), n20, n10
+
+
 SURROUND = [
     ("surround71_20ms_320k", 8, 960, 320000, 1.0),
     ("surround51_10ms_192k", 6, 480, 192000, 0.8),
@@ -183,6 +213,18 @@ def main():
     # a SILK stream (VOIP application at 12 kbit/s): NOT decodable by this library by design -- the error path
     raw, _ = encode("silk_voip_12k", 1, 960, 12000, True, "fb", 5, 0.4, 3000, application=2048)
     open(os.path.join(out_dir, "unsupported_silk_voip_12k.opus"), "wb").write(raw)
+    raw, n20, n10 = encode_two_sizes(10.0, 4000)
+    name = "twosize_st_20ms_then_10ms_10s"
+    open(os.path.join(out_dir, name + ".opus"), "wb").write(raw)
+    info = (C.c_long * 3)()
+    n = R.ref_decode_pcm(raw, len(raw), None, 0, info)
+    assert n > 0 and n10 >= 1, (n, n10)
+    pcm = np.zeros(n, np.float32)
+    assert R.ref_decode_pcm(raw, len(raw), pcm.ctypes.data_as(C.POINTER(C.c_float)), n, info) == n
+    dig[name + "/meta"] = np.array([2, 960, n, len(raw), n20, n10], np.int64)
+    dig[name + "/sum"] = np.array([pcm.astype(np.float64).sum(), (pcm.astype(np.float64) ** 2).sum()])
+    dig[name + "/every5"] = pcm[::5].copy()
+    print(f"{name}: {len(raw)} bytes, {n20} x 20 ms + {n10} x 10 ms frames, {n} samples")
     for k, (name, ch, frame, br, secs) in enumerate(SURROUND):
         raw, nstreams, ncoupled = encode_surround(name, ch, frame, br, secs, 2000 + k)
         open(os.path.join(out_dir, name + ".opus"), "wb").write(raw)

@@ -175,3 +175,20 @@ def test_long_streams_sliced_differently_decode_bit_identically(host):
     got = host.nyqh_batch_decode(raw, len(raw), 3, 2, first.ctypes.data_as(C.c_void_p), last.ctypes.data_as(C.c_void_p), n, stats)
     assert got == n and stats[2] == 3 * 11184
     assert np.array_equal(first, alone) and np.array_equal(last, alone)
+
+
+@pytest.mark.gpu
+def test_sliced_piece_with_a_later_segment(host):
+    """Sixteen copies of a 10 s stream (500 frames of 20 ms and one closing 10 ms frame) on sixteen threads share
+    one piece, which is long enough to be walked in time slices; the closing frame is a later segment that starts
+    from the decoder state the last slice leaves behind.  Same samples as the file decoded alone (one slice)."""
+    raw = open(os.path.join(GOLDEN, "corpus", "twosize_st_20ms_then_10ms_10s.opus"), "rb").read()
+    n = 960000
+    info = np.zeros(8, np.int64)
+    alone = np.zeros(n, np.float32)
+    assert host.nyqh_nyquistio_load_buffer(raw, len(raw), alone.ctypes.data_as(C.c_void_p), n, info) == n
+    first, last = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    stats = np.zeros(4, np.float64)
+    got = host.nyqh_batch_decode(raw, len(raw), 16, 16, first.ctypes.data_as(C.c_void_p), last.ctypes.data_as(C.c_void_p), n, stats)
+    assert got == n and stats[2] == 16 * 501
+    assert np.array_equal(first, alone) and np.array_equal(last, alone)

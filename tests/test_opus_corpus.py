@@ -18,7 +18,7 @@ from test_host_decoder import entropy_decode, load_host
 
 NAMES = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GOLDEN, "corpus", "*.opus"))
                if not os.path.basename(p).startswith("unsupported_"))
-FAMILY0 = [n for n in NAMES if not n.startswith("surround")]   # mono / stereo: one elementary stream
+FAMILY0 = [n for n in NAMES if not n.startswith(("surround", "twosize"))]   # one elementary stream, one frame size
 
 
 @pytest.fixture(scope="module")
@@ -32,7 +32,7 @@ def digest():
 
 
 def test_corpus_is_complete(digest):
-    assert len(FAMILY0) == 16 and len(NAMES) == 18
+    assert len(FAMILY0) == 16 and len(NAMES) == 19
     sizes = {int(digest[n + "/meta"][1]) for n in FAMILY0}
     assert sizes == {120, 240, 480, 960}                    # every CELT frame size
     assert {int(digest[n + "/meta"][0]) for n in NAMES} == {1, 2, 6, 8}

@@ -105,3 +105,26 @@ def mux_packets(head, packets, preskip, frame_samples, total_samples, serial=0x4
         out.append(hdr[:22] + struct.pack("<I", crc) + hdr[26:] + body)
         seq += 1
     return b"".join(out)
+
+
+def mux_packets_sized(head, packets, sizes, preskip, total_samples, serial=0x4E595132, per_page=8):
+    """like mux_packets, for packets of different durations (`sizes[i]` samples at 48 kHz)"""
+    tags = b"OpusTags" + struct.pack("<I", 8) + b"nyq-test" + struct.pack("<I", 0)
+    out = [page(serial, 0, 0, head, 2), page(serial, 1, 0, tags, 0)]
+    seq, done, i, n = 2, 0, 0, len(packets)
+    while i < n:
+        group = packets[i:i + per_page]
+        done += sum(sizes[i:i + len(group)])
+        i += len(group)
+        last = i >= n
+        gran = min(done, preskip + total_samples) if last else done
+        lac, body = [], b""
+        for pk in group:
+            lac += [255] * (len(pk) // 255) + [len(pk) % 255]
+            body += pk
+        assert len(lac) <= 255
+        hdr = b"OggS" + bytes([0, 4 if last else 0]) + struct.pack("<qIII", gran, serial, seq, 0) + bytes([len(lac)]) + bytes(lac)
+        crc = ogg_crc(hdr + body)
+        out.append(hdr[:22] + struct.pack("<I", crc) + hdr[26:] + body)
+        seq += 1
+    return b"".join(out)
