@@ -146,4 +146,38 @@ long nyqh_batch_decode(const unsigned char *file, long size, long count, int thr
     }
 }
 
+// A batch of DIFFERENT files (mixed shapes: channel counts, frame sizes, lengths, multistream) as one call.
+// nsamples[i] = interleaved sample count of file i (-1: that file failed), out = all decoded files back to back
+// (if capacity suffices).  Returns the total sample count, or -1 if the call itself failed.
+long nyqh_batch_decode_files(const unsigned char *const *files, const long *sizes, long count, int threads, long *nsamples,
+                             float *out, long capacity) {
+    try {
+        std::vector<std::vector<uint8_t>> bufs((size_t)count);
+        std::vector<const std::vector<uint8_t> *> ptrs((size_t)count);
+        for (long i = 0; i < count; i++) {
+            bufs[i].assign(files[i], files[i] + sizes[i]);
+            ptrs[i] = &bufs[i];
+        }
+        static nyq_host::BatchOpusDecoder &dec = *new nyq_host::BatchOpusDecoder(0);
+        std::vector<nyq_host::DecodedStream> res;
+        dec.decode(ptrs, res, nullptr, threads);
+        long total = 0;
+        for (long i = 0; i < count; i++) {
+            nsamples[i] = res[i].error.empty() ? (long)res[i].pcm.size() : -1;
+            if (nsamples[i] > 0) total += nsamples[i];
+        }
+        if (out && capacity >= total) {
+            long pos = 0;
+            for (long i = 0; i < count; i++)
+                if (nsamples[i] > 0) {
+                    std::memcpy(out + pos, res[i].pcm.data(), (size_t)nsamples[i] * sizeof(float));
+                    pos += nsamples[i];
+                }
+        }
+        return total;
+    } catch (const std::exception &) {
+        return -1;
+    }
+}
+
 }  // extern "C"

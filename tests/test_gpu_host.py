@@ -192,3 +192,43 @@ def test_sliced_piece_with_a_later_segment(host):
     got = host.nyqh_batch_decode(raw, len(raw), 16, 16, first.ctypes.data_as(C.c_void_p), last.ctypes.data_as(C.c_void_p), n, stats)
     assert got == n and stats[2] == 16 * 501
     assert np.array_equal(first, alone) and np.array_equal(last, alone)
+
+
+@pytest.mark.gpu
+def test_mixed_batch_every_file_as_if_decoded_alone(host):
+    """One batch of everything at once: mono and stereo, all four frame sizes, 5.1 and 7.1 multistream files, files
+    that close with a frame of another size, very different lengths (so groups are padded and a short stream with a
+    later segment needs its state recomputed), a SILK file that must fail alone, several copies of some files.
+    Every file must come out exactly as from NyquistIO::Load on that file alone."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(GOLDEN, "corpus", "*.opus"))) + [os.path.join(GOLDEN, "short.opus")]
+    paths = paths + paths[::3] + [os.path.join(GOLDEN, "short.opus")] * 3
+    raws = [open(p, "rb").read() for p in paths]
+    alone = []
+    info = np.zeros(8, np.int64)
+    for r in raws:
+        n = host.nyqh_nyquistio_load_buffer(r, len(r), None, 0, info)
+        if n < 0:
+            alone.append(None)
+            continue
+        a = np.zeros(n, np.float32)
+        assert host.nyqh_nyquistio_load_buffer(r, len(r), a.ctypes.data_as(C.c_void_p), n, info) == n
+        alone.append(a)
+    assert sum(a is None for a in alone) == sum("unsupported_" in p for p in paths) >= 1      # only the SILK file fails
+    cnt = len(raws)
+    files = (C.c_char_p * cnt)(*raws)
+    sizes = (C.c_long * cnt)(*[len(r) for r in raws])
+    ns = (C.c_long * cnt)()
+    cap = sum(a.size for a in alone if a is not None)
+    for threads in (16, 3):
+        out = np.zeros(cap, np.float32)
+        total = host.nyqh_batch_decode_files(files, sizes, cnt, threads, ns, out.ctypes.data_as(C.c_void_p), cap)
+        assert total == cap
+        pos = 0
+        for i, a in enumerate(alone):
+            if a is None:
+                assert ns[i] == -1
+                continue
+            assert ns[i] == a.size, paths[i]
+            assert np.array_equal(out[pos:pos + a.size], a), paths[i]
+            pos += a.size
