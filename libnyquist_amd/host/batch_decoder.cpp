@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -221,6 +222,465 @@ void parallelFor(size_t n, int threads, F &&body) {
     for (auto &t : pool) t.join();
 }
 
+
+// copy the decoder state of stream `k` out of / into the layout nyq_celt_state_floats(ns, ch) describes:
+// [overlap ns*ch*60 | post-filter history ns*ch*1088 | de-emphasis ns*ch | post-filter parameters ns*6]
+void stateOfStream(const float *batch, size_t ns, int ch, size_t k, float *one) {
+    const size_t nsc = ns * ch;
+    const float *ov = batch, *hi = ov + nsc * 60, *de = hi + nsc * 1088, *pf = de + nsc;
+    std::memcpy(one, ov + k * ch * 60, sizeof(float) * ch * 60); one += ch * 60;
+    std::memcpy(one, hi + k * ch * 1088, sizeof(float) * ch * 1088); one += ch * 1088;
+    std::memcpy(one, de + k * ch, sizeof(float) * ch); one += ch;
+    std::memcpy(one, pf + k * 6, sizeof(float) * 6);
+}
+void stateIntoBatch(float *batch, size_t ns, int ch, size_t k, const float *one) {
+    const size_t nsc = ns * ch;
+    float *ov = batch, *hi = ov + nsc * 60, *de = hi + nsc * 1088, *pf = de + nsc;
+    std::memcpy(ov + k * ch * 60, one, sizeof(float) * ch * 60); one += ch * 60;
+    std::memcpy(hi + k * ch * 1088, one, sizeof(float) * ch * 1088); one += ch * 1088;
+    std::memcpy(de + k * ch, one, sizeof(float) * ch); one += ch;
+    std::memcpy(pf + k * 6, one, sizeof(float) * 6);
+}
+
+// One memory-bounded sub-batch of files on its way through passes 1-3 (see batch_decoder.hpp).
+class SubBatch {
+public:
+    SubBatch(std::vector<FileJob> &jobs, std::vector<DecodedStream> &out, const std::vector<size_t> &members, void *const *ctxs,
+             int nfeeders, int threads, const std::function<void *(size_t)> &arena)
+        : jobs_(jobs), out_(out), members_(members), ctxs_(ctxs), nfeeders_(nfeeders), threads_(threads), arena_(arena),
+          firstSub_(jobs.size(), 0), finished_(jobs.size(), 0), streamed_(jobs.size(), 0), window_(jobs.size()),
+          subsLeft_(jobs.size()), gpuBusy_((size_t)nfeeders, 0.0) {}
+
+    // returns when every file of the sub-batch is decoded (or has its error set); throws if the GPU failed
+    void run() {
+        const auto tb = std::chrono::steady_clock::now();
+        flatten();
+        layout();
+        planOutput();
+        std::vector<std::thread> feeders;
+        for (int k = 0; k < nfeeders_; k++) feeders.emplace_back([this, k] { feederLoop(k); });
+        parallelFor(members_.size(), threads_, [&](size_t mi) { decodeFile(members_[mi]); });
+        const auto t1 = std::chrono::steady_clock::now();
+        cv_.notify_all();
+        for (auto &t : feeders) t.join();
+        if (!gpuError_.empty()) throw std::runtime_error(gpuError_);
+        laterSegments();
+        // pass 3 for the files that could not be finished as their pieces completed (later segments, or a stream of
+        // the file in a piece that ended after the file's other streams)
+        parallelFor(members_.size(), threads_, [&](size_t mi) {
+            const size_t i = members_[mi];
+            if (jobs_[i].error.empty() && !finished_[i]) finishFile(i);
+        });
+        cpuSeconds = std::chrono::duration<double>(t1 - tb).count();
+        tailSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+        for (double b : gpuBusy_) busySeconds += b;
+    }
+
+    double cpuSeconds = 0, tailSeconds = 0, busySeconds = 0;
+    std::atomic<long> frames{0};
+
+private:
+    StreamFrames &sf(size_t flat) { return *sfp_[flat]; }
+
+    // the GPU batch is over ELEMENTARY streams: flatten (file, stream) pairs
+    void flatten() {
+        for (size_t i : members_) {
+            firstSub_[i] = sfp_.size();
+            if (jobs_[i].error.empty())
+                for (auto &sub : jobs_[i].subs) sfp_.push_back(&sub);
+        }
+        fileOf_.resize(sfp_.size());
+        for (size_t i : members_) {
+            subsLeft_[i].store(jobs_[i].error.empty() ? (int)jobs_[i].subs.size() : 0, std::memory_order_relaxed);
+            if (jobs_[i].error.empty())
+                for (size_t k = 0; k < jobs_[i].subs.size(); k++) fileOf_[firstSub_[i] + k] = i;
+        }
+        stateOf_.resize(sfp_.size());
+        laterPcm_.resize(sfp_.size());
+    }
+
+    // layout: the first segment of every stream, grouped by (channels, LM) and padded to the longest; a group is cut
+    // into pieces of consecutive slots, a piece into time slices
+    void layout() {
+        const size_t n = sfp_.size();
+        std::map<std::pair<int, int>, size_t> groupOf;
+        for (size_t i = 0; i < n; i++) {
+            const std::pair<int, int> key{sf(i).channels, sf(i).plan[0].LM};
+            auto it = groupOf.find(key);
+            if (it == groupOf.end()) {
+                it = groupOf.emplace(key, groups_.size()).first;
+                groups_.emplace_back();
+                groups_.back().ch = key.first;
+                groups_.back().LM = key.second;
+                groups_.back().N = (size_t)120 << key.second;
+            }
+            Group &g = groups_[it->second];
+            sf(i).group = it->second;
+            sf(i).slot = g.ids.size();
+            g.ids.push_back(i);
+            g.maxF = std::max(g.maxF, (size_t)sf(i).plan[0].nframes);
+        }
+        size_t bytes = 0;
+        for (Group &g : groups_) {
+            g.ns = g.ids.size();
+            const size_t x = g.ns * g.maxF * g.ch * g.N * sizeof(float), q = g.ns * g.maxF;
+            bytes += 2 * align256(x) + 3 * align256(q * 4) + align256(q);
+        }
+        char *base = (char *)arena_(bytes);
+        for (size_t gi = 0; gi < groups_.size(); gi++) {
+            Group &g = groups_[gi];
+            const size_t x = g.ns * g.maxF * g.ch * g.N * sizeof(float), q = g.ns * g.maxF;
+            g.freq = (float *)base; base += align256(x);
+            g.out = (float *)base; base += align256(x);
+            g.pg = (float *)base; base += align256(q * 4);
+            g.pp = (int *)base; base += align256(q * 4);
+            g.pt = (int *)base; base += align256(q * 4);
+            g.tr = (uint8_t *)base; base += align256(q);
+            std::memset(g.pg, 0, q * 4);                        // padded frames: no post-filter, not transient
+            std::memset(g.pp, 0, q * 4);
+            std::memset(g.pt, 0, q * 4);
+            std::memset(g.tr, 0, q);
+            // ~24 MB of freq per piece, but never fewer streams than decoding threads: long streams finish in rounds
+            // of `threads` files, and the GPU's post-filter (one sequential wave per channel) wants them together
+            const size_t per = std::max<size_t>((size_t)std::max(1, threads_), kPieceBytes / std::max<size_t>(1, g.maxF * g.ch * g.N * sizeof(float)));
+            for (size_t k0 = 0; k0 < g.ns; k0 += per) {
+                pieces_.emplace_back();
+                Piece &p = pieces_.back();
+                p.group = gi;
+                p.k0 = k0;
+                p.k1 = std::min(g.ns, k0 + per);
+                // time slices: multiples of 64 frames (the synthesis kernels' in-wave carry chains then restart at the
+                // same frames as in one call over the whole length: bit-identical results whatever the slicing)
+                const size_t frame_bytes = (p.k1 - p.k0) * g.ch * g.N * sizeof(float);
+                p.sliceLen = g.maxF;
+                if (g.maxF * frame_bytes > (kSliceBytes * 3) / 2) p.sliceLen = std::max<size_t>(64, (kSliceBytes / frame_bytes) & ~(size_t)63);
+                p.nslices = (g.maxF + p.sliceLen - 1) / p.sliceLen;
+            }
+        }
+        progress_ = std::vector<std::atomic<long>>(n);
+        for (auto &pr : progress_) pr.store(0, std::memory_order_relaxed);
+        size_t pi = 0;                                          // slots -> pieces, destination pointers
+        for (size_t gi = 0; gi < groups_.size(); gi++) {
+            Group &g = groups_[gi];
+            for (size_t k = 0; k < g.ns; k++) {
+                while (!(pieces_[pi].group == gi && k >= pieces_[pi].k0 && k < pieces_[pi].k1)) pi++;
+                StreamFrames &s = sf(g.ids[k]);
+                s.piece = pi;
+                s.freq0 = g.freq + k * g.maxF * g.ch * g.N;
+                s.tr0 = g.tr + k * g.maxF;
+                s.pp0 = g.pp + k * g.maxF;
+                s.pt0 = g.pt + k * g.maxF;
+                s.pg0 = g.pg + k * g.maxF;
+                s.progress = &progress_[g.ids[k]];
+                s.sliceLen = pieces_[pi].nslices > 1 ? (long)pieces_[pi].sliceLen : 0;
+                if (s.plan.size() > 1) pieces_[pi].anyMore = true;
+            }
+        }
+        for (Piece &p : pieces_)
+            if (p.nslices > 1 || p.anyMore) p.state.assign(nyq_celt_state_floats(p.k1 - p.k0, groups_[p.group].ch), 0.f);
+    }
+
+    // Files whose output is the group output verbatim (one mono/stereo stream, one segment, identity mapping, unit
+    // gain) are copied out slice by slice as the GPU delivers them; window_[i] = [first, last) sample of the stream
+    // that belongs to the file after pre-skip / end trimming.
+    void planOutput() {
+        for (size_t i : members_) {
+            if (!jobs_[i].error.empty()) continue;
+            const FileJob &job = jobs_[i];
+            const OpusHead &head = job.f.head;
+            const int ch = head.channels;
+            const int64_t decoded = job.subs[0].samples;
+            const int64_t endSample = job.f.lastGranule >= 0 ? std::min<int64_t>(decoded, job.f.lastGranule) : decoded;
+            const int64_t total = std::max<int64_t>(0, endSample - head.preSkip);
+            window_[i] = {head.preSkip, head.preSkip + total};
+            streamed_[i] = ch <= 2 && job.subs.size() == 1 && job.subs[0].plan.size() == 1 && job.subs[0].channels == ch &&
+                           head.outputGainQ8 == 0 && head.mapping[0] == 0 && (ch == 1 || head.mapping[1] == 1);
+        }
+    }
+
+    // pass 1 for one file (a decoding thread)
+    void decodeFile(size_t i) {
+        FileJob &job = jobs_[i];
+        if (!job.error.empty()) return;
+        try {
+            entropyDecode(job, [&](StreamFrames &s) {
+                std::lock_guard<std::mutex> lk(mu_);
+                offer(s.piece);
+            });
+        } catch (const std::exception &e) {
+            job.error = e.what();
+        }
+        for (StreamFrames &s : job.subs) {
+            const Group &g = groups_[s.group];
+            const size_t have = job.error.empty() ? (size_t)s.plan[0].nframes : 0;   // a failed file plays as silence
+            std::memset(s.freq0 + have * g.ch * g.N, 0, (g.maxF - have) * g.ch * g.N * sizeof(float));
+            if (!job.error.empty()) {
+                std::memset(s.tr0, 0, g.maxF);
+                std::memset(s.pp0, 0, g.maxF * 4);
+                std::memset(s.pt0, 0, g.maxF * 4);
+                std::memset(s.pg0, 0, g.maxF * 4);
+            }
+            frames += s.plan[0].nframes;
+            s.progress->store((long)g.maxF, std::memory_order_release);   // decoded and padded to the group's length
+            std::lock_guard<std::mutex> lk(mu_);
+            offer(s.piece);
+        }
+    }
+
+    // queue the next slice of piece `pi` if every stream of the piece has been decoded that far (call with mu_ held)
+    void offer(size_t pi) {
+        Piece &p = pieces_[pi];
+        if (p.inFlight || p.nextSlice >= p.nslices) return;
+        const Group &g = groups_[p.group];
+        const long target = (long)std::min((p.nextSlice + 1) * p.sliceLen, g.maxF);
+        for (size_t k = p.k0; k < p.k1; k++)
+            if (progress_[g.ids[k]].load(std::memory_order_acquire) < target) return;
+        p.inFlight = true;
+        ready_.push_back(pi);
+        cv_.notify_one();
+    }
+
+    // pass 2: one feeder thread = one GPU context; slices of one piece go in order (the decoder state of the piece
+    // travels with them on the host), different pieces side by side
+    void feederLoop(int which) {
+        nyq_ctx *ctx = (nyq_ctx *)ctxs_[which];
+        for (;;) {
+            size_t pi;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return !ready_.empty() || finishedPieces_ == pieces_.size(); });
+                if (ready_.empty()) return;
+                pi = ready_.front();
+                ready_.pop_front();
+            }
+            Piece &p = pieces_[pi];
+            const Group &g = groups_[p.group];
+            const size_t myslice = p.nextSlice;
+            const size_t f0 = myslice * p.sliceLen, len = std::min(p.sliceLen, g.maxF - f0);
+            const size_t so = p.k0 * g.maxF + f0;         // first stream of the piece, first frame of the slice
+            const bool last = myslice + 1 == p.nslices;
+            bool released = false;
+            const auto c0 = std::chrono::steady_clock::now();
+            try {
+                if (nyq_celt_frames_to_pcm_window(ctx, g.LM, g.freq + so * g.ch * g.N, g.tr + so, g.pp + so, g.pg + so, g.pt + so,
+                                                  g.out + so * g.ch * g.N, p.state.empty() ? nullptr : p.state.data(), p.k1 - p.k0, len,
+                                                  g.ch, g.maxF) != NYQ_OK)
+                    throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(ctx));
+                // the GPU part of the slice is done: the piece's next slice may start (its kernels only need the
+                // state, which is back on the host) while this thread copies samples out
+                if (!last) {
+                    std::lock_guard<std::mutex> lk(mu_);
+                    p.nextSlice++;
+                    p.inFlight = false;
+                    released = true;
+                    offer(pi);
+                }
+                {
+                    std::unique_lock<std::mutex> lk(mu_);
+                    cvAppend_.wait(lk, [&] { return p.appendTurn == myslice; });
+                }
+                handOver(p, f0, len);
+                {
+                    std::lock_guard<std::mutex> lk(mu_);
+                    p.appendTurn = myslice + 1;
+                }
+                cvAppend_.notify_all();
+                if (last && p.anyMore) keepStates(ctx, p);
+            } catch (const std::exception &e) {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (gpuError_.empty()) gpuError_ = e.what();
+            }
+            gpuBusy_[(size_t)which] += std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
+            if (last) finishFilesOf(p);
+            std::unique_lock<std::mutex> lk(mu_);
+            cvAppend_.wait(lk, [&] { return p.appendTurn >= myslice; });   // (earlier slices always get there)
+            if (p.appendTurn == myslice) {                  // an error above skipped the hand-over: do not block later slices
+                p.appendTurn = myslice + 1;
+                cvAppend_.notify_all();
+            }
+            if (!released) {
+                p.nextSlice++;
+                p.inFlight = false;
+                if (p.nextSlice == p.nslices) {
+                    if (++finishedPieces_ == pieces_.size()) cv_.notify_all();
+                } else {
+                    offer(pi);
+                }
+            }
+        }
+    }
+
+    // hand the slice's samples to the files that take them verbatim (slices of a piece arrive here in order)
+    void handOver(const Piece &p, size_t f0, size_t len) {
+        const Group &g = groups_[p.group];
+        for (size_t k = p.k0; k < p.k1; k++) {
+            const size_t i = fileOf_[g.ids[k]];
+            if (!streamed_[i]) continue;
+            const int64_t lo = std::max<int64_t>(window_[i].first, (int64_t)(f0 * g.N));
+            const int64_t hi = std::min<int64_t>(window_[i].second, (int64_t)((f0 + len) * g.N));
+            if (hi <= lo) continue;
+            std::vector<float> &pcm = out_[i].pcm;
+            if (pcm.empty()) pcm.reserve((size_t)(window_[i].second - window_[i].first) * g.ch);
+            const float *src = g.out + k * g.maxF * g.N * g.ch;
+            pcm.insert(pcm.end(), src + lo * g.ch, src + hi * g.ch);
+        }
+    }
+
+    // after a piece's last slice: the decoder state of every stream that continues with another segment.  The piece's
+    // state is exact only for streams whose first segment fills the whole padded length; a shorter one is given
+    // its own call.
+    void keepStates(nyq_ctx *ctx, const Piece &p) {
+        const Group &g = groups_[p.group];
+        for (size_t k = p.k0; k < p.k1; k++) {
+            const size_t flat = g.ids[k];
+            StreamFrames &s = sf(flat);
+            if (s.plan.size() < 2) continue;
+            std::vector<float> st1(nyq_celt_state_floats(1, g.ch), 0.f);
+            if ((size_t)s.plan[0].nframes != g.maxF) {
+                std::vector<float> out1((size_t)s.plan[0].nframes * g.N * g.ch);
+                if (nyq_celt_frames_to_pcm(ctx, g.LM, s.freq0, s.tr0, s.pp0, s.pg0, s.pt0, out1.data(), st1.data(), 1,
+                                           (size_t)s.plan[0].nframes, g.ch) != NYQ_OK)
+                    throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(ctx));
+            } else {
+                stateOfStream(p.state.data(), p.k1 - p.k0, g.ch, k - p.k0, st1.data());
+            }
+            stateOf_[flat] = std::move(st1);
+        }
+    }
+
+    // pass 3 right away for every file all of whose streams are through (and that has no later segment): what is left
+    // of it overlaps the entropy stage of the files still being decoded
+    void finishFilesOf(const Piece &p) {
+        const Group &g = groups_[p.group];
+        for (size_t k = p.k0; k < p.k1; k++) {
+            const size_t i = fileOf_[g.ids[k]];
+            if (subsLeft_[i].fetch_sub(1, std::memory_order_acq_rel) != 1 || !jobs_[i].error.empty()) continue;
+            bool simple = true;
+            for (const auto &sub : jobs_[i].subs) simple = simple && sub.plan.size() == 1;
+            if (!simple) continue;
+            try {
+                finishFile(i);
+            } catch (const std::exception &e) {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (gpuError_.empty()) gpuError_ = e.what();
+            }
+        }
+    }
+
+    // Later segments (a stream that changes its frame size, typically a short closing frame): round r takes
+    // segment r of every stream that has one, batched over the streams of equal shape (channels, frame size,
+    // frame count -- no padding, so the decoder state that comes back is exact) with their states gathered
+    // into the batch layout and scattered back.
+    void laterSegments() {
+        nyq_ctx *ctx = (nyq_ctx *)ctxs_[0];
+        const size_t n = sfp_.size();
+        for (size_t r = 1;; r++) {
+            std::map<std::tuple<int, int, long>, std::vector<size_t>> shapes;
+            for (size_t i = 0; i < n; i++)
+                if (sf(i).later.size() >= r && !stateOf_[i].empty())   // (no state: the file failed in pass 1)
+                    shapes[std::make_tuple(sf(i).channels, sf(i).later[r - 1].LM, sf(i).later[r - 1].nframes)].push_back(i);
+            if (shapes.empty()) break;
+            for (const auto &kv : shapes) {
+                const int ch = std::get<0>(kv.first), LM = std::get<1>(kv.first);
+                const size_t nf = (size_t)std::get<2>(kv.first), N = (size_t)120 << LM;
+                const std::vector<size_t> &ids = kv.second;
+                const size_t ns = ids.size(), per = nf * ch * N;
+                std::vector<float> freq(ns * per), pcm(ns * per), pg(ns * nf), state(nyq_celt_state_floats(ns, ch));
+                std::vector<int> pp(ns * nf), pt(ns * nf);
+                std::vector<uint8_t> tr(ns * nf);
+                for (size_t k = 0; k < ns; k++) {
+                    const Segment &sg = sf(ids[k]).later[r - 1];
+                    std::memcpy(&freq[k * per], sg.freq.data(), per * sizeof(float));
+                    std::memcpy(&tr[k * nf], sg.transient.data(), nf);
+                    std::memcpy(&pp[k * nf], sg.pfPitch.data(), nf * sizeof(int));
+                    std::memcpy(&pt[k * nf], sg.pfTapset.data(), nf * sizeof(int));
+                    std::memcpy(&pg[k * nf], sg.pfGain.data(), nf * sizeof(float));
+                    stateIntoBatch(state.data(), ns, ch, k, stateOf_[ids[k]].data());
+                }
+                if (nyq_celt_frames_to_pcm(ctx, LM, freq.data(), tr.data(), pp.data(), pg.data(), pt.data(), pcm.data(), state.data(),
+                                           ns, nf, ch) != NYQ_OK)
+                    throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(ctx));
+                for (size_t k = 0; k < ns; k++) {
+                    const size_t i = ids[k];
+                    laterPcm_[i].insert(laterPcm_[i].end(), &pcm[k * per], &pcm[k * per] + per);
+                    stateOfStream(state.data(), ns, ch, k, stateOf_[i].data());
+                    frames += (long)nf;
+                }
+            }
+        }
+    }
+
+    // pass 3 for one file: channel mapping (opus_multistream_decoder.c:305-331), then trimming (opusfile: skip
+    // pre_skip samples, stop at the last page's granule position) and the header gain
+    void finishFile(size_t i) {
+        finished_[i] = 1;
+        const FileJob &job = jobs_[i];
+        const OpusHead &head = job.f.head;
+        DecodedStream &d = out_[i];
+        const int ch = head.channels;
+        d.channels = ch;
+        d.preSkip = head.preSkip;
+        for (const auto &sub : job.subs) {
+            d.frames += sub.nframes;
+            d.transientFrames += sub.transientCount;
+        }
+        const int64_t a = window_[i].first, b = window_[i].second, total = b - a;
+        d.totalSamples = total;
+        if (streamed_[i]) return;                           // its samples went out slice by slice
+        d.pcm.resize((size_t)total * ch);
+        const float gain = head.outputGainQ8 == 0 ? 1.f   // OPUS_SET_GAIN, opus_decoder_clean.c:700-712
+                                                   : (float)std::exp(0.6931471805599453094 * (6.48814081e-4 * head.outputGainQ8));
+        for (int c = 0; c < ch; c++) {
+            const int idx = head.mapping[c];
+            float *dst = d.pcm.data() + c;
+            if (idx == 255) {                              // silent channel
+                for (int64_t t = 0; t < total; t++) dst[t * ch] = 0.f;
+                continue;
+            }
+            int sub, sc;
+            if (idx < 2 * head.coupledCount) { sub = idx / 2; sc = idx & 1; }
+            else { sub = idx - head.coupledCount; sc = 0; }
+            const size_t flat = firstSub_[i] + (size_t)sub;
+            const StreamFrames &s = sf(flat);
+            const Group &g = groups_[s.group];
+            const int sch = s.channels;
+            // samples [0, n0) come from the group output, the rest from the later segments
+            const int64_t n0 = (int64_t)s.plan[0].nframes * (int64_t)g.N;
+            const float *src0 = g.out + s.slot * g.maxF * g.N * sch;
+            const float *src1 = laterPcm_[flat].data();
+            for (int64_t t = a; t < b; t++) {
+                const float v = t < n0 ? src0[t * sch + sc] : src1[(t - n0) * sch + sc];
+                dst[(t - a) * ch] = gain == 1.f ? v : v * gain;
+            }
+        }
+    }
+
+    std::vector<FileJob> &jobs_;
+    std::vector<DecodedStream> &out_;
+    const std::vector<size_t> &members_;
+    void *const *ctxs_;
+    const int nfeeders_, threads_;
+    const std::function<void *(size_t)> &arena_;
+
+    std::vector<StreamFrames *> sfp_;                  // flattened elementary streams
+    std::vector<size_t> firstSub_, fileOf_;            // file -> first flat index; flat index -> file
+    std::vector<Group> groups_;
+    std::vector<Piece> pieces_;
+    std::vector<std::atomic<long>> progress_;          // per flat stream: frames of the first segment decoded (and padded)
+    std::vector<std::vector<float>> stateOf_;          // decoder state of streams that continue (nstreams = 1 layout)
+    std::vector<std::vector<float>> laterPcm_;         // segments 1.. of the streams that have them
+    std::vector<char> finished_, streamed_;            // per file: pass 3 done; samples handed over slice by slice
+    std::vector<std::pair<int64_t, int64_t>> window_;  // per file: [first, last) sample after trimming
+    std::vector<std::atomic<int>> subsLeft_;           // per file: elementary streams still on their way through the GPU
+
+    std::mutex mu_;                                    // scheduler: ready queue, Piece::{nextSlice, inFlight, appendTurn}
+    std::condition_variable cv_, cvAppend_;
+    std::deque<size_t> ready_;
+    size_t finishedPieces_ = 0;
+    std::string gpuError_;
+    std::vector<double> gpuBusy_;
+};
+
 }  // namespace
 
 BatchOpusDecoder::BatchOpusDecoder(int device) {
@@ -260,7 +720,7 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
     out.assign(nfiles, DecodedStream());
     std::vector<FileJob> jobs(nfiles);
     if (threads <= 0) threads = usableHostThreads();
-    auto t0 = std::chrono::steady_clock::now();
+    const auto t0 = std::chrono::steady_clock::now();
     // pass 0: scan
     parallelFor(nfiles, threads, [&](size_t i) {
         try {
@@ -280,6 +740,13 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
     std::vector<std::vector<size_t>> batches(1);
     {
         std::map<std::pair<int, int>, std::pair<size_t, size_t>> shape;   // (channels, LM) -> (streams, longest)
+        auto add = [&](const FileJob &job) {
+            for (const auto &sub : job.subs) {
+                auto &e = shape[{sub.channels, sub.plan[0].LM}];
+                e.first++;
+                e.second = std::max(e.second, (size_t)sub.plan[0].nframes);
+            }
+        };
         auto estimate = [&]() {
             size_t bytes = 0;
             for (const auto &kv : shape)
@@ -288,434 +755,26 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
         };
         for (size_t i = 0; i < nfiles; i++) {
             if (!jobs[i].error.empty()) continue;
-            auto before = shape;
-            for (const auto &sub : jobs[i].subs) {
-                auto &e = shape[{sub.channels, sub.plan[0].LM}];
-                e.first++;
-                e.second = std::max(e.second, (size_t)sub.plan[0].nframes);
-            }
+            add(jobs[i]);
             if (estimate() > budget && !batches.back().empty()) {
                 batches.emplace_back();
                 shape.clear();
-                for (const auto &sub : jobs[i].subs) {
-                    auto &e = shape[{sub.channels, sub.plan[0].LM}];
-                    e.first++;
-                    e.second = std::max(e.second, (size_t)sub.plan[0].nframes);
-                }
+                add(jobs[i]);
             }
             batches.back().push_back(i);
         }
     }
     double cpuSecs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), tailSecs = 0, busySecs = 0;
-    std::atomic<long> totalFrames{0};
+    long totalFrames = 0;
+    const std::function<void *(size_t)> arenaFn = [this](size_t bytes) { return arena(bytes); };
     for (const std::vector<size_t> &members : batches) {
-    const auto tb = std::chrono::steady_clock::now();
-    // the GPU batch is over ELEMENTARY streams: flatten (file, stream) pairs
-    std::vector<StreamFrames *> sfp;
-    std::vector<size_t> firstSub(nfiles, 0);
-    for (size_t i : members) {
-        firstSub[i] = sfp.size();
-        if (jobs[i].error.empty())
-            for (auto &sub : jobs[i].subs) sfp.push_back(&sub);
+        SubBatch sb(jobs, out, members, ctx_, kFeeders, threads, arenaFn);
+        sb.run();
+        cpuSecs += sb.cpuSeconds;
+        tailSecs += sb.tailSeconds;
+        busySecs += sb.busySeconds;
+        totalFrames += sb.frames.load();
     }
-    const size_t n = sfp.size();
-    struct Deref {                                         // keeps the code below reading sf[i].member
-        std::vector<StreamFrames *> &v;
-        StreamFrames &operator[](size_t i) { return *v[i]; }
-    } sf{sfp};
-    // layout: the first segment of every stream, grouped by (channels, LM) and padded to the longest; a
-    // group is cut into pieces of consecutive slots, each one GPU call
-    std::map<std::pair<int, int>, size_t> groupOf;
-    std::vector<Group> groups;
-    for (size_t i = 0; i < n; i++) {
-        const std::pair<int, int> key{sf[i].channels, sf[i].plan[0].LM};
-        auto it = groupOf.find(key);
-        if (it == groupOf.end()) {
-            it = groupOf.emplace(key, groups.size()).first;
-            groups.emplace_back();
-            groups.back().ch = key.first;
-            groups.back().LM = key.second;
-            groups.back().N = (size_t)120 << key.second;
-        }
-        Group &g = groups[it->second];
-        sf[i].group = it->second;
-        sf[i].slot = g.ids.size();
-        g.ids.push_back(i);
-        g.maxF = std::max(g.maxF, (size_t)sf[i].plan[0].nframes);
-    }
-    size_t bytes = 0;
-    for (Group &g : groups) {
-        g.ns = g.ids.size();
-        const size_t x = g.ns * g.maxF * g.ch * g.N * sizeof(float), q = g.ns * g.maxF;
-        bytes += 2 * align256(x) + 3 * align256(q * 4) + align256(q);
-    }
-    char *base = (char *)arena(bytes);
-    std::vector<Piece> pieces;
-    for (size_t gi = 0; gi < groups.size(); gi++) {
-        Group &g = groups[gi];
-        const size_t x = g.ns * g.maxF * g.ch * g.N * sizeof(float), q = g.ns * g.maxF;
-        g.freq = (float *)base; base += align256(x);
-        g.out = (float *)base; base += align256(x);
-        g.pg = (float *)base; base += align256(q * 4);
-        g.pp = (int *)base; base += align256(q * 4);
-        g.pt = (int *)base; base += align256(q * 4);
-        g.tr = (uint8_t *)base; base += align256(q);
-        std::memset(g.pg, 0, q * 4);                        // padded frames: no post-filter, not transient
-        std::memset(g.pp, 0, q * 4);
-        std::memset(g.pt, 0, q * 4);
-        std::memset(g.tr, 0, q);
-        // ~24 MB of freq per piece, but never fewer streams than decoding threads: long streams finish in rounds
-        // of `threads` files, and the GPU's post-filter (one sequential wave per channel) wants them together
-        const size_t per = std::max<size_t>((size_t)std::max(1, threads), kPieceBytes / std::max<size_t>(1, g.maxF * g.ch * g.N * sizeof(float)));
-        for (size_t k0 = 0; k0 < g.ns; k0 += per) {
-            pieces.emplace_back();
-            Piece &p = pieces.back();
-            p.group = gi;
-            p.k0 = k0;
-            p.k1 = std::min(g.ns, k0 + per);
-            // time slices: multiples of 64 frames (the synthesis kernels' in-wave carry chains then restart at the
-            // same frames as in one call over the whole length: bit-identical results whatever the slicing)
-            const size_t frame_bytes = (p.k1 - p.k0) * g.ch * g.N * sizeof(float);
-            p.sliceLen = g.maxF;
-            if (g.maxF * frame_bytes > (kSliceBytes * 3) / 2) p.sliceLen = std::max<size_t>(64, (kSliceBytes / frame_bytes) & ~(size_t)63);
-            p.nslices = (g.maxF + p.sliceLen - 1) / p.sliceLen;
-        }
-    }
-    std::vector<std::atomic<long>> progress(n);
-    for (auto &pr : progress) pr.store(0, std::memory_order_relaxed);
-    {   // slots -> pieces, destination pointers
-        size_t pi = 0;
-        for (size_t gi = 0; gi < groups.size(); gi++) {
-            Group &g = groups[gi];
-            for (size_t k = 0; k < g.ns; k++) {
-                while (!(pieces[pi].group == gi && k >= pieces[pi].k0 && k < pieces[pi].k1)) pi++;
-                StreamFrames &s = sf[g.ids[k]];
-                s.piece = pi;
-                s.freq0 = g.freq + k * g.maxF * g.ch * g.N;
-                s.tr0 = g.tr + k * g.maxF;
-                s.pp0 = g.pp + k * g.maxF;
-                s.pt0 = g.pt + k * g.maxF;
-                s.pg0 = g.pg + k * g.maxF;
-                s.progress = &progress[g.ids[k]];
-                s.sliceLen = pieces[pi].nslices > 1 ? (long)pieces[pi].sliceLen : 0;
-                if (s.plan.size() > 1) pieces[pi].anyMore = true;
-            }
-        }
-    }
-    std::vector<std::vector<float>> laterPcm(n);          // segments 1.. of the streams that have them
-    std::vector<char> finished(nfiles, 0);                // pass 3 done (each file is finished by exactly one thread)
-    std::vector<std::atomic<int>> subsLeft(nfiles);       // elementary streams of the file still on their way through the GPU
-    std::vector<size_t> fileOf(n);
-    for (size_t i : members) {
-        subsLeft[i].store(jobs[i].error.empty() ? (int)jobs[i].subs.size() : 0, std::memory_order_relaxed);
-        if (jobs[i].error.empty())
-            for (size_t k = 0; k < jobs[i].subs.size(); k++) fileOf[firstSub[i] + k] = i;
-    }
-    // pass 3: channel mapping (opus_multistream_decoder.c:305-331), then trimming (opusfile: skip pre_skip
-    // samples, stop at the last page's granule position) and the header gain
-    // Files whose output is the group output verbatim (one mono/stereo stream, one segment, identity mapping, unit
-    // gain) are copied out slice by slice as the GPU delivers them; `window[i]` = [first, last) sample of the stream
-    // that belongs to the file after pre-skip / end trimming.
-    std::vector<char> streamed(nfiles, 0);
-    std::vector<std::pair<int64_t, int64_t>> window(nfiles);
-    for (size_t i : members) {
-        if (!jobs[i].error.empty()) continue;
-        const FileJob &job = jobs[i];
-        const OpusHead &head = job.f.head;
-        const int ch = head.channels;
-        const int64_t decoded = job.subs[0].samples;
-        const int64_t endSample = job.f.lastGranule >= 0 ? std::min<int64_t>(decoded, job.f.lastGranule) : decoded;
-        const int64_t total = std::max<int64_t>(0, endSample - head.preSkip);
-        window[i] = {head.preSkip, head.preSkip + total};
-        streamed[i] = ch <= 2 && job.subs.size() == 1 && job.subs[0].plan.size() == 1 && job.subs[0].channels == ch &&
-                      head.outputGainQ8 == 0 && head.mapping[0] == 0 && (ch == 1 || head.mapping[1] == 1);
-    }
-    auto finishFile = [&](size_t i) {
-        finished[i] = 1;
-        const FileJob &job = jobs[i];
-        const OpusHead &head = job.f.head;
-        DecodedStream &d = out[i];
-        const int ch = head.channels;
-        d.channels = ch;
-        d.preSkip = head.preSkip;
-        const int64_t decoded = job.subs[0].samples;
-        for (const auto &sub : job.subs) {
-            d.frames += sub.nframes;
-            d.transientFrames += sub.transientCount;
-        }
-        const int64_t endSample = job.f.lastGranule >= 0 ? std::min<int64_t>(decoded, job.f.lastGranule) : decoded;
-        int64_t total = endSample - head.preSkip;
-        if (total < 0) total = 0;
-        d.totalSamples = total;
-        if (streamed[i]) return;                           // its samples went out slice by slice
-        d.pcm.resize((size_t)total * ch);
-        const float gain = head.outputGainQ8 == 0 ? 1.f   // OPUS_SET_GAIN, opus_decoder_clean.c:700-712
-                                                   : (float)std::exp(0.6931471805599453094 * (6.48814081e-4 * head.outputGainQ8));
-        for (int c = 0; c < ch; c++) {
-            const int idx = head.mapping[c];
-            float *dst = d.pcm.data() + c;
-            if (idx == 255) {                              // silent channel
-                for (int64_t t = 0; t < total; t++) dst[t * ch] = 0.f;
-                continue;
-            }
-            int sub, sc;
-            if (idx < 2 * head.coupledCount) { sub = idx / 2; sc = idx & 1; }
-            else { sub = idx - head.coupledCount; sc = 0; }
-            const size_t flat = firstSub[i] + (size_t)sub;
-            const StreamFrames &s = sf[flat];
-            const Group &g = groups[s.group];
-            const int sch = s.channels;
-            // samples [0, n0) come from the group output, the rest from the later segments
-            const int64_t n0 = (int64_t)s.plan[0].nframes * (int64_t)g.N;
-            const float *src0 = g.out + s.slot * g.maxF * g.N * sch;
-            const float *src1 = laterPcm[flat].data();
-            const int64_t a = head.preSkip, b = head.preSkip + total;
-            for (int64_t t = a; t < b; t++) {
-                const float v = t < n0 ? src0[t * sch + sc] : src1[(t - n0) * sch + sc];
-                dst[(t - a) * ch] = gain == 1.f ? v : v * gain;
-            }
-        }
-    };
-
-    // pass 1 (CPU threads) and pass 2 (feeder threads, one GPU context each) run at the same time: time slice s of a
-    // piece goes to the GPU when every stream of the piece has been decoded that far; slices of one piece go in
-    // order (the decoder state of the piece travels with them), different pieces side by side
-    std::mutex mu;
-    std::condition_variable cv, cvAppend;
-    std::deque<size_t> ready;
-    size_t finishedPieces = 0;
-    std::string gpuError;
-    std::vector<std::vector<float>> stateOf(n);           // decoder state of streams that continue (nstreams = 1 layout)
-    double gpuBusy[kFeeders] = {0};
-    for (Piece &p : pieces)
-        if (p.nslices > 1 || p.anyMore) p.state.assign(nyq_celt_state_floats(p.k1 - p.k0, groups[p.group].ch), 0.f);
-    auto offer = [&](size_t pi) {                         // call with `mu` held
-        Piece &p = pieces[pi];
-        if (p.inFlight || p.nextSlice >= p.nslices) return;
-        const Group &g = groups[p.group];
-        const long target = (long)std::min((p.nextSlice + 1) * p.sliceLen, g.maxF);
-        for (size_t k = p.k0; k < p.k1; k++)
-            if (progress[g.ids[k]].load(std::memory_order_acquire) < target) return;
-        p.inFlight = true;
-        ready.push_back(pi);
-        cv.notify_one();
-    };
-    auto feeder = [&](int which) {
-        nyq_ctx *ctx = (nyq_ctx *)ctx_[which];
-        for (;;) {
-            size_t pi;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return !ready.empty() || finishedPieces == pieces.size(); });
-                if (ready.empty()) return;
-                pi = ready.front();
-                ready.pop_front();
-            }
-            Piece &p = pieces[pi];
-            const Group &g = groups[p.group];
-            const size_t ns = p.k1 - p.k0, nsc = ns * g.ch;
-            const size_t f0 = p.nextSlice * p.sliceLen, len = std::min(p.sliceLen, g.maxF - f0);
-            const size_t so = p.k0 * g.maxF + f0;         // first stream of the piece, first frame of the slice
-            const size_t myslice = p.nextSlice;
-            const bool last = myslice + 1 == p.nslices;
-            bool released = false;
-            auto c0 = std::chrono::steady_clock::now();
-            try {
-                if (nyq_celt_frames_to_pcm_window(ctx, g.LM, g.freq + so * g.ch * g.N, g.tr + so, g.pp + so, g.pg + so, g.pt + so,
-                                                  g.out + so * g.ch * g.N, p.state.empty() ? nullptr : p.state.data(), ns, len, g.ch,
-                                                  g.maxF) != NYQ_OK)
-                    throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(ctx));
-                // the GPU part of the slice is done: the piece's next slice may start (its kernels only need the
-                // state, which is back on the host) while this thread copies samples out
-                if (!last) {
-                    std::lock_guard<std::mutex> lk(mu);
-                    p.nextSlice++;
-                    p.inFlight = false;
-                    released = true;
-                    offer(pi);
-                }
-                {
-                    std::unique_lock<std::mutex> lk(mu);
-                    cvAppend.wait(lk, [&] { return p.appendTurn == myslice; });
-                }
-                // hand the slice's samples to the files that take them verbatim
-                for (size_t k = p.k0; k < p.k1; k++) {
-                    const size_t i = fileOf[g.ids[k]];
-                    if (!streamed[i]) continue;
-                    const int64_t lo = std::max<int64_t>(window[i].first, (int64_t)(f0 * g.N));
-                    const int64_t hi = std::min<int64_t>(window[i].second, (int64_t)((f0 + len) * g.N));
-                    if (hi <= lo) continue;
-                    std::vector<float> &pcm = out[i].pcm;
-                    if (pcm.empty()) pcm.reserve((size_t)(window[i].second - window[i].first) * g.ch);
-                    const float *src = g.out + k * g.maxF * g.N * g.ch;
-                    pcm.insert(pcm.end(), src + lo * g.ch, src + hi * g.ch);
-                }
-                {
-                    std::lock_guard<std::mutex> lk(mu);
-                    p.appendTurn = myslice + 1;
-                }
-                cvAppend.notify_all();
-                // the piece's state is exact only for streams whose first segment fills the whole padded length;
-                // a shorter stream that continues with another segment is given its own call
-                const std::vector<float> &state = p.state;
-                for (size_t k = p.k0; last && p.anyMore && k < p.k1; k++) {
-                    const size_t i = g.ids[k];
-                    StreamFrames &s = sf[i];
-                    if (s.plan.size() < 2) continue;
-                    std::vector<float> st1(nyq_celt_state_floats(1, g.ch), 0.f);
-                    if ((size_t)s.plan[0].nframes != g.maxF) {
-                        std::vector<float> out1((size_t)s.plan[0].nframes * g.N * g.ch);
-                        if (nyq_celt_frames_to_pcm(ctx, g.LM, s.freq0, s.tr0, s.pp0, s.pg0, s.pt0, out1.data(), st1.data(), 1,
-                                                   (size_t)s.plan[0].nframes, g.ch) != NYQ_OK)
-                            throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(ctx));
-                    } else {                               // slice stream k out of the piece's state
-                        const size_t kk = k - p.k0;
-                        const float *ov = state.data(), *hi = ov + nsc * 60, *de = hi + nsc * 1088, *pf = de + nsc;
-                        float *o = st1.data();
-                        std::memcpy(o, ov + kk * g.ch * 60, sizeof(float) * g.ch * 60); o += g.ch * 60;
-                        std::memcpy(o, hi + kk * g.ch * 1088, sizeof(float) * g.ch * 1088); o += g.ch * 1088;
-                        std::memcpy(o, de + kk * g.ch, sizeof(float) * g.ch); o += g.ch;
-                        std::memcpy(o, pf + kk * 6, sizeof(float) * 6);
-                    }
-                    stateOf[i] = std::move(st1);
-                }
-            } catch (const std::exception &e) {
-                std::lock_guard<std::mutex> lk(mu);
-                if (gpuError.empty()) gpuError = e.what();
-            }
-            gpuBusy[which] += std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
-            if (last) {
-                // pass 3 right here for every file all of whose streams are through (and that has no later segment):
-                // the copy into the caller's vector overlaps the entropy stage of the files still being decoded
-                for (size_t k = p.k0; k < p.k1; k++) {
-                    const size_t i = fileOf[g.ids[k]];
-                    if (subsLeft[i].fetch_sub(1, std::memory_order_acq_rel) != 1 || !jobs[i].error.empty()) continue;
-                    bool simple = true;
-                    for (const auto &sub : jobs[i].subs) simple = simple && sub.plan.size() == 1;
-                    if (simple) {
-                        try {
-                            finishFile(i);
-                        } catch (const std::exception &e) {
-                            std::lock_guard<std::mutex> lk(mu);
-                            if (gpuError.empty()) gpuError = e.what();
-                        }
-                    }
-                }
-            }
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cvAppend.wait(lk, [&] { return p.appendTurn >= myslice; });   // (earlier slices always get there)
-                if (p.appendTurn == myslice) {              // an error above skipped the hand-over: do not block later slices
-                    p.appendTurn = myslice + 1;
-                    cvAppend.notify_all();
-                }
-                if (!released) {
-                    p.nextSlice++;
-                    p.inFlight = false;
-                    if (p.nextSlice == p.nslices) {
-                        if (++finishedPieces == pieces.size()) cv.notify_all();
-                    } else {
-                        offer(pi);
-                    }
-                }
-            }
-        }
-    };
-    std::vector<std::thread> feeders;
-    for (int k = 0; k < kFeeders; k++) feeders.emplace_back(feeder, k);
-    parallelFor(members.size(), threads, [&](size_t mi) {
-        const size_t i = members[mi];
-        FileJob &job = jobs[i];
-        if (!job.error.empty()) return;
-        try {
-            entropyDecode(job, [&](StreamFrames &s) {
-                std::lock_guard<std::mutex> lk(mu);
-                offer(s.piece);
-            });
-        } catch (const std::exception &e) {
-            job.error = e.what();
-        }
-        for (StreamFrames &s : job.subs) {
-            const Group &g = groups[s.group];
-            const size_t have = job.error.empty() ? (size_t)s.plan[0].nframes : 0;   // a failed file plays as silence
-            std::memset(s.freq0 + have * g.ch * g.N, 0, (g.maxF - have) * g.ch * g.N * sizeof(float));
-            if (!job.error.empty()) {
-                std::memset(s.tr0, 0, g.maxF);
-                std::memset(s.pp0, 0, g.maxF * 4);
-                std::memset(s.pt0, 0, g.maxF * 4);
-                std::memset(s.pg0, 0, g.maxF * 4);
-            }
-            totalFrames += s.plan[0].nframes;
-            s.progress->store((long)g.maxF, std::memory_order_release);   // decoded and padded to the group's length
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                offer(s.piece);
-            }
-        }
-    });
-    const auto t1 = std::chrono::steady_clock::now();
-    cv.notify_all();
-    for (auto &t : feeders) t.join();
-    if (!gpuError.empty()) throw std::runtime_error(gpuError);
-    nyq_ctx *ctx = (nyq_ctx *)ctx_[0];
-    // Later segments (a stream that changes its frame size, typically a short closing frame): round r takes
-    // segment r of every stream that has one, batched over the streams of equal shape (channels, frame size,
-    // frame count -- no padding, so the decoder state that comes back is exact) with their states gathered
-    // into the batch layout and scattered back.
-    for (size_t r = 1;; r++) {
-        std::map<std::tuple<int, int, long>, std::vector<size_t>> shapes;
-        for (size_t i = 0; i < n; i++)
-            if (sf[i].later.size() >= r && !stateOf[i].empty())   // (no state: the file failed in pass 1)
-                shapes[std::make_tuple(sf[i].channels, sf[i].later[r - 1].LM, sf[i].later[r - 1].nframes)].push_back(i);
-        if (shapes.empty()) break;
-        for (const auto &kv : shapes) {
-            const int ch = std::get<0>(kv.first), LM = std::get<1>(kv.first);
-            const size_t nf = (size_t)std::get<2>(kv.first), N = (size_t)120 << LM;
-            const std::vector<size_t> &ids = kv.second;
-            const size_t ns = ids.size(), nsc = ns * ch, per = nf * ch * N;
-            std::vector<float> freq(ns * per), pcm(ns * per), pg(ns * nf), state(nyq_celt_state_floats(ns, ch));
-            std::vector<int> pp(ns * nf), pt(ns * nf);
-            std::vector<uint8_t> tr(ns * nf);
-            float *ov = state.data(), *hi = ov + nsc * 60, *de = hi + nsc * 1088, *pf = de + nsc;
-            for (size_t k = 0; k < ns; k++) {
-                const Segment &sg = sf[ids[k]].later[r - 1];
-                std::memcpy(&freq[k * per], sg.freq.data(), per * sizeof(float));
-                std::memcpy(&tr[k * nf], sg.transient.data(), nf);
-                std::memcpy(&pp[k * nf], sg.pfPitch.data(), nf * sizeof(int));
-                std::memcpy(&pt[k * nf], sg.pfTapset.data(), nf * sizeof(int));
-                std::memcpy(&pg[k * nf], sg.pfGain.data(), nf * sizeof(float));
-                const float *o = stateOf[ids[k]].data();
-                std::memcpy(ov + k * ch * 60, o, sizeof(float) * ch * 60); o += ch * 60;
-                std::memcpy(hi + k * ch * 1088, o, sizeof(float) * ch * 1088); o += ch * 1088;
-                std::memcpy(de + k * ch, o, sizeof(float) * ch); o += ch;
-                std::memcpy(pf + k * 6, o, sizeof(float) * 6);
-            }
-            if (nyq_celt_frames_to_pcm(ctx, LM, freq.data(), tr.data(), pp.data(), pg.data(), pt.data(), pcm.data(), state.data(),
-                                       ns, nf, ch) != NYQ_OK)
-                throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(ctx));
-            for (size_t k = 0; k < ns; k++) {
-                const size_t i = ids[k];
-                laterPcm[i].insert(laterPcm[i].end(), &pcm[k * per], &pcm[k * per] + per);
-                float *o = stateOf[i].data();
-                std::memcpy(o, ov + k * ch * 60, sizeof(float) * ch * 60); o += ch * 60;
-                std::memcpy(o, hi + k * ch * 1088, sizeof(float) * ch * 1088); o += ch * 1088;
-                std::memcpy(o, de + k * ch, sizeof(float) * ch); o += ch;
-                std::memcpy(o, pf + k * 6, sizeof(float) * 6);
-                totalFrames += (long)nf;
-            }
-        }
-    }
-    // pass 3 for the files that could not be finished as their pieces completed (later segments, or a stream of the
-    // file in a piece that ended after the file's other streams)
-    parallelFor(members.size(), threads, [&](size_t mi) {
-        const size_t i = members[mi];
-        if (jobs[i].error.empty() && !finished[i]) finishFile(i);
-    });
-    const auto t2b = std::chrono::steady_clock::now();
-    cpuSecs += std::chrono::duration<double>(t1 - tb).count();
-    tailSecs += std::chrono::duration<double>(t2b - t1).count();
-    for (int k = 0; k < kFeeders; k++) busySecs += gpuBusy[k];
-    }   // sub-batches
     for (size_t i = 0; i < nfiles; i++)
         if (!jobs[i].error.empty()) {
             out[i].error = jobs[i].error;
