@@ -1,0 +1,70 @@
+// tests/sched/fake_gpu.cpp -- TEST ONLY.  A CPU stand-in for the few libnyq_imdct.so entry points the batch
+// decoder calls, so that its scheduler (decode threads, feeder threads, time slices, ordered hand-over of the
+// samples, sub-batches) can run under ThreadSanitizer where there is no GPU.  It does NOT decode audio: the
+// "PCM" of a frame is a checksum-like function of that frame's coefficients, its parameters, and a running
+// per-(stream, channel) state that is carried exactly like the real decoder state -- so any slice delivered out
+// of order, twice, or with the wrong state changes the output.  Never linked into the product.
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+#include "../../include/nyq_imdct.h"
+
+struct nyq_ctx {
+    int device;
+};
+
+extern "C" {
+
+int nyq_ctx_create(nyq_ctx **out, int device) {
+    *out = new nyq_ctx{device};
+    return NYQ_OK;
+}
+void nyq_ctx_destroy(nyq_ctx *c) { delete c; }
+const char *nyq_last_error(const nyq_ctx *) { return "fake"; }
+void *nyq_host_alloc(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
+void nyq_host_free(void *p) { std::free(p); }
+
+size_t nyq_celt_state_floats(size_t nstreams, int channels) {
+    const size_t nsc = nstreams * (size_t)(channels > 0 ? channels : 0);
+    return nsc * (60 + 1088 + 1) + nstreams * 6;
+}
+
+int nyq_celt_frames_to_pcm_window(nyq_ctx *, int LM, const float *freq, const unsigned char *transient, const int *pf_pitch,
+                                  const float *pf_gain, const int *pf_tapset, float *out, float *state, size_t nstreams,
+                                  size_t nframes, int channels, size_t frames_per_stream) {
+    const size_t N = (size_t)120 << LM, nsc = nstreams * channels;
+    for (size_t s = 0; s < nstreams; s++)
+        for (int c = 0; c < channels; c++) {
+            // the running state lives where the real overlap state lives: first float of the stream-channel's 60
+            float acc = state ? state[(s * channels + c) * 60] : 0.f;
+            for (size_t f = 0; f < nframes; f++) {
+                const size_t hf = s * frames_per_stream + f;
+                const float *x = freq + (hf * channels + c) * N;
+                float v = 0.f;
+                for (size_t k = 0; k < N; k += 7) v += x[k];
+                acc = 0.5f * acc + v + (transient ? (float)transient[hf] : 0.f) + (float)pf_pitch[hf] * 1e-3f + pf_gain[hf] +
+                      (float)pf_tapset[hf];
+                float *o = out + (hf * N) * channels + c;
+                for (size_t k = 0; k < N; k++) o[k * channels] = acc + (float)k * 1e-6f;
+            }
+            if (state) state[(s * channels + c) * 60] = acc;
+        }
+    if (state) {   // touch the rest of the state the way the real call does (read-modify-write)
+        float *hi = state + nsc * 60, *pf = hi + nsc * 1088 + nsc;
+        for (size_t i = 0; i < nsc * 1088; i += 64) hi[i] += 1.f;
+        for (size_t s = 0; s < nstreams; s++) pf[s * 6] += (float)nframes;
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(200 + 20 * (nstreams * nframes) / 64));   // a GPU takes a while
+    return NYQ_OK;
+}
+
+int nyq_celt_frames_to_pcm(nyq_ctx *c, int LM, const float *freq, const unsigned char *transient, const int *pf_pitch,
+                           const float *pf_gain, const int *pf_tapset, float *out, float *state, size_t nstreams, size_t nframes,
+                           int channels) {
+    return nyq_celt_frames_to_pcm_window(c, LM, freq, transient, pf_pitch, pf_gain, pf_tapset, out, state, nstreams, nframes, channels,
+                                         nframes);
+}
+
+}  // extern "C"

@@ -1,0 +1,42 @@
+"""The batch decoder's scheduler (decode threads publishing progress, feeder threads, time slices with carried
+state, ordered hand-over of the samples, memory-bounded sub-batches) under ThreadSanitizer, against a CPU stand-in
+for the GPU library (tests/sched/fake_gpu.cpp: its "PCM" depends on every frame, every parameter and the carried
+state, so a slice delivered out of order or with the wrong state shows).  The real entropy decoder runs; no GPU."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+SCHED = os.path.join(ROOT, "tests", "sched")
+
+
+@pytest.fixture(scope="module")
+def harness():
+    subprocess.run(["make", "-C", SCHED], check=True, stdout=subprocess.DEVNULL)
+    return os.path.join(SCHED, "sched_check_tsan")
+
+
+def run(harness, files, **env):
+    e = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66", **env)
+    r = subprocess.run([harness] + [os.path.join(GOLDEN, f) for f in files], env=e, capture_output=True, text=True, timeout=600)
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    assert "0 mismatches" in r.stdout
+    return r.stdout
+
+
+def test_mixed_batches_small_budget(harness):
+    """mono / stereo / 5.1 / two frame sizes / a failing SILK file, 8-3-1 threads, sub-batches of 40 MB"""
+    out = run(harness, ["corpus/st_20ms_32k.opus", "corpus/mono_5ms_64k.opus", "corpus/surround51_10ms_192k.opus",
+                        "corpus/twosize_st_20ms_then_10ms_10s.opus", "short.opus", "corpus/unsupported_silk_voip_12k.opus",
+                        "corpus/st_2p5ms_128k.opus"], NYQ_BATCH_BYTES="40000000")
+    assert "6 batches" in out
+
+
+def test_long_streams_in_time_slices(harness):
+    """a 224 s stream is walked in time slices next to short ones"""
+    out = run(harness, ["sb-reverie.opus", "corpus/st_20ms_32k.opus", "corpus/twosize_st_20ms_then_10ms_10s.opus", "short.opus"],
+              SCHED_THREADS="4", SCHED_REPS="2")
+    assert "1 batches" in out
