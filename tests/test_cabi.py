@@ -45,3 +45,15 @@ def test_fails_loudly_without_gpu():
     with pytest.raises(nyq.NyqError) as e:
         nyq.Context(0)
     assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+
+
+def test_header_is_plain_c():
+    """include/nyq_imdct.h is the FFI contract: it must compile as strict C99 on its own (no C++, no torch types)."""
+    import subprocess
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".c", delete=False) as f:
+        f.write('#include "nyq_imdct.h"\nint main(void) { return 0; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        "-fsyntax-only", f.name], capture_output=True, text=True)
+    os.unlink(f.name)
+    assert r.returncode == 0, r.stderr
