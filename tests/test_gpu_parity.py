@@ -570,3 +570,46 @@ def test_frames_to_pcm_window_slices_equal_one_call(ctx, oracle):
     with pytest.raises(Exception):
         ctx._ck(ctx.lib.nyq_celt_frames_to_pcm_window(ctx.h, 3, p(freq, 0), p(tr, 0), p(pp, 0), p(pg, 0), p(pt, 0), p(out, 0), p(st, 0),
                                                       ns, 64, ch, 32))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_shapes_synth_then_post_vs_oracle(ctx, oracle, seed):
+    """Randomised shapes through both GPU stages against the oracle: frame size, channel count, stream and frame
+    counts (around the kernels' group / chain / slice boundaries), transient density, incoming state, post-filter
+    parameters with short periods and switched-off frames, both stereo post-filter modes."""
+    ctx.set_tables(*oracle.tables()[:2])
+    rng = np.random.default_rng(9000 + seed)
+    lm = int(rng.integers(0, 4))
+    n = 120 << lm
+    ch = int(rng.choice([1, 2, 2, 2, 3, 5]))
+    ns = int(rng.choice([1, 2, 5, 17, 33]))
+    nf = int(rng.choice([1, 2, 15, 16, 17, 31, 33, 63, 64, 65, 70]))
+    ptr = float(rng.choice([0.0, 0.03, 0.3, 1.0]))
+    freq = (rng.standard_normal((ns, nf, ch, n)) * 30).astype(np.float32)
+    tr = (rng.uniform(size=(ns, nf)) < ptr).astype(np.uint8)
+    st = (rng.standard_normal((ns * ch, 60)) * 30).astype(np.float32) if seed % 2 else None
+    pcm, so = ctx.celt_synth(lm, freq, tr, st, channels=ch)
+    wp, ws = oracle.celt_synth(lm, freq, tr, st, nthreads=4)
+    assert rel_rms(pcm, wp) <= 1e-6, (lm, ch, ns, nf, ptr)
+    if st is not None:
+        assert rel_rms(so, ws) <= 1e-6
+    hist = (rng.standard_normal((ns, ch, 1088)) * 30).astype(np.float32)
+    pitch = rng.integers(15, 1023, (ns, nf)).astype(np.int32)
+    short = rng.uniform(size=(ns, nf)) < 0.5
+    pitch[short] = rng.integers(15, 70, int(short.sum()))
+    gain = (rng.integers(0, 9, (ns, nf)) * 0.09375).astype(np.float32)
+    gain[rng.uniform(size=(ns, nf)) < 0.3] = 0
+    taps = rng.integers(0, 3, (ns, nf)).astype(np.int32)
+    pst = np.stack([[rng.integers(15, 1023), rng.integers(15, 1023), 0.28125, 0.375, 1, 2] for _ in range(ns)]).astype(np.float32)
+    dm = (rng.standard_normal(ns * ch) * 10).astype(np.float32)
+    want, filt, wst, wdm = oracle.celt_post(lm, np.concatenate([hist, wp.reshape(ns, ch, nf * n)], axis=2), 1088, pitch, gain, taps, pst, dm)
+    for mode in (("0", "1") if ch == 2 else ("0",)):
+        os.environ["NYQ_POST_STEREO_PAIRS"] = mode
+        try:
+            out, gst, gh, gdm = _post_on_gpu(ctx, lm, wp.reshape(ns, ch, nf * n), pitch, gain, taps, pst, hist.reshape(ns * ch, 1088), dm, ch)
+        finally:
+            del os.environ["NYQ_POST_STEREO_PAIRS"]
+        assert rel_rms(out, want) <= 1e-5, (lm, ch, ns, nf, mode)
+        assert np.array_equal(gst, wst)
+        assert rel_rms(gh, filt[:, :, -1088:].reshape(ns * ch, 1088)) <= 1e-5
+        assert rel_rms(gdm, wdm) <= 1e-5
