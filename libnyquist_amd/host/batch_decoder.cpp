@@ -757,8 +757,16 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
             if (!jobs[i].error.empty()) continue;
             add(jobs[i]);
             if (estimate() > budget && !batches.back().empty()) {
-                batches.emplace_back();
+                // close the sub-batch on a multiple of the thread count: the decoding threads take files in rounds,
+                // and a last round of one long file would leave the other threads idle
+                std::vector<size_t> &cur = batches.back();
+                std::vector<size_t> carry;
+                const size_t keep = cur.size() >= (size_t)threads ? cur.size() - cur.size() % (size_t)threads : cur.size();
+                carry.assign(cur.begin() + (long)keep, cur.end());
+                cur.resize(keep);
+                batches.emplace_back(carry);
                 shape.clear();
+                for (size_t j : carry) add(jobs[j]);
                 add(jobs[i]);
             }
             batches.back().push_back(i);
