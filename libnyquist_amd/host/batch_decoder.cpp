@@ -380,9 +380,9 @@ private:
             if (p.nslices > 1 || p.anyMore) p.state.assign(nyq_celt_state_floats(p.k1 - p.k0, groups_[p.group].ch), 0.f);
     }
 
-    // Files whose output is the group output verbatim (one mono/stereo stream, one segment, identity mapping, unit
-    // gain) are copied out slice by slice as the GPU delivers them; window_[i] = [first, last) sample of the stream
-    // that belongs to the file after pre-skip / end trimming.
+    // Files whose output is the decoded stream verbatim (one mono/stereo stream, identity mapping, unit gain) are
+    // copied out slice by slice as the GPU delivers them (a later segment is appended when it exists);
+    // window_[i] = [first, last) sample of the stream that belongs to the file after pre-skip / end trimming.
     void planOutput() {
         for (size_t i : members_) {
             if (!jobs_[i].error.empty()) continue;
@@ -393,8 +393,8 @@ private:
             const int64_t endSample = job.f.lastGranule >= 0 ? std::min<int64_t>(decoded, job.f.lastGranule) : decoded;
             const int64_t total = std::max<int64_t>(0, endSample - head.preSkip);
             window_[i] = {head.preSkip, head.preSkip + total};
-            streamed_[i] = ch <= 2 && job.subs.size() == 1 && job.subs[0].plan.size() == 1 && job.subs[0].channels == ch &&
-                           head.outputGainQ8 == 0 && head.mapping[0] == 0 && (ch == 1 || head.mapping[1] == 1);
+            streamed_[i] = ch <= 2 && job.subs.size() == 1 && job.subs[0].channels == ch && head.outputGainQ8 == 0 &&
+                           head.mapping[0] == 0 && (ch == 1 || head.mapping[1] == 1);
         }
     }
 
@@ -516,8 +516,9 @@ private:
         for (size_t k = p.k0; k < p.k1; k++) {
             const size_t i = fileOf_[g.ids[k]];
             if (!streamed_[i]) continue;
+            const int64_t n0 = (int64_t)sf(g.ids[k]).plan[0].nframes * (int64_t)g.N;   // (frames past it are padding)
             const int64_t lo = std::max<int64_t>(window_[i].first, (int64_t)(f0 * g.N));
-            const int64_t hi = std::min<int64_t>(window_[i].second, (int64_t)((f0 + len) * g.N));
+            const int64_t hi = std::min<int64_t>(std::min<int64_t>(window_[i].second, n0), (int64_t)((f0 + len) * g.N));
             if (hi <= lo) continue;
             std::vector<float> &pcm = out_[i].pcm;
             if (pcm.empty()) pcm.reserve((size_t)(window_[i].second - window_[i].first) * g.ch);
@@ -626,7 +627,15 @@ private:
         }
         const int64_t a = window_[i].first, b = window_[i].second, total = b - a;
         d.totalSamples = total;
-        if (streamed_[i]) return;                           // its samples went out slice by slice
+        if (streamed_[i]) {                                 // the first segment went out slice by slice
+            const StreamFrames &s = sf(firstSub_[i]);
+            const int64_t n0 = (int64_t)s.plan[0].nframes * (int64_t)((size_t)120 << s.plan[0].LM);
+            if (b > n0) {                                   // what the later segments add
+                const float *src1 = laterPcm_[firstSub_[i]].data();
+                d.pcm.insert(d.pcm.end(), src1 + (std::max(a, n0) - n0) * ch, src1 + (b - n0) * ch);
+            }
+            return;
+        }
         d.pcm.resize((size_t)total * ch);
         const float gain = head.outputGainQ8 == 0 ? 1.f   // OPUS_SET_GAIN, opus_decoder_clean.c:700-712
                                                    : (float)std::exp(0.6931471805599453094 * (6.48814081e-4 * head.outputGainQ8));
