@@ -177,33 +177,44 @@ __device__ __forceinline__ void comb_call(float *ring, int lane, int r0, int n, 
     if (tmin - 2 <= kWave) {
         // short periods: one output per lane, scalar tap reads, no alignment cases
         const int w = tmin - 2;                                // T >= 15: w >= 13
-        for (int base = 0; base < kOverlap; base += w) {
-            const int i = base + lane;
-            if (lane < w && i < kOverlap) {
-                const int idx = r0 + i;
-                const float f = win2[i], nf = 1.0f - f;
-                const int t0i = idx - T0 - 2, t1i = idx - T1 - 2;
-#pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    float *rc = ring + c * kPostRing;
-                    float y = rc[idx];
-                    if (g0 != 0.f) {
-                        const float x0 = rc[t0i], x1 = rc[t0i + 1], x2 = rc[t0i + 2], x3 = rc[t0i + 3], x4 = rc[t0i + 4];
-                        y += (nf * g00) * x2;
-                        y += (nf * g01) * (x3 + x1);
-                        y += (nf * g02) * (x4 + x0);
-                    }
-                    if (g1 != 0.f) {
-                        const float x0 = rc[t1i], x1 = rc[t1i + 1], x2 = rc[t1i + 2], x3 = rc[t1i + 3], x4 = rc[t1i + 4];
-                        y += (f * g10) * x2;
-                        y += (f * g11) * (x3 + x1);
-                        y += (f * g12) * (x4 + x0);
-                    }
-                    rc[idx] = y;
-                }
+        const int nfull = kOverlap / w, rem = kOverlap - nfull * w;
+        float *rc0 = ring + (r0 + lane);
+        const float *wp = win2 + lane;
+        auto step = [&](float *rc, float f) {
+            const float nf = 1.0f - f;
+            float y = rc[0];
+            if (g0 != 0.f) {
+                const float *t = rc - T0 - 2;
+                const float x0 = t[0], x1 = t[1], x2 = t[2], x3 = t[3], x4 = t[4];
+                y += (nf * g00) * x2;
+                y += (nf * g01) * (x3 + x1);
+                y += (nf * g02) * (x4 + x0);
             }
-            NYQ_POST_SYNC();
+            if (g1 != 0.f) {
+                const float *t = rc - T1 - 2;
+                const float x0 = t[0], x1 = t[1], x2 = t[2], x3 = t[3], x4 = t[4];
+                y += (f * g10) * x2;
+                y += (f * g11) * (x3 + x1);
+                y += (f * g12) * (x4 + x0);
+            }
+            rc[0] = y;
+        };
+        if (lane < w) {
+            for (int sidx = 0; sidx < nfull; sidx++) {
+                const float f = *wp;
+#pragma unroll
+                for (int c = 0; c < NC; c++) step(rc0 + c * kPostRing, f);
+                rc0 += w;
+                wp += w;
+                NYQ_POST_SYNC();
+            }
         }
+        if (lane < rem) {
+            const float f = *wp;
+#pragma unroll
+            for (int c = 0; c < NC; c++) step(rc0 + c * kPostRing, f);
+        }
+        NYQ_POST_SYNC();
     } else {
     const int w = (tmin - 2) & ~3;
     for (int base = 0; base < kOverlap; base += w) {
@@ -255,25 +266,32 @@ __device__ __forceinline__ void comb_call(float *ring, int lane, int r0, int n, 
         // short periods (the common case in real streams): T1-2 <= 64 outputs per step anyway, so one output
         // per lane with five scalar tap reads is the leaner step
         const int w = T1 - 2;
-        int idx = r0 + kOverlap + lane;
-        int tp = idx - T1 - 2;
-        for (int base = kOverlap; base < n; base += w) {
-            if (lane < w && base + lane < n) {
+        // whole steps under one constant lane mask (no per-step bound checks: the recursion is bound by VALU issue,
+        // measured with SQ_INSTS_VALU / SQ_WAVE_CYCLES), then the remainder
+        const int nfull = (n - kOverlap) / w, rem = (n - kOverlap) - nfull * w;
+        float *rc0 = ring + (r0 + kOverlap + lane);            // this lane's output of the current step
+        auto step = [&](float *rc) {
+            const float *tp = rc - T1 - 2;
+            const float x0 = tp[0], x1 = tp[1], x2 = tp[2], x3 = tp[3], x4 = tp[4];
+            float y = rc[0];
+            y += g10 * x2;
+            y += g11 * (x3 + x1);
+            y += g12 * (x4 + x0);
+            rc[0] = y;
+        };
+        if (lane < w) {
+            for (int sidx = 0; sidx < nfull; sidx++) {
 #pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    float *rc = ring + c * kPostRing;
-                    const float x0 = rc[tp], x1 = rc[tp + 1], x2 = rc[tp + 2], x3 = rc[tp + 3], x4 = rc[tp + 4];
-                    float y = rc[idx];
-                    y += g10 * x2;
-                    y += g11 * (x3 + x1);
-                    y += g12 * (x4 + x0);
-                    rc[idx] = y;
-                }
+                for (int c = 0; c < NC; c++) step(rc0 + c * kPostRing);
+                rc0 += w;
+                NYQ_POST_SYNC();
             }
-            idx += w;
-            tp += w;
-            NYQ_POST_SYNC();
         }
+        if (lane < rem) {
+#pragma unroll
+            for (int c = 0; c < NC; c++) step(rc0 + c * kPostRing);
+        }
+        NYQ_POST_SYNC();
         return;
     }
     const int w1 = (T1 - 2 < 4 * kWave ? T1 - 2 : 4 * kWave) & ~3;
