@@ -126,35 +126,42 @@ __device__ __forceinline__ void comb_const_loop(float *ring, int lane, int r0, i
     const int o = 4 * lane;
     int idx = r0 + kOverlap + o;                               // this lane's outputs of the current step
     int rb = idx - T1 - 2 - AL;                                // aligned start of their taps
-    for (int base = kOverlap; base < n; base += w1) {
-        if (o < w1 && base + o < n) {
-            f4 cen[NC], q0[NC], q1[NC], q2[NC];
+    auto step = [&]() {
+        f4 cen[NC], q0[NC], q1[NC], q2[NC];
 #pragma unroll
-            for (int c = 0; c < NC; c++) {
-                const float *rc = ring + c * kPostRing;
-                q0[c] = lds4(rc, rb);
-                q1[c] = lds4(rc, rb + 4);
-                q2[c] = lds4(rc, rb + 8);
-                cen[c] = lds4(rc, idx);
-            }
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                float x[8];
-                pick8<AL>(q0[c], q1[c], q2[c], x);
-                float y[4] = {cen[c].x, cen[c].y, cen[c].z, cen[c].w};
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    y[u] += g10 * x[u + 2];
-                    y[u] += g11 * (x[u + 3] + x[u + 1]);
-                    y[u] += g12 * (x[u + 4] + x[u]);
-                }
-                sts4(ring + c * kPostRing, idx, f4{y[0], y[1], y[2], y[3]});
-            }
+        for (int c = 0; c < NC; c++) {
+            const float *rc = ring + c * kPostRing;
+            q0[c] = lds4(rc, rb);
+            q1[c] = lds4(rc, rb + 4);
+            q2[c] = lds4(rc, rb + 8);
+            cen[c] = lds4(rc, idx);
         }
-        idx += w1;
-        rb += w1;
-        NYQ_POST_SYNC();
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            float x[8];
+            pick8<AL>(q0[c], q1[c], q2[c], x);
+            float y[4] = {cen[c].x, cen[c].y, cen[c].z, cen[c].w};
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                y[u] += g10 * x[u + 2];
+                y[u] += g11 * (x[u + 3] + x[u + 1]);
+                y[u] += g12 * (x[u + 4] + x[u]);
+            }
+            sts4(ring + c * kPostRing, idx, f4{y[0], y[1], y[2], y[3]});
+        }
+    };
+    // whole steps under one constant lane mask, then the remainder (n - kOverlap and w1 are multiples of 4)
+    const int nfull = (n - kOverlap) / w1, rem = (n - kOverlap) - nfull * w1;
+    if (o < w1) {
+        for (int sidx = 0; sidx < nfull; sidx++) {
+            step();
+            idx += w1;
+            rb += w1;
+            NYQ_POST_SYNC();
+        }
     }
+    if (o < rem) step();
+    NYQ_POST_SYNC();
 }
 
 // One comb_filter() call (celt.c:114-172) on the n samples that start at index r0 (a multiple of 4, at least
