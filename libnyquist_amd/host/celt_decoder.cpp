@@ -988,14 +988,18 @@ void CeltDecoder::reset() {
     }
 }
 
-int CeltDecoder::decode(const uint8_t *data, int len, int frameSize, float *freq, CeltFrame &info) {
+int CeltDecoder::decode(const uint8_t *data, int len, int frameSize, float *freqOut, CeltFrame &info) {
     const CeltMode &m = m_;
     const int CC = channels_, C = streamChannels_;
+    // A mono decoder may be handed stereo-coded packets (the TOC's stereo flag is per packet): both channels are
+    // decoded and then mixed down (celt_decoder_clean.c:648-652), so the work buffer is max(CC, C) channels wide
+    // (:396 ALLOC(freq, IMAX(CC,C)*N)) while the caller's holds CC.
+    float *freq = C > CC ? wide_ : freqOut;
     int LM;
     for (LM = 0; LM <= kMaxLM; LM++)
         if ((kShortMdct << LM) == frameSize) break;
     if (LM > kMaxLM) return -1;
-    if (len < 0 || len > 1275 || !data || !freq) return -1;
+    if (len < 0 || len > 1275 || !data || !freqOut) return -1;
     const int M = 1 << LM;
     const int N = M * kShortMdct;
     const int start = start_, end = end_;
@@ -1101,7 +1105,7 @@ int CeltDecoder::decode(const uint8_t *data, int len, int frameSize, float *freq
     }
     if (CC == 2 && C == 1) std::memcpy(freq + N, freq, sizeof(float) * N);          // :643-647
     if (CC == 1 && C == 2)
-        for (int i = 0; i < N; i++) freq[i] = .5f * (freq[i] + freq[N + i]);       // :648-652
+        for (int i = 0; i < N; i++) freqOut[i] = .5f * (freq[i] + freq[N + i]);    // :648-652
 
     if (C == 1) std::memcpy(oldBandE_ + kBands, oldBandE_, sizeof(float) * kBands);  // :685-689
     if (!isTransient) {                                                               // :691-703

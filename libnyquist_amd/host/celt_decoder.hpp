@@ -47,6 +47,7 @@ private:
     float oldLogE_[2 * kBands];
     float oldLogE2_[2 * kBands];
     float backgroundLogE_[2 * kBands];
+    float wide_[2 * 960];     // both channels of a stereo-coded packet handed to a mono decoder
 };
 
 }  // namespace nyq_host

@@ -213,6 +213,27 @@ def main():
     # a SILK stream (VOIP application at 12 kbit/s): NOT decodable by this library by design -- the error path
     raw, _ = encode("silk_voip_12k", 1, 960, 12000, True, "fb", 5, 0.4, 3000, application=2048)
     open(os.path.join(out_dir, "unsupported_silk_voip_12k.opus"), "wb").write(raw)
+    # stereo-coded packets under a MONO OpusHead: legal (the stereo flag is per packet, RFC 6716 section 3.1), the
+    # decoder decodes both channels and mixes them down (celt_decoder_clean.c:648-652)
+    k = [c[0] for c in CORPUS].index("st_20ms_32k")
+    cname, cch, cframe, cbr, cvbr, cbw, ccx, csecs = CORPUS[k]
+    raw_st, ranges_st = encode(cname, cch, cframe, cbr, cvbr, cbw, ccx, csecs, 1000 + k)
+    pk, _, _ = oggopus.read_packets(raw_st)
+    head_st, audio = pk[0], pk[2:]
+    preskip_st = struct.unpack("<H", head_st[10:12])[0]
+    raw = oggopus.mux_family0(audio, 1, preskip_st, cframe, int(48000 * csecs))
+    name = "monohead_st_20ms_32k"
+    open(os.path.join(out_dir, name + ".opus"), "wb").write(raw)
+    info = (C.c_long * 3)()
+    n = R.ref_decode_pcm(raw, len(raw), None, 0, info)
+    assert n > 0 and info[0] == 1, (n, info[0])
+    pcm = np.zeros(n, np.float32)
+    assert R.ref_decode_pcm(raw, len(raw), pcm.ctypes.data_as(C.POINTER(C.c_float)), n, info) == n
+    dig[name + "/ranges"] = ranges_st
+    dig[name + "/meta"] = np.array([1, cframe, n, len(raw)], np.int64)
+    dig[name + "/sum"] = np.array([pcm.astype(np.float64).sum(), (pcm.astype(np.float64) ** 2).sum()])
+    dig[name + "/every5"] = pcm[::5].copy()
+    print(f"{name}: {len(raw)} bytes, {len(audio)} stereo-coded packets under a mono header, {n} samples")
     raw, n20, n10 = encode_two_sizes(10.0, 4000)
     name = "twosize_st_20ms_then_10ms_10s"
     open(os.path.join(out_dir, name + ".opus"), "wb").write(raw)

@@ -40,3 +40,18 @@ def test_long_streams_in_time_slices(harness):
     out = run(harness, ["sb-reverie.opus", "corpus/st_20ms_32k.opus", "corpus/twosize_st_20ms_then_10ms_10s.opus", "short.opus"],
               SCHED_THREADS="4", SCHED_REPS="2")
     assert "1 batches" in out
+
+
+def test_damaged_files_under_address_sanitizer():
+    """Random damage (byte flips, truncation, bit flips in the audio pages) of real files -- among them a mono-header
+    file with stereo-coded packets, a 5.1 file and one that changes its frame size -- through the whole batch path
+    against the fake GPU, built with AddressSanitizer + UBSan.  (This is the harness that caught the decoder writing
+    both channels of a stereo-coded packet into a mono stream's buffer.)"""
+    subprocess.run(["make", "-C", SCHED, "asan"], check=True, stdout=subprocess.DEVNULL)
+    files = ["corpus/monohead_st_20ms_32k.opus", "corpus/st_20ms_32k.opus", "corpus/mono_5ms_64k.opus", "corpus/surround51_10ms_192k.opus",
+             "corpus/twosize_st_20ms_then_10ms_10s.opus", "short.opus", "corpus/st_2p5ms_128k.opus", "corpus/mono_20ms_16k_nb.opus"]
+    r = subprocess.run([os.path.join(SCHED, "fuzz_check_asan"), "120", "7"] + [os.path.join(GOLDEN, f) for f in files],
+                       capture_output=True, text=True, timeout=900)
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    assert r.returncode == 0, (r.returncode, r.stderr[-1500:])
+    assert "120 iterations" in r.stdout
