@@ -708,6 +708,14 @@ BatchOpusDecoder::~BatchOpusDecoder() {
     for (int k = kFeeders - 1; k >= 0; k--) nyq_ctx_destroy((nyq_ctx *)ctx_[k]);
 }
 
+void BatchOpusDecoder::trim(size_t keepBytes) {
+    if (arena_ && arenaBytes_ > keepBytes) {
+        pinned_ ? nyq_host_free(arena_) : std::free(arena_);
+        arena_ = nullptr;
+        arenaBytes_ = 0;
+    }
+}
+
 // page-locked staging memory, kept from call to call (grow only); pageable memory if pinning fails
 void *BatchOpusDecoder::arena(size_t bytes) {
     if (bytes <= arenaBytes_) return arena_;

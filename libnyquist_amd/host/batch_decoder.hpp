@@ -44,6 +44,10 @@ public:
     void decode(const std::vector<const std::vector<uint8_t> *> &files, std::vector<DecodedStream> &out,
                 BatchStats *stats = nullptr, int threads = 0);
 
+    // give the page-locked staging memory back if it has grown beyond `keepBytes` (a pooled decoder should not sit
+    // on gigabytes of pinned memory after one big job)
+    void trim(size_t keepBytes);
+
 private:
     void *arena(size_t bytes);
     static constexpr int kFeeders = 6;        // GPU contexts / feeder threads: pieces in flight at once

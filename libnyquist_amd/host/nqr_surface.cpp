@@ -101,6 +101,7 @@ struct DecoderLease {
         if (!dec) dec = new nyq_host::BatchOpusDecoder(d);
     }
     ~DecoderLease() {
+        dec->trim((size_t)512 << 20);
         {
             std::lock_guard<std::mutex> lk(decoderPool().mu);
             auto &v = decoderPool().idle[device];
