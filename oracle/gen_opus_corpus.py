@@ -234,6 +234,21 @@ def main():
     dig[name + "/sum"] = np.array([pcm.astype(np.float64).sum(), (pcm.astype(np.float64) ** 2).sum()])
     dig[name + "/every5"] = pcm[::5].copy()
     print(f"{name}: {len(raw)} bytes, {len(audio)} stereo-coded packets under a mono header, {n} samples")
+    # the same stereo stream with an output gain of -4.5 dB in the header (Q7.8 = -1152; RFC 7845 section 5.1,
+    # applied by opusfile's default OP_HEADER_GAIN and by OPUS_SET_GAIN, opus_decoder_clean.c:700-712)
+    head_gain = head_st[:16] + struct.pack("<h", -1152) + head_st[18:]
+    raw = oggopus.mux_packets(head_gain, audio, preskip_st, cframe, int(48000 * csecs))
+    name = "gain_st_20ms_32k"
+    open(os.path.join(out_dir, name + ".opus"), "wb").write(raw)
+    n = R.ref_decode_pcm(raw, len(raw), None, 0, info)
+    assert n > 0 and info[0] == 2, (n, info[0])
+    pcm = np.zeros(n, np.float32)
+    assert R.ref_decode_pcm(raw, len(raw), pcm.ctypes.data_as(C.POINTER(C.c_float)), n, info) == n
+    dig[name + "/ranges"] = ranges_st
+    dig[name + "/meta"] = np.array([2, cframe, n, len(raw)], np.int64)
+    dig[name + "/sum"] = np.array([pcm.astype(np.float64).sum(), (pcm.astype(np.float64) ** 2).sum()])
+    dig[name + "/every5"] = pcm[::5].copy()
+    print(f"{name}: {len(raw)} bytes, header gain -4.5 dB, {n} samples, rms {np.sqrt((pcm.astype(np.float64)**2).mean()):.4f}")
     raw, n20, n10 = encode_two_sizes(10.0, 4000)
     name = "twosize_st_20ms_then_10ms_10s"
     open(os.path.join(out_dir, name + ".opus"), "wb").write(raw)

@@ -32,7 +32,7 @@ def digest():
 
 
 def test_corpus_is_complete(digest):
-    assert len(FAMILY0) == 17 and len(NAMES) == 20
+    assert len(FAMILY0) == 18 and len(NAMES) == 21
     sizes = {int(digest[n + "/meta"][1]) for n in FAMILY0}
     assert sizes == {120, 240, 480, 960}                    # every CELT frame size
     assert {int(digest[n + "/meta"][0]) for n in NAMES} == {1, 2, 6, 8}
