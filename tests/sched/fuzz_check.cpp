@@ -11,6 +11,31 @@
 
 #include "batch_decoder.hpp"
 
+// re-seal the pages after the damage (the parser verifies the Ogg CRC) so that the damage reaches the layers below
+static void resealPages(std::vector<uint8_t> &b) {
+    static uint32_t table[256];
+    if (!table[1])
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t r = i << 24;
+            for (int k = 0; k < 8; k++) r = (r & 0x80000000u) ? (r << 1) ^ 0x04c11db7u : r << 1;
+            table[i] = r;
+        }
+    size_t pos = 0;
+    while (pos + 27 <= b.size()) {
+        if (b[pos] != 'O' || b[pos + 1] != 'g' || b[pos + 2] != 'g' || b[pos + 3] != 'S') { pos++; continue; }
+        const size_t nsegs = b[pos + 26];
+        if (pos + 27 + nsegs > b.size()) break;
+        size_t len = 27 + nsegs;
+        for (size_t i = 0; i < nsegs; i++) len += b[pos + 27 + i];
+        if (pos + len > b.size()) break;
+        for (int i = 22; i < 26; i++) b[pos + i] = 0;
+        uint32_t c = 0;
+        for (size_t i = 0; i < len; i++) c = (c << 8) ^ table[((c >> 24) & 0xff) ^ b[pos + i]];
+        for (int i = 0; i < 4; i++) b[pos + 22 + i] = (uint8_t)(c >> (8 * i));
+        pos += len;
+    }
+}
+
 int main(int argc, char **argv) {
     if (argc < 4) return 2;
     const int iters = std::atoi(argv[1]);
@@ -43,6 +68,7 @@ int main(int argc, char **argv) {
                 default:
                     break;
             }
+            if (rng() % 4) resealPages(b);
             files.push_back(std::move(b));
         }
         std::vector<const std::vector<uint8_t> *> ptrs;

@@ -24,6 +24,30 @@ long_src = open(os.path.join(G, "sb-reverie.opus"), "rb").read()
 rng = np.random.default_rng(77)
 
 
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import oggopus  # noqa: E402
+import struct  # noqa: E402
+
+
+def reseal(raw):
+    raw = bytearray(raw)
+    pos = 0
+    while pos + 27 <= len(raw):
+        if raw[pos:pos + 4] != b"OggS":
+            pos += 1
+            continue
+        nseg = raw[pos + 26]
+        if pos + 27 + nseg > len(raw):
+            break
+        ln = 27 + nseg + sum(raw[pos + 27:pos + 27 + nseg])
+        if pos + ln > len(raw):
+            break
+        raw[pos + 22:pos + 26] = b"\0\0\0\0"
+        raw[pos + 22:pos + 26] = struct.pack("<I", oggopus.ogg_crc(bytes(raw[pos:pos + ln])))
+        pos += ln
+    return raw
+
+
 def damage(raw):
     raw = bytearray(raw)
     mode = int(rng.integers(0, 4))
@@ -36,6 +60,8 @@ def damage(raw):
         lo = min(len(raw) - 1, 120)
         for _ in range(int(rng.integers(1, 16))):
             raw[int(rng.integers(lo, len(raw)))] ^= 1 << int(rng.integers(0, 8))
+    if rng.integers(0, 4):                               # re-seal the pages so that the damage gets past the Ogg CRC
+        raw = reseal(raw)
     return bytes(raw)                                    # mode 3: untouched
 
 
