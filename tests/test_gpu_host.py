@@ -232,3 +232,37 @@ def test_mixed_batch_every_file_as_if_decoded_alone(host):
             assert ns[i] == a.size, paths[i]
             assert np.array_equal(out[pos:pos + a.size], a), paths[i]
             pos += a.size
+
+
+@pytest.mark.gpu
+def test_concurrent_loads_from_several_threads(host):
+    """NyquistIO::Load from six host threads at once (each call leases its own decoder = its own GPU contexts and
+    staging memory from the per-device pool): same samples as the sequential loads."""
+    import glob
+    import threading
+    paths = [p for p in sorted(glob.glob(os.path.join(GOLDEN, "corpus", "*.opus"))) if "unsupported" not in p] + [os.path.join(GOLDEN, "short.opus")]
+    raws = [open(p, "rb").read() for p in paths]
+    want = []
+    info = np.zeros(8, np.int64)
+    for r in raws:
+        n = host.nyqh_nyquistio_load_buffer(r, len(r), None, 0, info)
+        a = np.zeros(n, np.float32)
+        assert host.nyqh_nyquistio_load_buffer(r, len(r), a.ctypes.data_as(C.c_void_p), n, info) == n
+        want.append(a)
+    errors = []
+
+    def worker(tid):
+        inf = np.zeros(8, np.int64)
+        for rep in range(4):
+            for k in range(tid, len(raws), 3):
+                out = np.zeros(want[k].size, np.float32)
+                n = host.nyqh_nyquistio_load_buffer(raws[k], len(raws[k]), out.ctypes.data_as(C.c_void_p), out.size, inf)
+                if n != want[k].size or not np.array_equal(out, want[k]):
+                    errors.append((tid, rep, paths[k]))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
