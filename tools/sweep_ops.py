@@ -42,7 +42,7 @@ for shift, rows in () if ONLY and ONLY != 'imdct' else ((0, 1 << 20), (1, 1 << 2
     res.append(dict(op=f"imdct_batch_dev nfft {480 >> shift}", rows=rows, ms=ms, alg_GBps=rows * n2 * 8 / ms / 1e6,
                     rows_per_s=rows / ms * 1e3))
     del x, fin, tail
-for nfft, rows in () if ONLY and ONLY != 'ifft' else ((60, 1 << 22), (480, 1 << 19)):
+for nfft, rows in () if ONLY and ONLY != "ifft" else ((60, 1 << 22), (120, 1 << 21), (240, 1 << 20), (480, 1 << 19)):
     x = torch.rand((rows, 2 * nfft), generator=g, device=dev)
     y = torch.empty_like(x)
     ms = timeit(lambda: ctx.ifft_batch_dev(nfft, x.data_ptr(), y.data_ptr(), rows))
