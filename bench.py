@@ -20,7 +20,8 @@ stream); `cpu_baseline` = the reference's own clt_mdct_backward (oracle/_ref, ki
 bounded sample of the same rows.
 
 Secondary keys on the same line (rank 0; the last two at N = 1 only, never part of `value`):
-  opus_frame_synthesis  nyq_celt_synth_dev + nyq_celt_post_dev on 1024 streams x 256 stereo frames
+  opus_frame_synthesis  nyq_celt_synth_dev + nyq_celt_post_dev on 1024 streams x 256 stereo frames per GPU (every
+                        rank; whole-job Opus frames/s from the slowest rank's time)
   host_boundary         nyq_imdct_batch on pinned HOST buffers (PCIe both ways) and the per-call latency of
                         the reference's own offload interface (processMDCTCuda)
   opus_file_decode      256 Ogg Opus files through the plugin surface next to the reference's NyquistIO::Load
@@ -264,8 +265,10 @@ def main():
     # secondary figure (not the headline metric): Opus 20 ms stereo frames/s through the frame-sequence
     # operator nyq_celt_synth_dev on the measured sb-reverie.opus frame mix (2.8 % transient frames,
     # BASELINE.md section 2), 1024 concurrent streams x 256 frames, device resident.
+    # Opus frames/s: the device-resident frames -> PCM chain (frame synthesis, then post-filter + de-emphasis +
+    # interleave) on every rank's own streams; the whole-job rate uses the slowest rank's time, like `value`
     synth = None
-    if rank == 0:
+    if True:
         ns, nf, ch = 1024, 256, 2
         gs = torch.Generator(device=dev)
         gs.manual_seed(4)
@@ -316,6 +319,14 @@ def main():
         except Exception as e:
             synth["post_filter_error"] = repr(e)
         del sfreq, spcm, swork
+        chain_ms = synth["ms_per_call"] + synth.get("post_filter_ms_per_call", float("inf"))
+        if world > 1:
+            tt = torch.tensor([chain_ms], device=red_dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            chain_ms = float(tt.item())
+        synth["whole_job_stereo_frames_per_sec_synthesis_plus_post_filter"] = (
+            world * ns * nf / (chain_ms * 1e-3) if chain_ms != float("inf") else None)
+        synth["n_gpus"] = world
 
     # The reference's FFI hands over HOST buffers (mdct.c:52-55).  nyq_imdct_batch on pinned buffers: upload,
     # kernel and download pipelined over three streams; the rate is PCIe-bound and is reported beside `value`,
