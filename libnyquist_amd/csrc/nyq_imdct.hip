@@ -18,6 +18,7 @@
 
 #include "nyq_kernels.hpp"
 #include "nyq_post_kernels.hpp"
+#include "nyq_post_pipe.hpp"
 
 using namespace nyq;
 
@@ -48,6 +49,7 @@ struct nyq_ctx {
     int res_synth_long[4] = {0, 0, 0, 0};
     int res_synth_short = 0;
     int res_post[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    int res_post_pipe[4] = {0, 0, 0, 0};
     int res_vorbis[12] = {0};
     float *d_vtab = nullptr;             // Vorbis rotation + twiddle tables of every block size, one allocation
     size_t vrot_off[12] = {0}, vtw_off[12] = {0};   // float offsets by log2(n/4)
@@ -408,6 +410,24 @@ static int launch_post(nyq_ctx *ctx, const PostArgs &A) {
     return NYQ_OK;
 }
 
+// the workgroup-pipelined form (nyq_post_pipe.hpp): one workgroup of 2 comb waves + 1 I/O wave per two chains
+template <int LM>
+static int launch_post_pipe(nyq_ctx *ctx, const PostArgs &A) {
+    const size_t nunits = (size_t)A.nstreams * (size_t)A.channels;
+    const size_t npairs = (nunits + kPipeUnits - 1) / kPipeUnits;
+    int &res = ctx->res_post_pipe[LM];
+    if (res == 0) {
+        int per_cu = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, celt_post_pipe_kernel<LM>, kWave * kPipeWaves, 0);
+        if (e != hipSuccess || per_cu < 1) per_cu = 1;
+        res = per_cu * ctx->cus;
+    }
+    const unsigned grid = (unsigned)(npairs < (size_t)res ? npairs : (size_t)res);
+    hipLaunchKernelGGL((celt_post_pipe_kernel<LM>), dim3(grid), dim3(kWave * kPipeWaves), 0, ctx->stream, A, ctx->d_window);
+    NYQ_HIP(ctx, hipGetLastError());
+    return NYQ_OK;
+}
+
 extern "C" int nyq_celt_post_dev(nyq_ctx *ctx, int LM, const float *d_pcm, const int *d_pf_pitch, const float *d_pf_gain,
                                  const int *d_pf_tapset, const float *d_pf_state_in, float *d_pf_state_out,
                                  float *d_hist, float *d_deemph, float *d_out, size_t nstreams, size_t nframes,
@@ -441,9 +461,22 @@ extern "C" int nyq_celt_post_dev(nyq_ctx *ctx, int LM, const float *d_pcm, const
     // what matters is how many waves a CU has to interleave: pairs win once there are enough streams to give every
     // CU its six pair-waves (24 KB of LDS each), channel-waves win below that (same-process A/B).
     // NYQ_POST_STEREO_PAIRS=0/1 overrides the choice for profiling.
-    bool pair_mode = channels == 2 && nstreams >= (size_t)5 * (size_t)ctx->cus;
-    if (const char *pairs = std::getenv("NYQ_POST_STEREO_PAIRS"))
-        if (channels == 2 && (pairs[0] == '0' || pairs[0] == '1')) pair_mode = pairs[0] == '1';
+    // Default: the workgroup pipeline (a chain's wave issues only the recursion).  The round-1 forms
+    // (one wave per channel / per stereo pair doing everything) stay selectable for A/B runs and tests:
+    // NYQ_POST_STEREO_PAIRS=0 (wave per channel), =1 (wave per stereo pair), =2 or unset (pipeline).
+    bool pipe_mode = true, pair_mode = false;
+    if (const char *pairs = std::getenv("NYQ_POST_STEREO_PAIRS")) {
+        if (pairs[0] == '0' || pairs[0] == '1') pipe_mode = false;
+        pair_mode = channels == 2 && pairs[0] == '1';
+    }
+    if (pipe_mode) {
+        switch (LM) {
+            case 0: return launch_post_pipe<0>(ctx, A);
+            case 1: return launch_post_pipe<1>(ctx, A);
+            case 2: return launch_post_pipe<2>(ctx, A);
+            default: return launch_post_pipe<3>(ctx, A);
+        }
+    }
     if (pair_mode) {
         switch (LM) {
             case 0: return launch_post<0, 2>(ctx, A);

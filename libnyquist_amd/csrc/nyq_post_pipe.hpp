@@ -1,0 +1,673 @@
+// nyq_post_pipe.hpp -- the post-filter stage as a WORKGROUP PIPELINE (round 2).
+//
+// Same operator as nyq_post_kernels.hpp (comb_filter celt.c:114-172 as applied by
+// celt_decoder_clean.c:658-683, then deemphasis() :192-256 with scaling and channel interleave), other
+// execution shape.  The comb filter is a recursion along time: ONE chain per (stream, channel), a few
+// thousand chains per job, so a chain's own instruction stream is what bounds the stage (measured round 1:
+// 874 wave-instructions per channel-frame on the chain's wave, two waves per SIMD, 13 k cycles per frame).
+// Here a chain's wave issues nothing but the recursion; everything else moves to a helper wave of the
+// same workgroup that runs beside it:
+//
+//   workgroup = 2 chains (units 2p, 2p+1 = the two channels of a stereo stream, or two mono streams, ...)
+//     wave 0, 1   comb wave of chain 0 / 1: per frame, the comb steps of that frame and nothing else
+//     wave 2      I/O wave for both chains: global prefetch of frame f+2, raw frame f+1 into LDS,
+//                 de-emphasis + interleave + global store of frame f-1, post-filter parameters of
+//                 frame f+1 into an LDS slot, carry-over of the history that survives
+//   one s_barrier per frame.
+//
+// LDS per chain: two buffers A, B of 2048 floats = [1088 filtered history | frame].  The comb wave filters
+// frame f in place in `cur` and writes every output a second time into `nxt`'s history region
+// (nxt[idx - N]); meanwhile the I/O wave fills the rest of `nxt` (the older part of the history from
+// `cur`, the raw frame f+1) -- so the next frame starts right after the barrier, nothing is moved on the
+// chain's critical path, and every tap address is the output's address minus a wave-uniform constant.
+// The de-emphasis of frame f-1 reads cur's history region (final since the previous barrier) and stages
+// its interleaved output in nxt's frame region before the raw frame f+1 lands there.
+// 32 KB of LDS per workgroup: four workgroups (8 chains, 12 waves) per CU.
+#pragma once
+#include "nyq_post_kernels.hpp"
+
+namespace nyq {
+
+constexpr int kPipeWaves = 3;          // waves per workgroup: 2 comb + 1 I/O
+
+// Diagnostic build only (tools/chainbench.hip, -DNYQ_PIPE_STAMPS): per-role cycle accounting with s_memtime, summed
+// into a buffer of its own that nothing else reads.  The product build compiles none of it.
+#ifdef NYQ_PIPE_STAMPS
+__device__ unsigned long long g_pipe_stamps[16];
+#define NYQ_STAMP_DECL() unsigned long long st_t = __builtin_amdgcn_s_memtime(), st_acc[6] = {0, 0, 0, 0, 0, 0}
+#define NYQ_STAMP(slot)                                              \
+    do {                                                             \
+        const unsigned long long st_n = __builtin_amdgcn_s_memtime(); \
+        st_acc[slot] += st_n - st_t;                                 \
+        st_t = st_n;                                                 \
+    } while (0)
+#define NYQ_STAMP_FLUSH(base)                                                        \
+    do {                                                                             \
+        if (lane == 0)                                                               \
+            for (int st_i = 0; st_i < 6; st_i++) atomicAdd(&g_pipe_stamps[(base) + st_i], st_acc[st_i]); \
+    } while (0)
+__device__ unsigned long long g_stamp_mid_t;   // (unused placeholder: keeps the macro below self-contained)
+#define NYQ_STAMP_MID()                                                  \
+    do {                                                                 \
+        if (stm) {                                                       \
+            const unsigned long long st_n = __builtin_amdgcn_s_memtime(); \
+            stm[1] += st_n - stm[0];                                     \
+            stm[0] = st_n;                                               \
+        }                                                                \
+    } while (0)
+#else
+#define NYQ_STAMP_MID() do { } while (0)
+#define NYQ_STAMP_DECL() do { } while (0)
+#define NYQ_STAMP(slot) do { } while (0)
+#define NYQ_STAMP_FLUSH(base) do { } while (0)
+#endif
+constexpr int kPipeUnits = 2;          // chains per workgroup
+
+// copy cur[i0, i0+n) -> mir[i0, i0+n) (n, i0 multiples of 4), whole wave
+__device__ __forceinline__ void pipe_copy(const float *cur, float *mir, int lane, int i0, int n) {
+#pragma unroll 2
+    for (int v = lane; v < n / 4; v += kWave) sts4(mir, i0 + 4 * v, *reinterpret_cast<const vf4 *>(cur + i0 + 4 * v));
+}
+
+// The constant part of a comb_filter() call (comb_filter_const, celt.c:87-110) for one tap alignment AL: outputs
+// [i0, i0+n) of `ring`, w1 per step (four adjacent ones per lane), every output also stored at mir[idx].
+template <int AL>
+__device__ __forceinline__ void pipe_const_wide(float *ring, float *mir, int lane, int i0, int n, int T1, float g10,
+                                                float g11, float g12, int w1) {
+    const int o = 4 * lane;
+    int idx = i0 + o;
+    int rb = idx - T1 - 2 - AL;
+    auto step = [&]() {
+        const f4 q0 = lds4(ring, rb), q1 = lds4(ring, rb + 4), q2 = lds4(ring, rb + 8), cen = lds4(ring, idx);
+        float x[8];
+        pick8<AL>(q0, q1, q2, x);
+        float y[4] = {cen.x, cen.y, cen.z, cen.w};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            y[u] += g10 * x[u + 2];
+            y[u] += g11 * (x[u + 3] + x[u + 1]);
+            y[u] += g12 * (x[u + 4] + x[u]);
+        }
+        sts4(ring, idx, f4{y[0], y[1], y[2], y[3]});
+        sts4(mir, idx, f4{y[0], y[1], y[2], y[3]});
+    };
+    const int nfull = n / w1, rem = n - nfull * w1;
+    if (o < w1) {
+        for (int sidx = 0; sidx < nfull; sidx++) {
+            step();
+            idx += w1;
+            rb += w1;
+            NYQ_POST_SYNC();
+        }
+    }
+    if (o < rem) step();
+    NYQ_POST_SYNC();
+}
+
+// ---- lane shifts without LDS (gfx9 DPP) ---------------------------------------------------------------
+// dpp_shr1(old, v): lane l >= 1 receives v[l-1], lane 0 keeps old[0]  (v_mov_b32_dpp wave_shr:1, bound_ctrl:0)
+__device__ __forceinline__ float dpp_shr1(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_zero(float v) {   // lanes without a source (or rows masked off) receive 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, ROWMASK == 0xf));
+}
+
+// A run of n outputs ring[i0, i0+n) of ONE period T with w = T-2 <= 64 outputs per step, the recursion kept in
+// REGISTERS: lane l of a step needs y[base_prev + l - 4 .. base_prev + l] = the previous step's outputs of lanes
+// l-4 .. l, i.e. four one-lane shifts of the register that holds them (v_mov_b32_dpp wave_shr:1); what lanes 0..3
+// miss are the LAST four outputs of the step before that -- read from LDS one step ahead, so that no LDS round trip
+// is left on the dependency chain (the LDS form costs write -> read -> wait per step).  Outputs still go to ring[]
+// and mir[] (later frames, the wide forms and the de-emphasis read them there).
+//   XF = false: comb_filter_const (celt.c:87-110), gains ga[0..2]
+//   XF = true : the cross-fade loop of comb_filter (celt.c:139-160) when BOTH tap sets have this period: window
+//               weights from win2[wofs + i], set 0 gains ga, set 1 gains gb (same order of operations as the LDS form)
+template <bool XF>
+__device__ __forceinline__ void pipe_run_dpp(float *ring, float *mir, int lane, int i0, int n, int T, const float (&ga)[3],
+                                             const float (&gb)[3], const float *win2) {
+    const int w = T - 2;
+    const int nfull = n / w, rem = n - nfull * w;
+    float *rc = ring + (i0 + lane);
+    float *mc = mir + (i0 + lane);
+    const float *lp = ring + (i0 - w - 4);                     // wave-uniform: the four outputs in front of the previous step
+    const float *wp = win2 + lane;
+    float Y = 0.f, x = 0.f, f = 0.f, La, Lb, Lc, Ld;
+    if (lane < w) {
+        Y = rc[-w];
+        x = rc[0];
+        if (XF) f = wp[0];
+    }
+    La = lp[0]; Lb = lp[1]; Lc = lp[2]; Ld = lp[3];
+    auto step = [&](bool more) {
+        // operands of the NEXT step first (none of them depends on this step's result)
+        float xn = 0.f, fn = 0.f, Na = 0.f, Nb = 0.f, Nc = 0.f, Nd = 0.f;
+        if (more) {
+            xn = rc[w];
+            if (XF) fn = wp[w];
+            Na = lp[w]; Nb = lp[w + 1]; Nc = lp[w + 2]; Nd = lp[w + 3];
+        }
+        const float S1 = dpp_shr1(Ld, Y), S2 = dpp_shr1(Lc, S1), S3 = dpp_shr1(Lb, S2), S4 = dpp_shr1(La, S3);
+        float y = x;
+        if (XF) {
+            const float nf = 1.0f - f;
+            y += (nf * ga[0]) * S2;
+            y += (nf * ga[1]) * (S1 + S3);
+            y += (nf * ga[2]) * (Y + S4);
+            y += (f * gb[0]) * S2;
+            y += (f * gb[1]) * (S1 + S3);
+            y += (f * gb[2]) * (Y + S4);
+        } else {
+            y += ga[0] * S2;
+            y += ga[1] * (S1 + S3);
+            y += ga[2] * (Y + S4);
+        }
+        rc[0] = y;
+        mc[0] = y;
+        Y = y;
+        x = xn; f = fn; La = Na; Lb = Nb; Lc = Nc; Ld = Nd;
+        rc += w; mc += w; lp += w; wp += w;
+    };
+    if (lane < w) {
+        for (int sidx = 0; sidx < nfull; sidx++) {
+            step(true);                                        // (reads one step past the run: inside the buffer, unused)
+            NYQ_POST_SYNC();
+        }
+    }
+    if (lane < rem) step(false);
+    NYQ_POST_SYNC();
+}
+
+// One comb_filter() call (celt.c:114-172) on ring[r0, r0+n): cross-fade (T0,g0,ts0) -> (T1,g1,ts1) over the first 120
+// samples, constant after; every output y[idx] is stored at ring[idx] AND mir[idx].
+__device__ __forceinline__ void pipe_comb_call(float *ring, float *mir, int lane, int r0, int n, int T0, int T1,
+                                               float g0, float g1, int ts0, int ts1, const float *win2,
+                                               unsigned long long *stm = nullptr) {
+    if (g0 == 0.f && g1 == 0.f) {                             // celt.c:126-132: y = x
+        pipe_copy(ring, mir, lane, r0, n);
+        return;
+    }
+    float g00, g01, g02, g10, g11, g12;
+    comb_gains(g0, ts0, g00, g01, g02);
+    comb_gains(g1, ts1, g10, g11, g12);
+    // Outputs i .. i+w-1 are independent when w <= T-2 for every ACTIVE tap set (a switched-off side may carry any
+    // period, even 0: the reference multiplies those taps by zero, here they are skipped and do not bound w).
+    const int o = 4 * lane;
+    const float ga[3] = {g00, g01, g02}, gb[3] = {g10, g11, g12};
+    int tmin = 4 * kWave + 2;
+    if (g0 != 0.f && T0 < tmin) tmin = T0;
+    if (g1 != 0.f && T1 < tmin) tmin = T1;
+    if (T0 == T1 && g0 != 0.f && g1 != 0.f && T1 - 2 <= kWave) {
+        // both tap sets on one short period (always the case for the first 120 samples of a frame once the filter
+        // runs: celt_decoder_clean.c:678-683 makes old = current): recursion in registers
+        pipe_run_dpp<true>(ring, mir, lane, r0, kOverlap, T1, ga, gb, win2);
+    } else if (tmin - 2 <= kWave) {
+        // short periods: one output per lane
+        const int w = tmin - 2;
+        const int nfull = kOverlap / w, rem = kOverlap - nfull * w;
+        float *rc = ring + (r0 + lane);
+        float *mc = mir + (r0 + lane);
+        const float *wp = win2 + lane;
+        auto step = [&]() {
+            const float f = *wp;
+            const float nf = 1.0f - f;
+            float y = rc[0];
+            if (g0 != 0.f) {
+                const float *t = rc - T0 - 2;
+                const float x0 = t[0], x1 = t[1], x2 = t[2], x3 = t[3], x4 = t[4];
+                y += (nf * g00) * x2;
+                y += (nf * g01) * (x3 + x1);
+                y += (nf * g02) * (x4 + x0);
+            }
+            if (g1 != 0.f) {
+                const float *t = rc - T1 - 2;
+                const float x0 = t[0], x1 = t[1], x2 = t[2], x3 = t[3], x4 = t[4];
+                y += (f * g10) * x2;
+                y += (f * g11) * (x3 + x1);
+                y += (f * g12) * (x4 + x0);
+            }
+            rc[0] = y;
+            mc[0] = y;
+        };
+        if (lane < w) {
+            for (int sidx = 0; sidx < nfull; sidx++) {
+                step();
+                rc += w;
+                mc += w;
+                wp += w;
+                NYQ_POST_SYNC();
+            }
+        }
+        if (lane < rem) step();
+        NYQ_POST_SYNC();
+    } else {
+        const int w = (tmin - 2) & ~3;
+        for (int base = 0; base < kOverlap; base += w) {
+            if (o < w && base + o < kOverlap) {
+                const int idx = r0 + base + o;
+                const f4 fw = lds4(win2, base + o);
+                const float f[4] = {fw.x, fw.y, fw.z, fw.w};
+                const f4 cen = lds4(ring, idx);
+                float y[4] = {cen.x, cen.y, cen.z, cen.w};
+                if (g0 != 0.f) {
+                    float x[1][8];
+                    taps8<1>(ring, idx - T0 - 2, x);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const float nf = 1.0f - f[u];
+                        y[u] += (nf * g00) * x[0][u + 2];
+                        y[u] += (nf * g01) * (x[0][u + 3] + x[0][u + 1]);
+                        y[u] += (nf * g02) * (x[0][u + 4] + x[0][u]);
+                    }
+                }
+                if (g1 != 0.f) {
+                    float x[1][8];
+                    taps8<1>(ring, idx - T1 - 2, x);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        y[u] += (f[u] * g10) * x[0][u + 2];
+                        y[u] += (f[u] * g11) * (x[0][u + 3] + x[0][u + 1]);
+                        y[u] += (f[u] * g12) * (x[0][u + 4] + x[0][u]);
+                    }
+                }
+                sts4(ring, idx, f4{y[0], y[1], y[2], y[3]});
+                sts4(mir, idx, f4{y[0], y[1], y[2], y[3]});
+            }
+            NYQ_POST_SYNC();
+        }
+    }
+    const int i0 = r0 + kOverlap, nc = n - kOverlap;
+    if (nc <= 0) return;
+    NYQ_STAMP_MID();
+    if (g1 == 0.f) {                                          // celt.c:163-169
+        pipe_copy(ring, mir, lane, i0, nc);
+        return;
+    }
+    if (T1 - 2 <= kWave) {
+        // short periods (the common case in real streams): one output per lane, recursion in registers
+        pipe_run_dpp<false>(ring, mir, lane, i0, nc, T1, gb, gb, win2);
+        return;
+    }
+    const int w1 = (T1 - 2 < 4 * kWave ? T1 - 2 : 4 * kWave) & ~3;
+    switch ((i0 - T1 - 2) & 3) {
+        case 0: pipe_const_wide<0>(ring, mir, lane, i0, nc, T1, g10, g11, g12, w1); break;
+        case 1: pipe_const_wide<1>(ring, mir, lane, i0, nc, T1, g10, g11, g12, w1); break;
+        case 2: pipe_const_wide<2>(ring, mir, lane, i0, nc, T1, g10, g11, g12, w1); break;
+        default: pipe_const_wide<3>(ring, mir, lane, i0, nc, T1, g10, g11, g12, w1); break;
+    }
+}
+
+// ---- de-emphasis of one frame (celt_decoder_clean.c:243-248) -----------------------------------------
+// t[j] = a[j] + c t[j-1] over N = NL * CH samples: lane l < NL runs the recurrence over its own CH consecutive
+// samples with a zero carry-in, ONE weighted wavefront scan with ratio q = c^CH turns the lane-end values into the
+// true ones, and each lane then adds c^k times the value entering its chunk.  The scan runs on DPP lane shifts
+// (row_shr 1, 2, 4, 8 inside the 16-lane rows, then row_bcast 15 and 31 across them): six VALU steps, no LDS.
+template <int N>
+struct DeGeo {
+    static constexpr int CH = (N + kWave - 1) / kWave;   // 15, 8, 4, 2
+    static constexpr int NL = N / CH;                    // 64, 60, 60, 60
+    static_assert(NL * CH == N, "frame splits evenly over the lanes");
+};
+
+struct DeConst {
+    float cstep[4];   // q^(2^k)
+    float wA;         // q^((lane & 15) + 1): weight of the previous row's last value
+    float wB;         // q^(lane - 31)      : weight of lane 31's value in rows 2, 3
+    float pw;         // q^lane
+    float pwEnd;      // q^NL
+};
+
+template <int N>
+__device__ __forceinline__ void deemph_init(DeConst &D, int lane) {
+    constexpr int CH = DeGeo<N>::CH, NL = DeGeo<N>::NL;
+    float q = 1.f;
+#pragma unroll
+    for (int k = 0; k < CH; k++) q *= kPreemph;
+    float st[7];
+    st[0] = q;
+#pragma unroll
+    for (int k = 1; k < 7; k++) st[k] = st[k - 1] * st[k - 1];
+    auto powq = [&](int e) {                                   // q^e, 0 <= e < 128
+        float r = 1.f;
+#pragma unroll
+        for (int k = 0; k < 7; k++)
+            if (e & (1 << k)) r *= st[k];
+        return r;
+    };
+#pragma unroll
+    for (int k = 0; k < 4; k++) D.cstep[k] = st[k];
+    D.wA = powq((lane & 15) + 1);
+    D.wB = powq(lane >= 32 ? lane - 31 : 0);
+    D.pw = powq(lane);
+    D.pwEnd = powq(NL);
+}
+
+// K frames side by side (their instruction streams interleave): src[k] the filtered frame (LDS, N floats),
+// stage[k] N floats of LDS that receive the scaled samples, mem[k] = coef0 * (last output), celt_decoder_clean.c:246
+template <int N, int K>
+__device__ __forceinline__ void deemph_frames(const float *const (&src)[K], float *const (&stage)[K], float (&mem)[K],
+                                              const bool (&on)[K], int lane, const DeConst &D) {
+    constexpr int CH = DeGeo<N>::CH, NL = DeGeo<N>::NL;
+    float loc[K][CH];
+    const int li = lane < NL ? lane : 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if (!on[k]) continue;
+        if constexpr (CH % 4 == 0) {
+#pragma unroll
+            for (int j = 0; j < CH; j += 4) {
+                const f4 q = lds4(src[k], li * CH + j);
+                loc[k][j] = q.x; loc[k][j + 1] = q.y; loc[k][j + 2] = q.z; loc[k][j + 3] = q.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CH; j++) loc[k][j] = src[k][li * CH + j];
+        }
+    }
+    float e[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        float acc = 0.f;
+        if (on[k]) {
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                acc = (loc[k][j] + 1e-30f) + kPreemph * acc;  // + VERY_SMALL
+                loc[k][j] = acc;
+            }
+        }
+        e[k] = lane < NL ? acc : 0.f;                          // e[l] -> sum_{i<=l} q^(l-i) acc[i]
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        e[k] += D.cstep[0] * dpp_zero<0x111, 0xf>(e[k]);      // row_shr:1
+        e[k] += D.cstep[1] * dpp_zero<0x112, 0xf>(e[k]);      // row_shr:2
+        e[k] += D.cstep[2] * dpp_zero<0x114, 0xf>(e[k]);      // row_shr:4
+        e[k] += D.cstep[3] * dpp_zero<0x118, 0xf>(e[k]);      // row_shr:8
+        e[k] += D.wA * dpp_zero<0x142, 0xa>(e[k]);            // row_bcast:15 into rows 1, 3
+        e[k] += D.wB * dpp_zero<0x143, 0xc>(e[k]);            // row_bcast:31 into rows 2, 3
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if (!on[k]) continue;
+        // value entering lane l's chunk: c t[l CH - 1] = c e[l-1] + q^l mem, with mem = c t[-1]
+        const float prevEnd = dpp_shr1(0.f, e[k]);
+        float cp = kPreemph * prevEnd + D.pw * mem[k];         // (lane 0: prevEnd = 0, pw = 1)
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            loc[k][j] = (loc[k][j] + cp) * (1.f / 32768.f);
+            cp *= kPreemph;
+        }
+        if (lane < NL) {
+            if constexpr (CH % 4 == 0) {
+#pragma unroll
+                for (int j = 0; j < CH; j += 4) sts4(stage[k], lane * CH + j, f4{loc[k][j], loc[k][j + 1], loc[k][j + 2], loc[k][j + 3]});
+            } else {
+#pragma unroll
+                for (int j = 0; j < CH; j++) stage[k][lane * CH + j] = loc[k][j];
+            }
+        }
+        mem[k] = kPreemph * __shfl(e[k], NL - 1) + D.pwEnd * mem[k];   // c t[N-1]
+    }
+}
+
+// post-filter parameters of one frame as the I/O wave hands them to the comb wave (LDS slot of 4 dwords)
+struct PipeParams {
+    int T;
+    float g;
+    int ts;
+    int pad;
+};
+
+template <int LM>
+__global__ __launch_bounds__(kWave *kPipeWaves, 3) void celt_post_pipe_kernel(PostArgs A, const float *__restrict__ window) {
+    constexpr int N = 120 << LM;
+    constexpr int NV = N / 4;
+    constexpr int NLD = (NV + kWave - 1) / kWave;   // float4 per lane and frame (4, 2, 1, 1)
+    constexpr int R0 = kPostHist;                   // frame start inside a buffer
+    constexpr int KEEP = kPostHist - N;             // history samples that survive a frame: cur[N, 1088) -> nxt[0, KEEP)
+    __shared__ __attribute__((aligned(16))) float bufs[kPipeUnits][2][kPostRing];
+    __shared__ __attribute__((aligned(16))) float win2[kOverlap];
+    __shared__ __attribute__((aligned(16))) PipeParams pslot[kPipeUnits][2];
+    for (int i = threadIdx.x; i < kOverlap; i += kWave * kPipeWaves) win2[i] = window[i] * window[i];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long nunits = A.nstreams * A.channels;
+    const long npairs = (nunits + kPipeUnits - 1) / kPipeUnits;
+    const long nfr = A.nframes;
+    __syncthreads();
+
+    // The two roles are two separate loops over the same workgroup units (the register allocator then sees two
+    // disjoint live ranges); both execute the same number of barriers per unit: one after the I/O wave's prologue,
+    // one per frame, one closing iteration -- the last also separates this unit's LDS use from the next prologue.
+#ifndef NYQ_PIPE_DBG_NO_COMB
+    if (wave < kPipeUnits) {
+        for (long pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+            const long u0 = pair * kPipeUnits;
+            // ---------------- comb wave of unit u0 + wave ----------------
+            const long u = u0 + wave;
+            const bool live = u < nunits;
+            const long s = live ? u / A.channels : 0;
+            const int c = (int)(u - s * A.channels);
+            float *bA = bufs[wave][0], *bB = bufs[wave][1];
+            int T_old = 0, T_cur = 0, ts_old = 0, ts_cur = 0;
+            float g_old = 0.f, g_cur = 0.f;
+            if (live && A.pf_state) {
+                const float *ps = A.pf_state + 6 * s;
+                T_old = (int)ps[0]; T_cur = (int)ps[1]; g_old = ps[2]; g_cur = ps[3]; ts_old = (int)ps[4]; ts_cur = (int)ps[5];
+            }
+            __syncthreads();                                   // prologue of the I/O wave done
+            NYQ_STAMP_DECL();
+            for (long f = 0; f <= nfr; f++) {
+                NYQ_STAMP(1);                                  // slot 1: waiting at the barrier
+                if (live && f < nfr) {
+                    float *cur = (f & 1) ? bB : bA, *nxt = (f & 1) ? bA : bB;
+                    float *mir = nxt - N;                      // mir[idx] = nxt[idx - N]
+                    const PipeParams P = pslot[wave][f & 1];
+                    const int T_new = __builtin_amdgcn_readfirstlane(P.T), ts_new = __builtin_amdgcn_readfirstlane(P.ts);
+                    const float g_new = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, P.g)));
+                    if (T_cur < kCombMinPeriod) T_cur = kCombMinPeriod;   // celt_decoder_clean.c:661-662
+                    if (T_old < kCombMinPeriod) T_old = kCombMinPeriod;
+                    if (T_cur > kCombMaxPeriod) T_cur = kCombMaxPeriod;   // (a decoder never produces more: keeps taps in the buffer)
+                    if (T_old > kCombMaxPeriod) T_old = kCombMaxPeriod;
+                    const int T_nw = T_new < kCombMinPeriod ? kCombMinPeriod : T_new > kCombMaxPeriod ? kCombMaxPeriod : T_new;
+                    NYQ_STAMP(2);                              // slot 2: parameters, set-up
+                    pipe_comb_call(cur, mir, lane, R0, kOverlap, T_old, T_cur, g_old, g_cur, ts_old, ts_cur, win2);
+                    NYQ_STAMP(3);                              // slot 3: first 120 samples (old -> current parameters)
+#ifdef NYQ_PIPE_STAMPS
+                    unsigned long long stm[2] = {st_t, 0};
+                    if (LM != 0)
+                        pipe_comb_call(cur, mir, lane, R0 + kOverlap, N - kOverlap, T_cur, T_nw, g_cur, g_new, ts_cur, ts_new, win2, stm);
+                    st_acc[4] += stm[1];                       // slot 4: cross-fade of the second call; slot 0: its constant part
+                    st_t = stm[0];
+#else
+                    if (LM != 0)
+                        pipe_comb_call(cur, mir, lane, R0 + kOverlap, N - kOverlap, T_cur, T_nw, g_cur, g_new, ts_cur, ts_new, win2);
+#endif
+                    T_old = T_cur; g_old = g_cur; ts_old = ts_cur;       // :672-677
+                    T_cur = T_new; g_cur = g_new; ts_cur = ts_new;
+                    if (LM != 0) { T_old = T_cur; g_old = g_cur; ts_old = ts_cur; }   // :678-683
+                }
+                NYQ_STAMP(0);                                  // slot 0: the comb steps of the frame
+                __syncthreads();
+            }
+            if (wave == 0) NYQ_STAMP_FLUSH(0);
+            if (live && A.pf_state_out && c == 0 && lane == 0) {
+                float *ps = A.pf_state_out + 6 * s;
+                ps[0] = (float)T_old; ps[1] = (float)T_cur; ps[2] = g_old; ps[3] = g_cur; ps[4] = (float)ts_old; ps[5] = (float)ts_cur;
+            }
+        }
+    }
+#endif
+#ifndef NYQ_PIPE_DBG_NO_IO
+    if (wave >= kPipeUnits) {
+        DeConst D;
+        deemph_init<N>(D, lane);
+        for (long pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+            const long u0 = pair * kPipeUnits;
+            // ---------------- I/O wave for both units ----------------
+            const bool pairOut = A.channels == 2;              // both units are the channels of one stream: interleaved 16-byte stores
+            bool live[kPipeUnits];
+            long sU[kPipeUnits];
+            int cU[kPipeUnits];
+            const vf4 *src[kPipeUnits];
+            float mem[kPipeUnits];
+            // the prefetched frame (+ its parameters): frame f+1 lands from these registers in iteration f, right after
+            // that frame f+2 is fetched into them -- the loads have a whole frame time to arrive, and the wait for them
+            // sits in front of this iteration's stores (vmcnt counts loads and stores in issue order)
+            vf4 nx[kPipeUnits][NLD];
+            int pT[kPipeUnits], pS[kPipeUnits];
+            float pG[kPipeUnits];
+#pragma unroll
+            for (int k = 0; k < kPipeUnits; k++) {
+                const long u = u0 + k;
+                live[k] = u < nunits;
+                sU[k] = live[k] ? u / A.channels : 0;
+                cU[k] = (int)(u - sU[k] * A.channels);
+                src[k] = reinterpret_cast<const vf4 *>(A.pcm + (live[k] ? u : 0) * nfr * N);
+                mem[k] = (live[k] && A.deemph) ? A.deemph[u] : 0.f;
+                pT[k] = 0; pS[k] = 0; pG[k] = 0.f;
+#pragma unroll
+                for (int q = 0; q < NLD; q++) nx[k][q] = vf4{0, 0, 0, 0};
+            }
+            auto fetch = [&](long fidx) {                      // frame fidx and its parameters -> registers
+#pragma unroll
+                for (int k = 0; k < kPipeUnits; k++) {
+                    if (!live[k]) continue;
+                    const vf4 *fr = src[k] + fidx * NV;
+#pragma unroll
+                    for (int q = 0; q < NLD; q++) {
+                        const int v = lane + q * kWave;
+                        nx[k][q] = fr[v < NV ? v : NV - 1]; // lanes past the frame re-read its last vector
+                    }
+                    const long pi = sU[k] * nfr + fidx;
+                    pT[k] = A.pf_pitch[pi];
+                    pG[k] = A.pf_gain[pi];
+                    pS[k] = A.pf_tapset[pi];
+                }
+            };
+            auto land = [&](long fidx, int b) {                // registers -> frame region of buffer b, parameter slot fidx & 1
+#pragma unroll
+                for (int k = 0; k < kPipeUnits; k++) {
+                    if (!live[k]) continue;
+#pragma unroll
+                    for (int q = 0; q < NLD; q++) {
+                        const int v = lane + q * kWave;
+                        if (v < NV) sts4(bufs[k][b], R0 + 4 * v, nx[k][q]);
+                    }
+                    if (lane == 0) {
+                        PipeParams *ps = &pslot[k][fidx & 1];
+                        ps->T = pT[k];
+                        ps->g = pG[k];
+                        ps->ts = pS[k];
+                    }
+                }
+            };
+            // prologue: buffer A = [history before frame 0 | frame 0]
+#pragma unroll
+            for (int k = 0; k < kPipeUnits; k++) {
+                if (!live[k]) continue;
+#pragma unroll 1
+                for (int j = lane; j < kPostHist; j += kWave) bufs[k][0][j] = A.hist ? A.hist[(u0 + k) * kPostHist + j] : 0.f;
+            }
+            if (nfr > 0) {
+                fetch(0);
+                land(0, 0);
+                if (nfr > 1) fetch(1);
+            }
+            __syncthreads();
+            NYQ_STAMP_DECL();
+            for (long f = 0; f <= nfr; f++) {
+                NYQ_STAMP(5);                                  // slot 5: waiting at the barrier
+                const int cb = (int)(f & 1), nb = cb ^ 1;
+                // the part of cur's history that is still history after frame f
+                if (f < nfr && KEEP > 0) {
+#pragma unroll
+                    for (int k = 0; k < kPipeUnits; k++)
+                        if (live[k]) pipe_copy(bufs[k][cb] + N, bufs[k][nb], lane, 0, KEEP);
+                }
+                NYQ_STAMP(0);                                  // slot 0: history carry-over
+                // frame f-1 is final in cur[1088 - N, 1088): de-emphasis, staged in nxt's frame region, picked up again
+                // in the output's interleaved order (registers) -- before the raw frame f+1 lands in that region
+                vf4 sv[2 * NLD];
+                if (f >= 1) {
+                    const float *const dsrc[kPipeUnits] = {bufs[0][cb] + R0 - N, bufs[1][cb] + R0 - N};
+                    float *const dstg[kPipeUnits] = {bufs[0][nb] + R0, bufs[1][nb] + R0};
+                    deemph_frames<N, kPipeUnits>(dsrc, dstg, mem, live, lane, D);
+                    NYQ_POST_SYNC();
+                    if (pairOut) {
+                        // float4 v = {L[2v], R[2v], L[2v+1], R[2v+1]}
+#pragma unroll
+                        for (int q = 0; q < 2 * NLD; q++) {
+                            const int v = lane + q * kWave, vv = v < 2 * NV ? v : 0;
+                            const float2 l = *reinterpret_cast<const float2 *>(dstg[0] + 2 * vv);
+                            const float2 r = *reinterpret_cast<const float2 *>(dstg[1] + 2 * vv);
+                            sv[q] = vf4{l.x, r.x, l.y, r.y};
+                        }
+                    } else if (A.channels == 1) {
+#pragma unroll
+                        for (int k = 0; k < kPipeUnits; k++)
+#pragma unroll
+                            for (int q = 0; q < NLD; q++) {
+                                const int v = lane + q * kWave;
+                                sv[k * NLD + q] = *reinterpret_cast<const vf4 *>(dstg[k] + 4 * (v < NV ? v : 0));
+                            }
+                    } else {
+                        // any other channel count: strided 4-byte stores straight from the stage (rare shapes)
+#pragma unroll
+                        for (int k = 0; k < kPipeUnits; k++) {
+                            if (!live[k]) continue;
+                            float *dst = A.out + (sU[k] * nfr * N + (f - 1) * N) * A.channels + cU[k];
+#pragma unroll 2
+                            for (int j = lane; j < N; j += kWave) dst[(long)j * A.channels] = dstg[k][j];
+                        }
+                    }
+                    NYQ_POST_SYNC();
+                }
+                NYQ_STAMP(1);                                  // slot 1: de-emphasis + pick-up
+                if (f + 1 < nfr) land(f + 1, nb);
+                NYQ_STAMP(2);                                  // slot 2: prefetched frame -> LDS (waits for its loads)
+                if (f >= 1) {
+                    const long t0 = (f - 1) * N;               // first sample of the frame
+                    if (pairOut) {
+                        vf4 *d4 = reinterpret_cast<vf4 *>(A.out + (sU[0] * nfr * N + t0) * 2);
+#pragma unroll
+                        for (int q = 0; q < 2 * NLD; q++) {
+                            const int v = lane + q * kWave;
+                            if (v < 2 * NV) d4[v] = sv[q];
+                        }
+                    } else if (A.channels == 1) {
+#pragma unroll
+                        for (int k = 0; k < kPipeUnits; k++) {
+                            if (!live[k]) continue;
+                            vf4 *d4 = reinterpret_cast<vf4 *>(A.out + sU[k] * nfr * N + t0);
+#pragma unroll
+                            for (int q = 0; q < NLD; q++) {
+                                const int v = lane + q * kWave;
+                                if (v < NV) d4[v] = sv[k * NLD + q];
+                            }
+                        }
+                    }
+                }
+                if (f + 2 < nfr) fetch(f + 2);
+                NYQ_STAMP(3);                                  // slot 3: global stores of frame f-1, fetch of frame f+2
+                if (f == nfr) {
+                    // state for the next call: cur = [history in front of the next frame | ...]
+#pragma unroll
+                    for (int k = 0; k < kPipeUnits; k++) {
+                        if (!live[k]) continue;
+                        if (A.hist)
+#pragma unroll 1
+                            for (int j = lane; j < kPostHist; j += kWave) A.hist[(u0 + k) * kPostHist + j] = bufs[k][cb][j];
+                        if (A.deemph && lane == 0) A.deemph[u0 + k] = mem[k];
+                    }
+                }
+                NYQ_STAMP(4);
+                __syncthreads();
+            }
+            NYQ_STAMP_FLUSH(8);
+        }
+    }
+#endif
+}
+
+}  // namespace nyq

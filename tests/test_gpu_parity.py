@@ -603,7 +603,7 @@ def test_random_shapes_synth_then_post_vs_oracle(ctx, oracle, seed):
     pst = np.stack([[rng.integers(15, 1023), rng.integers(15, 1023), 0.28125, 0.375, 1, 2] for _ in range(ns)]).astype(np.float32)
     dm = (rng.standard_normal(ns * ch) * 10).astype(np.float32)
     want, filt, wst, wdm = oracle.celt_post(lm, np.concatenate([hist, wp.reshape(ns, ch, nf * n)], axis=2), 1088, pitch, gain, taps, pst, dm)
-    for mode in (("0", "1") if ch == 2 else ("0",)):
+    for mode in (("0", "1", "2") if ch == 2 else ("0", "2")):     # wave per channel, per stereo pair, workgroup pipeline
         os.environ["NYQ_POST_STEREO_PAIRS"] = mode
         try:
             out, gst, gh, gdm = _post_on_gpu(ctx, lm, wp.reshape(ns, ch, nf * n), pitch, gain, taps, pst, hist.reshape(ns * ch, 1088), dm, ch)

@@ -1,0 +1,129 @@
+// tools/chainbench.hip -- A/B harness of the frames -> PCM chain (post-filter stage forms; fused forms), ONE process,
+// variants interleaved round-robin (cdna_hip_programming.md section 5.4 rule 24).  Tuning tool, not part of the product.
+//
+//   hipcc -O3 -fno-slp-vectorize --offload-arch=gfx950 -std=c++17 -Ilibnyquist_amd/csrc -o tools/chainbench tools/chainbench.hip
+//   hipcc ... -DNYQ_PIPE_STAMPS -o tools/chainbench_stamps tools/chainbench.hip     (per-role cycle accounting, diagnostic)
+//   ./tools/chainbench [rounds] [nstreams] [nframes] [case]     case: mix | short | long | all | off
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "nyq_kernels.hpp"
+#include "nyq_post_kernels.hpp"
+#include "nyq_post_pipe.hpp"
+using namespace nyq;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+struct Variant {
+    std::string name;
+    std::function<void()> run;
+    std::vector<float> ms;
+};
+
+int main(int argc, char **argv) {
+    const int rounds = argc > 1 ? atoi(argv[1]) : 10;
+    const long ns = argc > 2 ? atol(argv[2]) : 1024, nf = argc > 3 ? atol(argv[3]) : 256;
+    const char *cs = argc > 4 ? argv[4] : "mix";
+    const int ch = 2, N = 960;
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    const size_t nx = (size_t)ns * ch * nf * N;
+    float *d_pcm, *d_out, *d_win, *d_gain;
+    int *d_pitch, *d_tap;
+    CK(hipMalloc(&d_pcm, nx * 4)); CK(hipMalloc(&d_out, nx * 4)); CK(hipMalloc(&d_win, 120 * 4));
+    CK(hipMalloc(&d_gain, ns * nf * 4)); CK(hipMalloc(&d_pitch, ns * nf * 4)); CK(hipMalloc(&d_tap, ns * nf * 4));
+    {
+        std::vector<float> h(nx);
+        unsigned s = 4;
+        for (size_t i = 0; i < nx; i++) { s = s * 1664525u + 1013904223u; h[i] = ((float)(s >> 8) / 8388608.0f - 1.0f) * 300.f; }
+        CK(hipMemcpy(d_pcm, h.data(), nx * 4, hipMemcpyHostToDevice));
+        std::vector<float> w(120);
+        for (int i = 0; i < 120; i++) { double x = sin(.5 * M_PI * (i + .5) / 120); w[i] = (float)sin(.5 * M_PI * x * x); }
+        CK(hipMemcpy(d_win, w.data(), 120 * 4, hipMemcpyHostToDevice));
+        std::mt19937 g(7);
+        std::vector<int> pp(ns * nf), pt(ns * nf);
+        std::vector<float> pg(ns * nf);
+        int lo = 15, hi = 80;
+        double on = 0.7;
+        if (!strcmp(cs, "short")) { hi = 60; on = 1.0; }
+        if (!strcmp(cs, "long")) { lo = 300; hi = 1000; on = 1.0; }
+        if (!strcmp(cs, "all")) { hi = 1000; on = 8.0 / 9.0; }
+        if (!strcmp(cs, "off")) on = 0.0;
+        for (long i = 0; i < ns * nf; i++) {
+            pp[i] = lo + (int)(g() % (unsigned)(hi - lo));
+            pt[i] = (int)(g() % 3u);
+            pg[i] = ((g() % 1000000u) / 1e6 < on) ? (1 + (int)(g() % 8u)) * 0.09375f : 0.f;
+        }
+        CK(hipMemcpy(d_pitch, pp.data(), ns * nf * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_tap, pt.data(), ns * nf * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_gain, pg.data(), ns * nf * 4, hipMemcpyHostToDevice));
+    }
+    PostArgs A;
+    A.pcm = d_pcm; A.pf_pitch = d_pitch; A.pf_gain = d_gain; A.pf_tapset = d_tap; A.pf_state = nullptr; A.pf_state_out = nullptr;
+    A.hist = nullptr; A.deemph = nullptr; A.out = d_out; A.nstreams = ns; A.nframes = nf; A.channels = ch;
+
+    std::vector<Variant> v;
+    {
+        int occ = 0;
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, celt_post_kernel<3, 4, 1>, kWave * 4, 0));
+        const unsigned grid = (unsigned)std::min<long>((ns * ch + 3) / 4, (long)occ * cus);
+        char nm[128]; snprintf(nm, sizeof nm, "r1 wave per channel (occ %d blk/CU)", occ);
+        v.push_back({nm, [=] { hipLaunchKernelGGL((celt_post_kernel<3, 4, 1>), dim3(grid), dim3(kWave * 4), 0, 0, A, d_win); }, {}});
+    }
+    {
+        int occ = 0;
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, celt_post_kernel<3, 2, 2>, kWave * 2, 0));
+        const unsigned grid = (unsigned)std::min<long>((ns + 1) / 2, (long)occ * cus);
+        char nm[128]; snprintf(nm, sizeof nm, "r1 wave per stereo pair (occ %d blk/CU)", occ);
+        v.push_back({nm, [=] { hipLaunchKernelGGL((celt_post_kernel<3, 2, 2>), dim3(grid), dim3(kWave * 2), 0, 0, A, d_win); }, {}});
+    }
+    {
+        int occ = 0;
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, celt_post_pipe_kernel<3>, kWave * kPipeWaves, 0));
+        const unsigned grid = (unsigned)std::min<long>((ns * ch + 1) / 2, (long)occ * cus);
+        char nm[128]; snprintf(nm, sizeof nm, "r2 workgroup pipeline (occ %d blk/CU, grid %u)", occ, grid);
+        v.push_back({nm, [=] { hipLaunchKernelGGL((celt_post_pipe_kernel<3>), dim3(grid), dim3(kWave * kPipeWaves), 0, 0, A, d_win); }, {}});
+    }
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (auto &x : v) x.run();
+    CK(hipDeviceSynchronize());
+#ifdef NYQ_PIPE_STAMPS
+    {
+        unsigned long long z[16] = {0};
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_pipe_stamps), z, sizeof z));
+        v.back().run();
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_pipe_stamps), sizeof z));
+        const double nwg = (double)((ns * ch + 1) / 2), per = nwg * nf;   // per workgroup-frame (comb: wave 0 only)
+        printf("cycles per frame (s_memtime ticks, mean over workgroups), case %s\n", cs);
+        printf("  comb wave : set-up %.0f  first-120 %.0f  cross-fade %.0f  constant part %.0f  barrier wait %.0f\n", z[2] / per, z[3] / per,
+               z[4] / per, z[0] / per, z[1] / per);
+        printf("  I/O  wave : keep-copy %.0f  de-emphasis %.0f  store %.0f  land+fetch %.0f  tail %.0f  barrier wait %.0f\n",
+               z[8] / per, z[9] / per, z[10] / per, z[11] / per, z[12] / per, z[13] / per);
+    }
+#endif
+    for (int r = 0; r < rounds; r++)
+        for (auto &x : v) {
+            CK(hipEventRecord(a)); x.run(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+            float ms; CK(hipEventElapsedTime(&ms, a, b)); x.ms.push_back(ms);
+        }
+    CK(hipGetLastError());
+    printf("case %s: %ld streams x %ld frames x %d ch\n%-56s %9s %9s %9s %8s\n", cs, ns, nf, ch, "variant", "median ms", "min ms", "alg GB/s", "frac 8T");
+    for (auto &x : v) {
+        std::sort(x.ms.begin(), x.ms.end());
+        const float med = x.ms[x.ms.size() / 2], mn = x.ms[0];
+        const double gbs = 7680.0 * ns * nf * ch / (med * 1e-3) / 1e9;
+        printf("%-56s %9.4f %9.4f %9.1f %8.3f\n", x.name.c_str(), med, mn, gbs, gbs / 8000.0);
+    }
+    return 0;
+}

@@ -80,10 +80,10 @@ for label, lo, hi, gmax in () if ONLY and ONLY != 'post' else (("pitch 15..1000,
         pg = on * (torch.randint(1, 9, (ns, nf), generator=g, device=dev) * 0.09375).float()
     else:
         pg = (torch.randint(0, gmax, (ns, nf), generator=g, device=dev) * 0.09375).float()
-    for mode in ("0", "1"):      # one wave per channel (default) vs one wave per stereo pair, same process, same box
+    for mode in ("0", "1", "2"):      # one wave per channel vs one wave per stereo pair vs workgroup pipeline (default), same process, same box
         os.environ["NYQ_POST_STEREO_PAIRS"] = mode
         ms = timeit(lambda: ctx.celt_post_dev(3, pcm.data_ptr(), pp.data_ptr(), pg.data_ptr(), pt.data_ptr(), 0, 0, 0, 0, out.data_ptr(), ns, nf, ch), 5)
-        res.append(dict(op=f"celt_post_dev {ns} streams x {nf} frames x 2ch, {label}" + (" [stereo pairs]" if mode == "1" else ""),
+        res.append(dict(op=f"celt_post_dev {ns} streams x {nf} frames x 2ch, {label}" + (" [stereo pairs]" if mode == "1" else " [pipeline]" if mode == "2" else ""),
                         rows=ns * nf * ch, ms=ms, alg_GBps=ns * nf * ch * 7680 / ms / 1e6, rows_per_s=ns * nf * ch / ms * 1e3))
     del os.environ["NYQ_POST_STEREO_PAIRS"]
 if not ONLY or ONLY == 'post':
