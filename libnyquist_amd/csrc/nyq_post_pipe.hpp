@@ -114,6 +114,11 @@ __device__ __forceinline__ float dpp_zero(float v) {   // lanes without a source
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, ROWMASK == 0xf));
 }
 
+template <int Q>
+__device__ __forceinline__ float dpp_quad_bcast(float v) {   // every lane of a quad receives the quad's lane Q
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), Q * 0x55, 0xf, 0xf, true));
+}
+
 // A run of n outputs ring[i0, i0+n) of ONE period T with w = T-2 <= 64 outputs per step, the recursion kept in
 // REGISTERS: lane l of a step needs y[base_prev + l - 4 .. base_prev + l] = the previous step's outputs of lanes
 // l-4 .. l, i.e. four one-lane shifts of the register that holds them (v_mov_b32_dpp wave_shr:1); what lanes 0..3
@@ -130,24 +135,27 @@ __device__ __forceinline__ void pipe_run_dpp(float *ring, float *mir, int lane, 
     const int nfull = n / w, rem = n - nfull * w;
     float *rc = ring + (i0 + lane);
     float *mc = mir + (i0 + lane);
-    const float *lp = ring + (i0 - w - 4);                     // wave-uniform: the four outputs in front of the previous step
     const float *wp = win2 + lane;
-    float Y = 0.f, x = 0.f, f = 0.f, La, Lb, Lc, Ld;
+    float Y = 0.f, x = 0.f, f = 0.f;
     if (lane < w) {
         Y = rc[-w];
         x = rc[0];
         if (XF) f = wp[0];
     }
-    La = lp[0]; Lb = lp[1]; Lc = lp[2]; Ld = lp[3];
+    float R = rc[-w - 4];                                      // lanes 0..3: the four outputs in front of the previous step
+    float O1, O2, O3, O4;                                      // lane 0: y[base_prev - 1 .. base_prev - 4]
+    auto spread = [&]() {                                      // needs lanes 0..3 active: the quad broadcast reads them
+        O1 = dpp_quad_bcast<3>(R); O2 = dpp_quad_bcast<2>(R); O3 = dpp_quad_bcast<1>(R); O4 = dpp_quad_bcast<0>(R);
+    };
     auto step = [&](bool more) {
         // operands of the NEXT step first (none of them depends on this step's result)
-        float xn = 0.f, fn = 0.f, Na = 0.f, Nb = 0.f, Nc = 0.f, Nd = 0.f;
+        float xn = 0.f, fn = 0.f, Rn = 0.f;
         if (more) {
             xn = rc[w];
             if (XF) fn = wp[w];
-            Na = lp[w]; Nb = lp[w + 1]; Nc = lp[w + 2]; Nd = lp[w + 3];
+            Rn = rc[-4];
         }
-        const float S1 = dpp_shr1(Ld, Y), S2 = dpp_shr1(Lc, S1), S3 = dpp_shr1(Lb, S2), S4 = dpp_shr1(La, S3);
+        const float S1 = dpp_shr1(O1, Y), S2 = dpp_shr1(O2, S1), S3 = dpp_shr1(O3, S2), S4 = dpp_shr1(O4, S3);
         float y = x;
         if (XF) {
             const float nf = 1.0f - f;
@@ -165,15 +173,17 @@ __device__ __forceinline__ void pipe_run_dpp(float *ring, float *mir, int lane, 
         rc[0] = y;
         mc[0] = y;
         Y = y;
-        x = xn; f = fn; La = Na; Lb = Nb; Lc = Nc; Ld = Nd;
-        rc += w; mc += w; lp += w; wp += w;
+        x = xn; f = fn; R = Rn;
+        rc += w; mc += w; wp += w;
     };
     if (lane < w) {
         for (int sidx = 0; sidx < nfull; sidx++) {
+            spread();
             step(true);                                        // (reads one step past the run: inside the buffer, unused)
             NYQ_POST_SYNC();
         }
     }
+    spread();                                                  // (whole wave: the remainder may have fewer than four lanes)
     if (lane < rem) step(false);
     NYQ_POST_SYNC();
 }
