@@ -131,6 +131,21 @@ int nyq_celt_post_dev(nyq_ctx *ctx, int LM, const float *d_pcm, const int *d_pf_
                       float *d_pf_state_out, float *d_hist, float *d_deemph, float *d_out,
                       size_t nstreams, size_t nframes, int channels);
 
+/* The two stages above as ONE operator: freq[] -> interleaved PCM, everything celt_decode_with_ec does after
+ * denormalise_bands (celt_decoder_clean.c:620-723).  For 20 ms stereo frames (LM 3, channels 2:
+ * nyq_celt_chain_fused_supported) it is a single launch in which the time-domain frame never leaves the CU
+ * (3840 B in + 3840 B out per channel-frame instead of twice that); every other shape runs the two kernels
+ * above through d_pcm ([nstreams*channels][nframes*N]) and d_work (nyq_celt_synth_work_floats), which the
+ * fused shape ignores (NULL allowed).  State pointers as in the two stages: d_overlap [nstreams*channels][60],
+ * d_hist [nstreams*channels][1088], d_deemph [nstreams*channels], d_pf_state_in/out [nstreams][6]; NULL = reset
+ * decoder / discard.  Asynchronous, no allocation. */
+int nyq_celt_chain_fused_supported(int LM, int channels);
+int nyq_celt_chain_dev(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned char *d_transient,
+                       const int *d_pf_pitch, const float *d_pf_gain, const int *d_pf_tapset,
+                       const float *d_pf_state_in, float *d_pf_state_out, float *d_overlap, float *d_hist,
+                       float *d_deemph, float *d_out, float *d_pcm, float *d_work,
+                       size_t nstreams, size_t nframes, int channels);
+
 /* libvorbis' mdct_backward (third_party/libvorbis/src/mdct.c:397-491) on `batch` rows: n/2 coefficients
  * in, n samples out per row, n a power of two in 64..8192 (every Vorbis block size).
  * d_in [batch][n/2], d_out [batch][n].  out[i] = sum_k in[k] cos(2 pi/n (i + 1/2 + n/4)(k + 1/2)):

@@ -22,6 +22,7 @@ EXPORTS = [
     "nyq_ctx_synchronize", "nyq_ctx_set_tables", "nyq_ctx_get_tables", "nyq_ctx_device_info",
     "nyq_ifft_batch_dev", "nyq_imdct_batch_dev", "nyq_imdct_chain_dev",
     "nyq_celt_synth_work_floats", "nyq_celt_synth_dev", "nyq_celt_synth", "nyq_celt_post_dev",
+    "nyq_celt_chain_fused_supported", "nyq_celt_chain_dev",
     "nyq_celt_frames_to_pcm", "nyq_celt_frames_to_pcm_window", "nyq_celt_state_floats", "nyq_vorbis_imdct_batch_dev", "nyq_vorbis_imdct_batch",
     "nyq_ifft_batch", "nyq_imdct_batch", "nyq_imdct_chain", "nyq_host_alloc", "nyq_host_free",
     "processMDCTCuda", "processMDCTCudaB1C2", "cleanupCudaBuffers", "printCudaVersion",
@@ -107,6 +108,8 @@ def load(path=None):
     L.nyq_celt_synth_dev.argtypes = [vp, i, fp, fp, fp, fp, fp, sz, sz, i]
     L.nyq_celt_synth.argtypes = [vp, i, fp, fp, fp, fp, sz, sz, i]
     L.nyq_celt_post_dev.argtypes = [vp, i, fp, fp, fp, fp, fp, fp, fp, fp, fp, sz, sz, i]
+    L.nyq_celt_chain_fused_supported.argtypes = [i, i]
+    L.nyq_celt_chain_dev.argtypes = [vp, i] + [fp] * 13 + [sz, sz, i]
     L.nyq_celt_frames_to_pcm.argtypes = [vp, i, fp, fp, fp, fp, fp, fp, fp, sz, sz, i]
     L.nyq_celt_frames_to_pcm_window.argtypes = [vp, i, fp, fp, fp, fp, fp, fp, fp, sz, sz, i, sz]
     L.nyq_celt_state_floats.argtypes = [sz, i]
@@ -282,6 +285,14 @@ class Context:
         self._ck(self.lib.nyq_celt_post_dev(self.h, lm, V(d_pcm), V(d_pf_pitch), V(d_pf_gain), V(d_pf_tapset),
                                             V(d_pf_state_in), V(d_pf_state_out), V(d_hist), V(d_deemph), V(d_out),
                                             nstreams, nframes, channels))
+
+    def celt_chain_dev(self, lm, d_freq, d_transient, d_pf_pitch, d_pf_gain, d_pf_tapset, d_pf_state_in, d_pf_state_out,
+                       d_overlap, d_hist, d_deemph, d_out, d_pcm, d_work, nstreams, nframes, channels):
+        """freq[] -> interleaved PCM (one fused launch for LM 3 stereo, the two kernels otherwise)."""
+        V = lambda p: C.c_void_p(p or 0)
+        self._ck(self.lib.nyq_celt_chain_dev(self.h, lm, V(d_freq), V(d_transient), V(d_pf_pitch), V(d_pf_gain), V(d_pf_tapset),
+                                             V(d_pf_state_in), V(d_pf_state_out), V(d_overlap), V(d_hist), V(d_deemph),
+                                             V(d_out), V(d_pcm), V(d_work), nstreams, nframes, channels))
 
     # -- device-resident operators (raw pointers)
     def ifft_batch_dev(self, nfft, d_in, d_out, batch):

@@ -19,6 +19,7 @@
 #include "nyq_kernels.hpp"
 #include "nyq_post_kernels.hpp"
 #include "nyq_post_pipe.hpp"
+#include "nyq_chain_fused.hpp"
 
 using namespace nyq;
 
@@ -50,6 +51,7 @@ struct nyq_ctx {
     int res_synth_short = 0;
     int res_post[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
     int res_post_pipe[4] = {0, 0, 0, 0};
+    int res_chain_fused = 0;
     int res_vorbis[12] = {0};
     float *d_vtab = nullptr;             // Vorbis rotation + twiddle tables of every block size, one allocation
     size_t vrot_off[12] = {0}, vtw_off[12] = {0};   // float offsets by log2(n/4)
@@ -491,6 +493,64 @@ extern "C" int nyq_celt_post_dev(nyq_ctx *ctx, int LM, const float *d_pcm, const
         case 2: return launch_post<2, 1>(ctx, A);
         default: return launch_post<3, 1>(ctx, A);
     }
+}
+
+// ---- freq[] -> PCM in one launch ---------------------------------------------------------------
+extern "C" int nyq_celt_chain_fused_supported(int LM, int channels) { return LM == 3 && channels == 2; }
+
+extern "C" int nyq_celt_chain_dev(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned char *d_transient,
+                                  const int *d_pf_pitch, const float *d_pf_gain, const int *d_pf_tapset,
+                                  const float *d_pf_state_in, float *d_pf_state_out, float *d_overlap, float *d_hist,
+                                  float *d_deemph, float *d_out, float *d_pcm, float *d_work, size_t nstreams,
+                                  size_t nframes, int channels) {
+    if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_celt_chain_dev: ctx is NULL");
+    if (LM < 0 || LM > 3) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_chain_dev: LM must be 0..3");
+    if (channels < 1 || channels > 255) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_chain_dev: channels must be 1..255");
+    if (nstreams == 0 || nframes == 0) return NYQ_OK;
+    if (!d_freq || !d_pf_pitch || !d_pf_gain || !d_pf_tapset || !d_out)
+        return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_chain_dev: NULL freq/parameters/out");
+    if (d_pf_state_in && d_pf_state_in == d_pf_state_out)
+        return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_chain_dev: pf_state_in and pf_state_out must not alias");
+    if (!aligned16(d_freq) || !aligned16(d_out) || !aligned16(d_overlap) || !aligned16(d_hist))
+        return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_chain_dev: device pointers must be 16-byte aligned");
+    // The fused kernel is correct (tests/test_gpu_chain.py) but measured 3x SLOWER than the two launches (6.1 ms vs 1.9 ms
+    // for 1024 x 256 stereo frames, profiles/r02_*): one IMDCT wave per four chains cannot keep up with the comb waves, and
+    // the LDS that would hold more IMDCT slices is what keeps every chain resident.  It runs only on request (NYQ_CHAIN_FUSED=1).
+    const char *force = std::getenv("NYQ_CHAIN_FUSED");
+    const bool fused = nyq_celt_chain_fused_supported(LM, channels) && force && force[0] == '1';
+    if (!fused) {
+        if (!d_pcm || !d_work)
+            return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_chain_dev: this frame size / channel count runs as two kernels and needs d_pcm and d_work");
+        int rc = nyq_celt_synth_dev(ctx, LM, d_freq, d_transient, d_pcm, d_overlap, d_work, nstreams, nframes, channels);
+        if (rc != NYQ_OK) return rc;
+        return nyq_celt_post_dev(ctx, LM, d_pcm, d_pf_pitch, d_pf_gain, d_pf_tapset, d_pf_state_in, d_pf_state_out, d_hist,
+                                 d_deemph, d_out, nstreams, nframes, channels);
+    }
+    ChainArgs A;
+    A.freq = d_freq;
+    A.transient = d_transient;
+    A.ov_state = d_overlap;
+    A.pf_pitch = d_pf_pitch;
+    A.pf_gain = d_pf_gain;
+    A.pf_tapset = d_pf_tapset;
+    A.pf_state = d_pf_state_in;
+    A.pf_state_out = d_pf_state_out;
+    A.hist = d_hist;
+    A.deemph = d_deemph;
+    A.out = d_out;
+    A.nstreams = (long)nstreams;
+    A.nframes = (long)nframes;
+    if (ctx->res_chain_fused == 0) {
+        int per_cu = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, celt_chain_fused_kernel, kWave * kFuseWaves, 0);
+        if (e != hipSuccess || per_cu < 1) per_cu = 1;
+        ctx->res_chain_fused = per_cu * ctx->cus;
+    }
+    const size_t ngroups = (nstreams + 1) / 2;
+    const unsigned grid = (unsigned)(ngroups < (size_t)ctx->res_chain_fused ? ngroups : (size_t)ctx->res_chain_fused);
+    hipLaunchKernelGGL(celt_chain_fused_kernel, dim3(grid), dim3(kWave * kFuseWaves), 0, ctx->stream, A, ctx->d_trig, ctx->d_window);
+    NYQ_HIP(ctx, hipGetLastError());
+    return NYQ_OK;
 }
 
 // ---- Vorbis inverse MDCT ---------------------------------------------------------------------

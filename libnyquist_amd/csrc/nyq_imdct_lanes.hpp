@@ -175,6 +175,7 @@ NYQ_HD cpx postrot(cpx v, float c, float s, float sine) {
 //                                   short blocks of a transient frame, celt_decoder_clean.c:292-300)
 //   static constexpr bool CHAINS    row g may take its carry from row g-1's raw tail
 //   bool valid(g); const float *in(g); int stride(); float *fin(g);
+//   float *head(g)  where out[0..60) of row g goes (fin(g) unless a caller keeps the row in a rotated layout)
 //   float *tail(g)  (nullptr: do not store);  const float *carry(g)  (nullptr: zeros);
 //   bool chain(g)   (CHAINS only: carry of row g = raw tail of row g-1 of this group,
 //                    or for g == 0 the tail left in the ring by the previous group)
@@ -192,6 +193,7 @@ struct IndepRows {
     NYQ_HD const float *in(int g) const { return in_ + (row0 + g) * (long)Geo<N2R>::NIN; }
     NYQ_HD int stride() const { return 1; }
     NYQ_HD float *fin(int g) const { return fin_ + (row0 + g) * (long)Geo<N2R>::NIN; }
+    NYQ_HD float *head(int g) const { return fin(g); }
     NYQ_HD float *tail(int g) const { return tail_ ? tail_ + (row0 + g) * kHalfOv : nullptr; }
     NYQ_HD const float *carry(int g) const { return carry_ ? carry_ + (row0 + g) * kHalfOv : nullptr; }
     NYQ_HD bool chain(int) const { return false; }
@@ -262,6 +264,7 @@ struct FrameLongRows {
     NYQ_HD const float *in(int g) const { return in0 + g * in_step; }
     NYQ_HD int stride() const { return 1; }
     NYQ_HD float *fin(int g) const { return fin0 + g * (long)N; }
+    NYQ_HD float *head(int g) const { return fin(g); }
     // row 0 of a later group of the chunk chains to the ring slot the previous group left
     NYQ_HD bool chain(int g) const { return (g > 0 || qq > 0) && is_long(g - 1); }
     NYQ_HD const float *carry(int) const { return nullptr; }
@@ -294,6 +297,7 @@ struct FrameShortRows {
     NYQ_HD const float *in(int g) const { return in0 + (b0 + g); }
     NYQ_HD int stride() const { return B; }
     NYQ_HD float *fin(int g) const { return fin0 + 120L * (b0 + g); }
+    NYQ_HD float *head(int g) const { return fin(g); }
     NYQ_HD bool chain(int g) const { return b0 + g > 0; }
     NYQ_HD const float *carry(int) const { return nullptr; }
     NYQ_HD float *tail(int g) const { return (b0 + g == B - 1) ? tail_slot : nullptr; }
@@ -471,7 +475,7 @@ NYQ_HD void stage_out(const LaneConst<N2R> &K, int lane, const cpx *lds, float *
                 f4 hi, lo;
                 tdac_mix<N2R>(K, F, C, hi, lo);
                 st_f4<NT>(orow + 60 + 4 * j, hi);
-                st_f4<NT>(orow + 56 - 4 * j, lo);
+                st_f4<NT>(rows.head(g) + 56 - 4 * j, lo);
                 float *tl = rows.tail(g);
                 if (tl) st_f4<NT>(tl + 56 - 4 * j, Bk);
             }
@@ -506,7 +510,7 @@ NYQ_HD void stage_out_heads(const LaneConst<N2R> &K, int lane, const float *ring
         tdac_mix<N2R>(K, H.F[sub], C, hi, lo);
         float *orow = rows.fin(g);
         st_f4<NT>(orow + 60 + 4 * j, hi);
-        st_f4<NT>(orow + 56 - 4 * j, lo);
+        st_f4<NT>(rows.head(g) + 56 - 4 * j, lo);
         float *tl = rows.tail(g);
         if (tl) st_f4<NT>(tl + 56 - 4 * j, H.Bk[sub]);
     }

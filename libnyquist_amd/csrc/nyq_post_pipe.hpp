@@ -64,14 +64,16 @@ __device__ unsigned long long g_stamp_mid_t;   // (unused placeholder: keeps the
 constexpr int kPipeUnits = 2;          // chains per workgroup
 
 // copy cur[i0, i0+n) -> mir[i0, i0+n) (n, i0 multiples of 4), whole wave
+template <bool MIR>
 __device__ __forceinline__ void pipe_copy(const float *cur, float *mir, int lane, int i0, int n) {
+    if (!MIR) return;                                          // single-buffer callers filter in place: nothing to copy
 #pragma unroll 2
     for (int v = lane; v < n / 4; v += kWave) sts4(mir, i0 + 4 * v, *reinterpret_cast<const vf4 *>(cur + i0 + 4 * v));
 }
 
 // The constant part of a comb_filter() call (comb_filter_const, celt.c:87-110) for one tap alignment AL: outputs
 // [i0, i0+n) of `ring`, w1 per step (four adjacent ones per lane), every output also stored at mir[idx].
-template <int AL>
+template <bool MIR, int AL>
 __device__ __forceinline__ void pipe_const_wide(float *ring, float *mir, int lane, int i0, int n, int T1, float g10,
                                                 float g11, float g12, int w1) {
     const int o = 4 * lane;
@@ -89,7 +91,7 @@ __device__ __forceinline__ void pipe_const_wide(float *ring, float *mir, int lan
             y[u] += g12 * (x[u + 4] + x[u]);
         }
         sts4(ring, idx, f4{y[0], y[1], y[2], y[3]});
-        sts4(mir, idx, f4{y[0], y[1], y[2], y[3]});
+        if (MIR) sts4(mir, idx, f4{y[0], y[1], y[2], y[3]});
     };
     const int nfull = n / w1, rem = n - nfull * w1;
     if (o < w1) {
@@ -128,7 +130,7 @@ __device__ __forceinline__ float dpp_quad_bcast(float v) {   // every lane of a 
 //   XF = false: comb_filter_const (celt.c:87-110), gains ga[0..2]
 //   XF = true : the cross-fade loop of comb_filter (celt.c:139-160) when BOTH tap sets have this period: window
 //               weights from win2[wofs + i], set 0 gains ga, set 1 gains gb (same order of operations as the LDS form)
-template <bool XF>
+template <bool MIR, bool XF>
 __device__ __forceinline__ void pipe_run_dpp(float *ring, float *mir, int lane, int i0, int n, int T, const float (&ga)[3],
                                              const float (&gb)[3], const float *win2) {
     const int w = T - 2;
@@ -171,7 +173,7 @@ __device__ __forceinline__ void pipe_run_dpp(float *ring, float *mir, int lane, 
             y += ga[2] * (Y + S4);
         }
         rc[0] = y;
-        mc[0] = y;
+        if (MIR) mc[0] = y;
         Y = y;
         x = xn; f = fn; R = Rn;
         rc += w; mc += w; wp += w;
@@ -190,11 +192,12 @@ __device__ __forceinline__ void pipe_run_dpp(float *ring, float *mir, int lane, 
 
 // One comb_filter() call (celt.c:114-172) on ring[r0, r0+n): cross-fade (T0,g0,ts0) -> (T1,g1,ts1) over the first 120
 // samples, constant after; every output y[idx] is stored at ring[idx] AND mir[idx].
+template <bool MIR>
 __device__ __forceinline__ void pipe_comb_call(float *ring, float *mir, int lane, int r0, int n, int T0, int T1,
                                                float g0, float g1, int ts0, int ts1, const float *win2,
                                                unsigned long long *stm = nullptr) {
     if (g0 == 0.f && g1 == 0.f) {                             // celt.c:126-132: y = x
-        pipe_copy(ring, mir, lane, r0, n);
+        pipe_copy<MIR>(ring, mir, lane, r0, n);
         return;
     }
     float g00, g01, g02, g10, g11, g12;
@@ -210,7 +213,7 @@ __device__ __forceinline__ void pipe_comb_call(float *ring, float *mir, int lane
     if (T0 == T1 && g0 != 0.f && g1 != 0.f && T1 - 2 <= kWave) {
         // both tap sets on one short period (always the case for the first 120 samples of a frame once the filter
         // runs: celt_decoder_clean.c:678-683 makes old = current): recursion in registers
-        pipe_run_dpp<true>(ring, mir, lane, r0, kOverlap, T1, ga, gb, win2);
+        pipe_run_dpp<MIR, true>(ring, mir, lane, r0, kOverlap, T1, ga, gb, win2);
     } else if (tmin - 2 <= kWave) {
         // short periods: one output per lane
         const int w = tmin - 2;
@@ -237,7 +240,7 @@ __device__ __forceinline__ void pipe_comb_call(float *ring, float *mir, int lane
                 y += (f * g12) * (x4 + x0);
             }
             rc[0] = y;
-            mc[0] = y;
+            if (MIR) mc[0] = y;
         };
         if (lane < w) {
             for (int sidx = 0; sidx < nfull; sidx++) {
@@ -281,7 +284,7 @@ __device__ __forceinline__ void pipe_comb_call(float *ring, float *mir, int lane
                     }
                 }
                 sts4(ring, idx, f4{y[0], y[1], y[2], y[3]});
-                sts4(mir, idx, f4{y[0], y[1], y[2], y[3]});
+                if (MIR) sts4(mir, idx, f4{y[0], y[1], y[2], y[3]});
             }
             NYQ_POST_SYNC();
         }
@@ -290,20 +293,20 @@ __device__ __forceinline__ void pipe_comb_call(float *ring, float *mir, int lane
     if (nc <= 0) return;
     NYQ_STAMP_MID();
     if (g1 == 0.f) {                                          // celt.c:163-169
-        pipe_copy(ring, mir, lane, i0, nc);
+        pipe_copy<MIR>(ring, mir, lane, i0, nc);
         return;
     }
     if (T1 - 2 <= kWave) {
         // short periods (the common case in real streams): one output per lane, recursion in registers
-        pipe_run_dpp<false>(ring, mir, lane, i0, nc, T1, gb, gb, win2);
+        pipe_run_dpp<MIR, false>(ring, mir, lane, i0, nc, T1, gb, gb, win2);
         return;
     }
     const int w1 = (T1 - 2 < 4 * kWave ? T1 - 2 : 4 * kWave) & ~3;
     switch ((i0 - T1 - 2) & 3) {
-        case 0: pipe_const_wide<0>(ring, mir, lane, i0, nc, T1, g10, g11, g12, w1); break;
-        case 1: pipe_const_wide<1>(ring, mir, lane, i0, nc, T1, g10, g11, g12, w1); break;
-        case 2: pipe_const_wide<2>(ring, mir, lane, i0, nc, T1, g10, g11, g12, w1); break;
-        default: pipe_const_wide<3>(ring, mir, lane, i0, nc, T1, g10, g11, g12, w1); break;
+        case 0: pipe_const_wide<MIR, 0>(ring, mir, lane, i0, nc, T1, g10, g11, g12, w1); break;
+        case 1: pipe_const_wide<MIR, 1>(ring, mir, lane, i0, nc, T1, g10, g11, g12, w1); break;
+        case 2: pipe_const_wide<MIR, 2>(ring, mir, lane, i0, nc, T1, g10, g11, g12, w1); break;
+        default: pipe_const_wide<MIR, 3>(ring, mir, lane, i0, nc, T1, g10, g11, g12, w1); break;
     }
 }
 
@@ -451,6 +454,9 @@ __global__ __launch_bounds__(kWave *kPipeWaves, 3) void celt_post_pipe_kernel(Po
     // one per frame, one closing iteration -- the last also separates this unit's LDS use from the next prologue.
 #ifndef NYQ_PIPE_DBG_NO_COMB
     if (wave < kPipeUnits) {
+#ifndef NYQ_PIPE_NO_PRIO
+        __builtin_amdgcn_s_setprio(3);                         // the chain's wave wins instruction arbitration on its SIMD
+#endif
         for (long pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
             const long u0 = pair * kPipeUnits;
             // ---------------- comb wave of unit u0 + wave ----------------
@@ -481,17 +487,17 @@ __global__ __launch_bounds__(kWave *kPipeWaves, 3) void celt_post_pipe_kernel(Po
                     if (T_old > kCombMaxPeriod) T_old = kCombMaxPeriod;
                     const int T_nw = T_new < kCombMinPeriod ? kCombMinPeriod : T_new > kCombMaxPeriod ? kCombMaxPeriod : T_new;
                     NYQ_STAMP(2);                              // slot 2: parameters, set-up
-                    pipe_comb_call(cur, mir, lane, R0, kOverlap, T_old, T_cur, g_old, g_cur, ts_old, ts_cur, win2);
+                    pipe_comb_call<true>(cur, mir, lane, R0, kOverlap, T_old, T_cur, g_old, g_cur, ts_old, ts_cur, win2);
                     NYQ_STAMP(3);                              // slot 3: first 120 samples (old -> current parameters)
 #ifdef NYQ_PIPE_STAMPS
                     unsigned long long stm[2] = {st_t, 0};
                     if (LM != 0)
-                        pipe_comb_call(cur, mir, lane, R0 + kOverlap, N - kOverlap, T_cur, T_nw, g_cur, g_new, ts_cur, ts_new, win2, stm);
+                        pipe_comb_call<true>(cur, mir, lane, R0 + kOverlap, N - kOverlap, T_cur, T_nw, g_cur, g_new, ts_cur, ts_new, win2, stm);
                     st_acc[4] += stm[1];                       // slot 4: cross-fade of the second call; slot 0: its constant part
                     st_t = stm[0];
 #else
                     if (LM != 0)
-                        pipe_comb_call(cur, mir, lane, R0 + kOverlap, N - kOverlap, T_cur, T_nw, g_cur, g_new, ts_cur, ts_new, win2);
+                        pipe_comb_call<true>(cur, mir, lane, R0 + kOverlap, N - kOverlap, T_cur, T_nw, g_cur, g_new, ts_cur, ts_new, win2);
 #endif
                     T_old = T_cur; g_old = g_cur; ts_old = ts_cur;       // :672-677
                     T_cur = T_new; g_cur = g_new; ts_cur = ts_new;
@@ -593,7 +599,7 @@ __global__ __launch_bounds__(kWave *kPipeWaves, 3) void celt_post_pipe_kernel(Po
                 if (f < nfr && KEEP > 0) {
 #pragma unroll
                     for (int k = 0; k < kPipeUnits; k++)
-                        if (live[k]) pipe_copy(bufs[k][cb] + N, bufs[k][nb], lane, 0, KEEP);
+                        if (live[k]) pipe_copy<true>(bufs[k][cb] + N, bufs[k][nb], lane, 0, KEEP);
                 }
                 NYQ_STAMP(0);                                  // slot 0: history carry-over
                 // frame f-1 is final in cur[1088 - N, 1088): de-emphasis, staged in nxt's frame region, picked up again

@@ -1,0 +1,116 @@
+"""GPU tier: nyq_celt_chain_dev -- freq[] -> interleaved PCM as ONE fused launch (LM 3, stereo) against the oracle
+(compute_inv_mdcts + comb_filter + deemphasis restated in oracle/nyq_oracle.c) and against the two-kernel chain it
+replaces, decoder state carried in and out."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_rms
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import libnyquist_amd as nyq
+    c = nyq.Context(0)
+    yield c
+    c.close()
+
+
+def _run_chain(ctx, lm, freq, tr, pitch, gain, taps, pst, ov, hist, dm, ch, fused):
+    import torch
+    dev = torch.device("cuda", 0)
+    T = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dt)).to(dev)
+    ns, nf = pitch.shape
+    n = 120 << lm
+    d_freq, d_tr = T(freq, np.float32), T(tr, np.uint8)
+    d_pp, d_pg, d_pt = T(pitch, np.int32), T(gain, np.float32), T(taps, np.int32)
+    d_si = T(pst, np.float32)
+    d_so = torch.zeros_like(d_si)
+    d_ov, d_h, d_m = T(ov, np.float32), T(hist, np.float32), T(dm, np.float32)
+    d_out = torch.zeros((ns, nf * n, ch), device=dev)
+    d_pcm = torch.empty((ns * ch, nf * n), device=dev)
+    d_work = torch.empty(ctx.celt_synth_work_floats(ns, nf, ch), device=dev)
+    torch.cuda.synchronize(dev)
+    os.environ["NYQ_CHAIN_FUSED"] = "1" if fused else "0"
+    try:
+        ctx.celt_chain_dev(lm, d_freq.data_ptr(), d_tr.data_ptr(), d_pp.data_ptr(), d_pg.data_ptr(), d_pt.data_ptr(), d_si.data_ptr(),
+                           d_so.data_ptr(), d_ov.data_ptr(), d_h.data_ptr(), d_m.data_ptr(), d_out.data_ptr(), d_pcm.data_ptr(),
+                           d_work.data_ptr(), ns, nf, ch)
+        ctx.synchronize()
+    finally:
+        del os.environ["NYQ_CHAIN_FUSED"]
+    return d_out.cpu().numpy(), d_so.cpu().numpy(), d_ov.cpu().numpy(), d_h.cpu().numpy(), d_m.cpu().numpy()
+
+
+def _case(rng, ns, nf, ptr, ch=2, lm=3):
+    n = 120 << lm
+    freq = (rng.standard_normal((ns, nf, ch, n)) * 30).astype(np.float32)
+    tr = (rng.uniform(size=(ns, nf)) < ptr).astype(np.uint8)
+    ov = (rng.standard_normal((ns * ch, 60)) * 30).astype(np.float32)
+    hist = (rng.standard_normal((ns * ch, 1088)) * 30).astype(np.float32)
+    pitch = rng.integers(15, 1023, (ns, nf)).astype(np.int32)
+    short = rng.uniform(size=(ns, nf)) < 0.6
+    pitch[short] = rng.integers(15, 70, int(short.sum()))
+    gain = (rng.integers(0, 9, (ns, nf)) * 0.09375).astype(np.float32)
+    gain[rng.uniform(size=(ns, nf)) < 0.3] = 0
+    taps = rng.integers(0, 3, (ns, nf)).astype(np.int32)
+    pst = np.stack([[rng.integers(15, 1023), rng.integers(15, 1023), 0.28125, 0.375, 1, 2] for _ in range(ns)]).astype(np.float32)
+    dm = (rng.standard_normal(ns * ch) * 10).astype(np.float32)
+    return freq, tr, pitch, gain, taps, pst, ov, hist, dm
+
+
+@pytest.mark.parametrize("ns,nf,ptr", [(1, 1, 0.0), (1, 2, 1.0), (2, 3, 0.5), (3, 17, 0.1), (5, 40, 0.03), (8, 33, 1.0), (33, 20, 0.3)])
+def test_fused_chain_vs_oracle_and_two_kernel_chain(ctx, oracle, ns, nf, ptr):
+    """The fused launch against the oracle (synthesis, then post-filter + de-emphasis) and, bit for bit, against the
+    two-kernel chain: same lane program, same recursion, same order of operations."""
+    ctx.set_tables(*oracle.tables()[:2])
+    rng = np.random.default_rng(4200 + ns * 100 + nf)
+    freq, tr, pitch, gain, taps, pst, ov, hist, dm = _case(rng, ns, nf, ptr)
+    ch, n = 2, 960
+    wp, ws = oracle.celt_synth(3, freq, tr, ov, nthreads=4)
+    want, filt, wst, wdm = oracle.celt_post(3, np.concatenate([hist.reshape(ns, ch, 1088), wp.reshape(ns, ch, nf * n)], axis=2), 1088,
+                                            pitch, gain, taps, pst, dm)
+    out, gst, gov, gh, gdm = _run_chain(ctx, 3, freq, tr, pitch, gain, taps, pst, ov, hist, dm, ch, fused=True)
+    assert rel_rms(out, want) <= 1e-5, (ns, nf, ptr)
+    assert np.array_equal(gst, wst)
+    assert rel_rms(gov, ws) <= 1e-6
+    assert rel_rms(gh, filt[:, :, -1088:].reshape(ns * ch, 1088)) <= 1e-5
+    assert rel_rms(gdm, wdm) <= 1e-5
+    out2, gst2, gov2, gh2, gdm2 = _run_chain(ctx, 3, freq, tr, pitch, gain, taps, pst, ov, hist, dm, ch, fused=False)
+    assert rel_rms(out, out2) <= 1e-6 and np.abs(out - out2).max() <= 2e-6
+    assert np.array_equal(gst, gst2)
+    assert rel_rms(gov, gov2) <= 1e-6 and rel_rms(gh, gh2) <= 1e-6
+
+
+def test_fused_chain_continues_from_its_own_state(ctx, oracle):
+    """Two calls with the state of the first handed to the second == one call over both halves."""
+    ctx.set_tables(*oracle.tables()[:2])
+    rng = np.random.default_rng(77)
+    ns, nf = 6, 24
+    freq, tr, pitch, gain, taps, pst, ov, hist, dm = _case(rng, ns, nf, 0.1)
+    whole = _run_chain(ctx, 3, freq, tr, pitch, gain, taps, pst, ov, hist, dm, 2, fused=True)
+    h = 11
+    a = _run_chain(ctx, 3, freq[:, :h], tr[:, :h], pitch[:, :h], gain[:, :h], taps[:, :h], pst, ov, hist, dm, 2, fused=True)
+    b = _run_chain(ctx, 3, freq[:, h:], tr[:, h:], pitch[:, h:], gain[:, h:], taps[:, h:], a[1], a[2], a[3], a[4], 2, fused=True)
+    got = np.concatenate([a[0], b[0]], axis=1)
+    assert np.array_equal(got, whole[0])
+    for x, y in zip(b[1:], whole[1:]):
+        assert np.array_equal(x, y)
+
+
+def test_other_shapes_run_the_two_kernel_chain(ctx, oracle):
+    """Frame sizes / channel counts the fused kernel does not cover go through synth + post inside the same entry."""
+    ctx.set_tables(*oracle.tables()[:2])
+    rng = np.random.default_rng(5)
+    for lm, ch in ((2, 2), (3, 1), (0, 3)):
+        ns, nf, n = 3, 9, 120 << lm
+        freq, tr, pitch, gain, taps, pst, ov, hist, dm = _case(rng, ns, nf, 0.2, ch=ch, lm=lm)
+        wp, ws = oracle.celt_synth(lm, freq, tr, ov, nthreads=2)
+        want, filt, wst, wdm = oracle.celt_post(lm, np.concatenate([hist.reshape(ns, ch, 1088), wp.reshape(ns, ch, nf * n)], axis=2), 1088,
+                                                pitch, gain, taps, pst, dm)
+        out, gst, gov, gh, gdm = _run_chain(ctx, lm, freq, tr, pitch, gain, taps, pst, ov, hist, dm, ch, fused=True)
+        assert rel_rms(out, want) <= 1e-5, (lm, ch)
+        assert np.array_equal(gst, wst)

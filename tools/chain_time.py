@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Time the frames -> PCM chain (nyq_celt_chain_dev) fused vs as two kernels, same process, interleaved; HIP events on
+the operator's stream.  usage: chain_time.py [nstreams] [nframes] [mix|short|long|off]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import libnyquist_amd as nyq  # noqa: E402
+
+ns = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+nf = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+case = sys.argv[3] if len(sys.argv) > 3 else "mix"
+dev = torch.device("cuda", 0)
+ctx = nyq.Context(0)
+stream = torch.cuda.Stream(dev)
+torch.cuda.set_stream(stream)
+ctx.set_stream(stream.cuda_stream)
+g = torch.Generator(device=dev)
+g.manual_seed(4)
+ch, n = 2, 960
+freq = torch.randn((ns, nf, ch, n), generator=g, device=dev) * 30.0
+trans = (torch.rand((ns, nf), generator=g, device=dev) < 0.028).to(torch.uint8)
+lo, hi, on = {"mix": (15, 80, 0.7), "short": (15, 60, 1.0), "long": (300, 1000, 1.0), "off": (15, 80, 0.0)}[case]
+pitch = torch.randint(lo, hi, (ns, nf), generator=g, device=dev, dtype=torch.int32)
+gain = (torch.rand((ns, nf), generator=g, device=dev) < on).float() * (torch.randint(1, 9, (ns, nf), generator=g, device=dev) * 0.09375).float()
+tap = torch.randint(0, 3, (ns, nf), generator=g, device=dev, dtype=torch.int32)
+out = torch.empty((ns, nf * n, ch), device=dev)
+pcm = torch.empty((ns * ch, nf * n), device=dev)
+work = torch.empty(ctx.celt_synth_work_floats(ns, nf, ch), device=dev)
+
+
+def run():
+    ctx.celt_chain_dev(3, freq.data_ptr(), trans.data_ptr(), pitch.data_ptr(), gain.data_ptr(), tap.data_ptr(), 0, 0, 0, 0, 0,
+                       out.data_ptr(), pcm.data_ptr(), work.data_ptr(), ns, nf, ch)
+
+
+res = {}
+outs = {}
+times = {"0": [], "1": []}
+for rnd in range(8):
+    for mode in ("0", "1"):
+        os.environ["NYQ_CHAIN_FUSED"] = mode
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        run()
+        b.record(stream)
+        torch.cuda.synchronize(dev)
+        if rnd >= 2:
+            times[mode].append(a.elapsed_time(b))
+        if rnd == 0:
+            outs[mode] = out.clone()
+for mode, name in (("0", "two kernels"), ("1", "fused")):
+    ms = sorted(times[mode])[len(times[mode]) // 2]
+    res[name] = {"ms": ms, "stereo_frames_per_sec": ns * nf / ms * 1e3, "GBps_in_plus_out": ns * nf * ch * 7680 / ms / 1e6}
+res["max_abs_diff_fused_vs_two_kernels"] = float((outs["0"] - outs["1"]).abs().max())
+res["case"] = f"{ns} streams x {nf} frames x 2 ch, LM 3, 2.8 % transient, post-filter case {case}"
+print(json.dumps(res))
