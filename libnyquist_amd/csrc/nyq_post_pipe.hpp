@@ -138,26 +138,22 @@ __device__ __forceinline__ void pipe_run_dpp(float *ring, float *mir, int lane, 
     float *rc = ring + (i0 + lane);
     float *mc = mir + (i0 + lane);
     const float *wp = win2 + lane;
-    float Y = 0.f, x = 0.f, f = 0.f;
+    // Operands of a step that do not depend on the recursion -- the raw sample x, the window weight f, and R (lanes
+    // 0..3: the four outputs in front of the previous step's, final since the step before) -- are read TWO steps
+    // ahead into two alternating register sets (a: even steps, b: odd steps), right behind the write they follow.
+    float Y = 0.f, xa = 0.f, fa = 0.f, xb = 0.f, fb = 0.f;
     if (lane < w) {
         Y = rc[-w];
-        x = rc[0];
-        if (XF) f = wp[0];
+        xa = rc[0];
+        xb = rc[w];
+        if (XF) { fa = wp[0]; fb = wp[w]; }
     }
-    float R = rc[-w - 4];                                      // lanes 0..3: the four outputs in front of the previous step
-    float O1, O2, O3, O4;                                      // lane 0: y[base_prev - 1 .. base_prev - 4]
-    auto spread = [&]() {                                      // needs lanes 0..3 active: the quad broadcast reads them
-        O1 = dpp_quad_bcast<3>(R); O2 = dpp_quad_bcast<2>(R); O3 = dpp_quad_bcast<1>(R); O4 = dpp_quad_bcast<0>(R);
-    };
-    auto step = [&](bool more) {
-        // operands of the NEXT step first (none of them depends on this step's result)
-        float xn = 0.f, fn = 0.f, Rn = 0.f;
-        if (more) {
-            xn = rc[w];
-            if (XF) fn = wp[w];
-            Rn = rc[-4];
-        }
-        const float S1 = dpp_shr1(O1, Y), S2 = dpp_shr1(O2, S1), S3 = dpp_shr1(O3, S2), S4 = dpp_shr1(O4, S3);
+    float Ra = rc[-w - 4], Rb = rc[-4];
+    // one step at offset `o` floats from rc (o = 0 or w), operands (x, f, R); returns with Y = its outputs
+    auto step = [&](int o, float x, float f, float R) {
+        // (the quad broadcast needs lanes 0..3 active; whole steps have >= 13 lanes, the remainder spreads beforehand)
+        const float S1 = dpp_shr1(dpp_quad_bcast<3>(R), Y), S2 = dpp_shr1(dpp_quad_bcast<2>(R), S1),
+                    S3 = dpp_shr1(dpp_quad_bcast<1>(R), S2), S4 = dpp_shr1(dpp_quad_bcast<0>(R), S3);
         float y = x;
         if (XF) {
             const float nf = 1.0f - f;
@@ -172,21 +168,53 @@ __device__ __forceinline__ void pipe_run_dpp(float *ring, float *mir, int lane, 
             y += ga[1] * (S1 + S3);
             y += ga[2] * (Y + S4);
         }
-        rc[0] = y;
-        if (MIR) mc[0] = y;
+        rc[o] = y;
+        if (MIR) mc[o] = y;
         Y = y;
-        x = xn; f = fn; R = Rn;
-        rc += w; mc += w; wp += w;
     };
+    int done = 0;
     if (lane < w) {
-        for (int sidx = 0; sidx < nfull; sidx++) {
-            spread();
-            step(true);                                        // (reads one step past the run: inside the buffer, unused)
+        for (; done + 2 <= nfull; done += 2) {
+            step(0, xa, fa, Ra);
+            xa = rc[2 * w];                                    // (reads up to two steps past the run: inside the LDS, unused)
+            if (XF) fa = wp[2 * w];
+            Ra = rc[w - 4];
             NYQ_POST_SYNC();
+            step(w, xb, fb, Rb);
+            xb = rc[3 * w];
+            if (XF) fb = wp[3 * w];
+            Rb = rc[2 * w - 4];
+            NYQ_POST_SYNC();
+            rc += 2 * w; mc += 2 * w; wp += 2 * w;
+        }
+        if (done < nfull) {                                    // odd count: one more whole step, then b is the next set
+            step(0, xa, fa, Ra);
+            NYQ_POST_SYNC();
+            rc += w; mc += w; wp += w;
+            xa = xb; fa = fb; Ra = Rb;
         }
     }
-    spread();                                                  // (whole wave: the remainder may have fewer than four lanes)
-    if (lane < rem) step(false);
+    // remainder (fewer than w outputs, maybe fewer than four lanes: the quad broadcast of R runs on the whole wave first)
+    const float Q1 = dpp_quad_bcast<3>(Ra), Q2 = dpp_quad_bcast<2>(Ra), Q3 = dpp_quad_bcast<1>(Ra), Q4 = dpp_quad_bcast<0>(Ra);
+    if (lane < rem) {
+        const float S1 = dpp_shr1(Q1, Y), S2 = dpp_shr1(Q2, S1), S3 = dpp_shr1(Q3, S2), S4 = dpp_shr1(Q4, S3);
+        float y = xa;
+        if (XF) {
+            const float nf = 1.0f - fa;
+            y += (nf * ga[0]) * S2;
+            y += (nf * ga[1]) * (S1 + S3);
+            y += (nf * ga[2]) * (Y + S4);
+            y += (fa * gb[0]) * S2;
+            y += (fa * gb[1]) * (S1 + S3);
+            y += (fa * gb[2]) * (Y + S4);
+        } else {
+            y += ga[0] * S2;
+            y += ga[1] * (S1 + S3);
+            y += ga[2] * (Y + S4);
+        }
+        rc[0] = y;
+        if (MIR) mc[0] = y;
+    }
     NYQ_POST_SYNC();
 }
 
