@@ -53,6 +53,37 @@ def shard_rows(total_rows, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def csrc_digest():
+    """sha1 over the kernel sources (csrc/*.hpp, *.hip): measurements taken with other kernels must not be replayed."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "libnyquist_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(rows):
+    """roofline.traffic: HBM bytes per launch of the headline kernel from the PMC passes recorded in
+    profiles/traffic_latest.json (tools/pmc_summary.py) -- only if that file was produced with THESE kernel sources
+    and this row count; otherwise null, with the reason."""
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    src = {"file": "profiles/traffic_latest.json", "csrc_sha16_now": csrc_digest()}
+    if not os.path.exists(tpath):
+        return None, dict(src, status="absent")
+    try:
+        tj = json.load(open(tpath))
+    except Exception as e:
+        return None, dict(src, status=f"unreadable: {e!r}")
+    src.update({k: tj.get(k) for k in ("csrc_sha16", "git_head", "kernel", "measured_on", "rows")})
+    if tj.get("rows") != rows:
+        return None, dict(src, status="other row count")
+    if tj.get("csrc_sha16") != src["csrc_sha16_now"]:
+        return None, dict(src, status="stale: kernel sources changed since the PMC passes")
+    return tj.get("hbm_bytes_per_launch"), dict(src, status="measured with these kernel sources (separate --pmc FETCH_SIZE / WRITE_SIZE passes)")
+
+
 def cpu_share():
     """Host cores this process may actually use: affinity mask clipped by the cgroup CPU quota."""
     try:
@@ -76,30 +107,34 @@ def cpu_share():
     return n
 
 
-def opus_file_decode_leg(count=256, fname="short.opus", n=421930):
+def opus_file_decode_leg(count=256, fname="short.opus", n=421930, threads=None):
     """File-level decode of `count` copies of tests/golden/<fname> (short.opus: 220 stereo 20 ms CELT frames + one
     closing 2.5 ms frame, 123 kbit/s; sb-reverie.opus: 11184 frames = 224 s, BASELINE config 4's file) as ONE
     batch through libnyquist_host (CPU entropy stage in
     threads, IMDCT/post-filter pieces on the GPU behind it, PCIe included), and the same files through the
     reference's own NyquistIO::Load on the same number of host threads (oracle/_ref/libref_decode.so: the
     cpu_baseline of this leg)."""
-    threads = cpu_share()
+    threads = threads or cpu_share()
     raw = open(os.path.join(ROOT, "tests", "golden", fname), "rb").read()
     H = ctypes.CDLL(os.path.join(ROOT, "libnyquist_amd", "libnyquist_host.so"))
-    H.nyqh_batch_decode.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+    H.nyqh_batch_decode_timed.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                     ctypes.c_long, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")]
-    H.nyqh_batch_decode.restype = ctypes.c_long
+    H.nyqh_batch_decode_timed.restype = ctypes.c_long
     first = np.zeros(n, np.float32)
-    stats = np.zeros(4, np.float64)
-    H.nyqh_batch_decode(raw, len(raw), count, threads, first.ctypes.data_as(ctypes.c_void_p), None, n, stats)   # contexts, pinned staging
-    got = H.nyqh_batch_decode(raw, len(raw), count, threads, first.ctypes.data_as(ctypes.c_void_p), None, n, stats)
+    stats = np.zeros(6, np.float64)
+    H.nyqh_batch_decode_timed(raw, len(raw), count, threads, first.ctypes.data_as(ctypes.c_void_p), None, n, stats)   # contexts, pinned staging, pooled buffers
+    t0 = time.perf_counter()
+    got = H.nyqh_batch_decode_timed(raw, len(raw), count, threads, first.ctypes.data_as(ctypes.c_void_p), None, n, stats)
+    wall = time.perf_counter() - t0          # a clock AROUND the call; every result is consumed and released inside it
     if got != n:
         raise RuntimeError(f"nyqh_batch_decode returned {got}")
-    cpu_s, tail_s, frames, thr = stats
-    leg = {"file": fname, "files": count, "frames": int(frames), "host_threads": int(thr), "seconds": cpu_s + tail_s,
-           "files_per_sec": count / (cpu_s + tail_s), "frames_per_sec": frames / (cpu_s + tail_s),
-           "cpu_entropy_stage_s": cpu_s, "not_hidden_gpu_and_trim_s": tail_s,
-           "x_realtime": count * (n / 2 / 48000.0) / (cpu_s + tail_s), "checksum_file0": float(first.astype(np.float64).sum())}
+    cpu_s, tail_s, frames, thr, wall_inside, ndev = stats
+    leg = {"file": fname, "files": count, "frames": int(frames), "host_threads": int(thr), "devices": int(ndev),
+           "seconds": wall, "wall_seconds": wall, "wall_seconds_measured_inside_the_library": float(wall_inside),
+           "files_per_sec": count / wall, "frames_per_sec": frames / wall,
+           "breakdown_cpu_entropy_stage_s": cpu_s, "breakdown_not_hidden_gpu_and_trim_s": tail_s,
+           "wall_over_stage_sum": wall / (cpu_s + tail_s),
+           "x_realtime": count * (n / 2 / 48000.0) / wall, "checksum_file0": float(first.astype(np.float64).sum())}
     rp = os.path.join(ROOT, "oracle", "_ref", "libref_decode.so")
     if os.path.exists(rp):
         R = ctypes.CDLL(rp)
@@ -112,7 +147,7 @@ def opus_file_decode_leg(count=256, fname="short.opus", n=421930):
         leg["cpu_baseline"] = {"kind": "reference", "cores": threads, "seconds": secs, "files_per_sec": count / secs,
                                "samples_per_file": int(ns.value), "checksum_file0": ck.value,
                                "sample": f"{count} in-memory copies of {fname} through the reference's NyquistIO::Load, {threads} threads"}
-        leg["vs_cpu_baseline"] = secs / (cpu_s + tail_s)
+        leg["vs_cpu_baseline"] = secs / wall          # wall clock against wall clock
     return leg
 
 
@@ -217,7 +252,9 @@ def main():
     ctx.set_stream(stream.cuda_stream)
     cus, devname = ctx.device_info()
 
-    rows = args.rows
+    # the job is world x args.rows rows; this rank's share (weak scaling: the global batch grows with the GPU count)
+    lo, hi = shard_rows(world * args.rows, world, rank)
+    rows = hi - lo
     gen = torch.Generator(device=dev)
     gen.manual_seed(480 + rank)
     x = torch.rand((rows, N2), generator=gen, device=dev, dtype=torch.float32).mul_(2.0).sub_(1.0)
@@ -315,11 +352,23 @@ def main():
             synth["post_filter_ms_per_call"] = pms
             synth["post_filter_algorithmic_GBps"] = ns * nf * ch * ALG_BYTES_PER_IMDCT / (pms * 1e-3) / 1e9
             synth["post_filter_config"] = "70 % of the frames filtered, period uniform 15..79, gain 0.09..0.75, random tapset"
+            # the chain as ONE operator (nyq_celt_chain_dev: freq[] -> interleaved PCM), timed as a unit
+            def cstep():
+                ctx.celt_chain_dev(3, sfreq.data_ptr(), strans.data_ptr(), ppitch.data_ptr(), pgain.data_ptr(), ptap.data_ptr(), 0, 0,
+                                   sstate.data_ptr(), 0, 0, pout.data_ptr(), spcm.data_ptr(), swork.data_ptr(), ns, nf, ch)
+            cstep()
+            s0.record(stream)
+            for _ in range(10):
+                cstep()
+            s1.record(stream)
+            torch.cuda.synchronize(dev)
+            synth["chain_ms_per_call"] = s0.elapsed_time(s1) / 10
+            synth["chain_GBps_freq_in_plus_pcm_out"] = ns * nf * ch * ALG_BYTES_PER_IMDCT / (synth["chain_ms_per_call"] * 1e-3) / 1e9
             del ppitch, pgain, ptap, pout
         except Exception as e:
             synth["post_filter_error"] = repr(e)
         del sfreq, spcm, swork
-        chain_ms = synth["ms_per_call"] + synth.get("post_filter_ms_per_call", float("inf"))
+        chain_ms = synth.get("chain_ms_per_call", synth["ms_per_call"] + synth.get("post_filter_ms_per_call", float("inf")))
         if world > 1:
             tt = torch.tensor([chain_ms], device=red_dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -371,14 +420,25 @@ def main():
         except Exception as e:
             host_boundary = {"error": repr(e)}
 
+    # File-level decode on EVERY rank: each decodes its own copies on its own GPU with its share of the host threads
+    # (NYQ_DEVICE selects the device of the C entry point); the whole-job rate uses the slowest rank's wall clock.
     file_leg = None
-    if rank == 0 and world == 1 and not args.no_host_leg:
+    if not args.no_host_leg:
         try:
-            file_leg = opus_file_decode_leg()
-            # BASELINE config 4's file (224 s per stream): the GPU walks it in time slices behind the entropy stage
-            file_leg["long_streams"] = opus_file_decode_leg(32, "sb-reverie.opus", 21472602)
+            os.environ["NYQ_DEVICE"] = str(local_rank)
+            thr = max(1, cpu_share() // world)
+            file_leg = opus_file_decode_leg(256 if world == 1 else 128, threads=thr)
+            if world == 1:
+                # BASELINE config 4's file (224 s per stream): the GPU walks it in time slices behind the entropy stage
+                file_leg["long_streams"] = opus_file_decode_leg(32, "sb-reverie.opus", 21472602)
         except Exception as e:
             file_leg = {"error": repr(e)} if file_leg is None else dict(file_leg, long_streams_error=repr(e))
+        if world > 1:                        # (every rank takes part, whatever happened above)
+            tt = torch.tensor([file_leg.get("wall_seconds", float("inf"))], device=red_dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            if "files" in file_leg:
+                file_leg["whole_job"] = {"n_gpus": world, "files": world * file_leg["files"], "slowest_rank_wall_seconds": float(tt.item()),
+                                         "files_per_sec": world * file_leg["files"] / float(tt.item())}
 
     if world > 1:
         t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
@@ -404,15 +464,7 @@ def main():
         total = world * rows * args.steps
         value = total / elapsed
         achieved = ALG_BYTES_PER_IMDCT * rows / (kern_avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("rows") == rows:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_source = measured_traffic(rows)
         out = {
             "metric": "N=480 IMDCTs/sec (batched)",
             "value": value,
@@ -427,7 +479,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "configs[2]: synthetic nfft-480 IMDCT batch (MDCT N=1920, shift 0, stride 1, overlap 120, zero carry)",
-                       "rows_per_gpu": rows, "global_rows": world * rows, "seed": 480,
+                       "rows_per_gpu": rows, "global_rows": world * args.rows, "rank0_rows": [lo, hi], "seed": 480,
                        "outputs": "960 finished samples + 60-float tail per row",
                        "parallelism": f"rows sharded over {world} GPU(s), no collective",
                        "device": devname, "compute_units": cus},
@@ -437,7 +489,7 @@ def main():
             "host_boundary": host_boundary,
             "opus_file_decode": file_leg,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "nyq::imdct_rows_kernel<32, KCfg<1,false,0>>", "kernel_avg_ms": kern_avg_ms,
                          "kernel_median_ms_rank0": float(np.median(kern_ms)),
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_IMDCT * rows,

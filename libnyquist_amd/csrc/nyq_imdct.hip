@@ -325,10 +325,14 @@ static int synth_core(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned 
     const size_t nsc = nstreams * (size_t)channels;
     const size_t pitch = (nframes + 1) * NYQ_HALF_OV * sizeof(float), slot = NYQ_HALF_OV * sizeof(float);
     // tails slot 0 of every (stream, channel) = the state handed in
-    if (d_state_in)
-        NYQ_HIP(ctx, hipMemcpy2DAsync(d_work, pitch, d_state_in, slot, slot, nsc, hipMemcpyDeviceToDevice, ctx->stream));
-    else
+    const unsigned cgrid = (unsigned)((nsc * 15 + 255) / 256);
+    if (d_state_in) {
+        hipLaunchKernelGGL(tail_rows_copy_kernel, dim3(cgrid), dim3(256), 0, ctx->stream, d_work, (long)((nframes + 1) * NYQ_HALF_OV),
+                           d_state_in, (long)NYQ_HALF_OV, (long)nsc);
+        NYQ_HIP(ctx, hipGetLastError());
+    } else {
         NYQ_HIP(ctx, hipMemset2DAsync(d_work, pitch, 0, slot, nsc, ctx->stream));
+    }
     SynthArgs A;
     A.freq = d_freq;
     A.transient = LM > 0 ? d_transient : nullptr;   // LM 0: one block either way (B = 1)
@@ -358,9 +362,11 @@ static int synth_core(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned 
     hipLaunchKernelGGL(synth_fixup_kernel, dim3((unsigned)((units + per_block - 1) / per_block)),
                        dim3(kWave * kFixupWaves), 0, ctx->stream, A, 120 << LM, chain_frames, ctx->d_window);
     NYQ_HIP(ctx, hipGetLastError());
-    if (d_state_out)
-        NYQ_HIP(ctx, hipMemcpy2DAsync(d_state_out, slot, d_work + nframes * NYQ_HALF_OV, pitch, slot, nsc,
-                                      hipMemcpyDeviceToDevice, ctx->stream));
+    if (d_state_out) {
+        hipLaunchKernelGGL(tail_rows_copy_kernel, dim3(cgrid), dim3(256), 0, ctx->stream, d_state_out, (long)NYQ_HALF_OV,
+                           d_work + nframes * NYQ_HALF_OV, (long)((nframes + 1) * NYQ_HALF_OV), (long)nsc);
+        NYQ_HIP(ctx, hipGetLastError());
+    }
     return NYQ_OK;
 }
 
@@ -659,7 +665,8 @@ extern "C" int nyq_ifft_batch(nyq_ctx *ctx, int nfft, const float *in, float *ou
 // transfers that overlap the kernels; pageable buffers work too but are staged by the runtime.
 extern "C" void *nyq_host_alloc(size_t bytes) {
     void *p = nullptr;
-    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    // portable: every device of the process may DMA from / to it (one decoder can feed several GPUs)
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) return nullptr;
     return p;
 }
 

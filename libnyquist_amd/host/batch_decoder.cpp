@@ -163,7 +163,7 @@ void entropyDecode(FileJob &job, OnSlice &&onSlice) {
 
 // streams of one shape (channels, frame size of the first segment), padded to the longest
 struct Group {
-    int ch = 0, LM = 0;
+    int ch = 0, LM = 0, dev = 0;        // dev: index into the decoder's device list
     size_t N = 0, ns = 0, maxF = 0;
     std::vector<size_t> ids;            // flattened stream indices, slot order
     float *freq = nullptr, *out = nullptr, *pg = nullptr;
@@ -245,11 +245,13 @@ void stateIntoBatch(float *batch, size_t ns, int ch, size_t k, const float *one)
 // One memory-bounded sub-batch of files on its way through passes 1-3 (see batch_decoder.hpp).
 class SubBatch {
 public:
+    // ctxs: ndev * feedersPerDev contexts, device d's at [d * feedersPerDev, ...); arena(dev, bytes) = that device's staging memory
     SubBatch(std::vector<FileJob> &jobs, std::vector<DecodedStream> &out, const std::vector<size_t> &members, void *const *ctxs,
-             int nfeeders, int threads, const std::function<void *(size_t)> &arena)
-        : jobs_(jobs), out_(out), members_(members), ctxs_(ctxs), nfeeders_(nfeeders), threads_(threads), arena_(arena),
-          firstSub_(jobs.size(), 0), finished_(jobs.size(), 0), streamed_(jobs.size(), 0), window_(jobs.size()),
-          subsLeft_(jobs.size()), gpuBusy_((size_t)nfeeders, 0.0) {}
+             int ndev, int feedersPerDev, int threads, const std::function<void *(int, size_t)> &arena)
+        : jobs_(jobs), out_(out), members_(members), ctxs_(ctxs), ndev_(ndev), feedersPerDev_(feedersPerDev),
+          nfeeders_(ndev * feedersPerDev), threads_(threads), arena_(arena), firstSub_(jobs.size(), 0), finished_(jobs.size(), 0),
+          streamed_(jobs.size(), 0), window_(jobs.size()), subsLeft_(jobs.size()), ready_((size_t)ndev),
+          gpuBusy_((size_t)(ndev * feedersPerDev), 0.0) {}
 
     // returns when every file of the sub-batch is decoded (or has its error set); throws if the GPU failed
     void run() {
@@ -303,16 +305,21 @@ private:
     // into pieces of consecutive slots, a piece into time slices
     void layout() {
         const size_t n = sfp_.size();
-        std::map<std::pair<int, int>, size_t> groupOf;
+        // Elementary stream number s of a (channels, frame size) class goes to device s mod G:
+        // a group -- one set of staging buffers, one shape of GPU calls -- belongs to ONE device.
+        std::map<std::pair<int, int>, size_t> seenOfClass;
+        std::map<std::tuple<int, int, int>, size_t> groupOf;
         for (size_t i = 0; i < n; i++) {
-            const std::pair<int, int> key{sf(i).channels, sf(i).plan[0].LM};
+            const int dev = (int)(seenOfClass[{sf(i).channels, sf(i).plan[0].LM}]++ % (size_t)ndev_);
+            const std::tuple<int, int, int> key{sf(i).channels, sf(i).plan[0].LM, dev};
             auto it = groupOf.find(key);
             if (it == groupOf.end()) {
                 it = groupOf.emplace(key, groups_.size()).first;
                 groups_.emplace_back();
-                groups_.back().ch = key.first;
-                groups_.back().LM = key.second;
-                groups_.back().N = (size_t)120 << key.second;
+                groups_.back().ch = std::get<0>(key);
+                groups_.back().LM = std::get<1>(key);
+                groups_.back().N = (size_t)120 << std::get<1>(key);
+                groups_.back().dev = dev;
             }
             Group &g = groups_[it->second];
             sf(i).group = it->second;
@@ -320,15 +327,18 @@ private:
             g.ids.push_back(i);
             g.maxF = std::max(g.maxF, (size_t)sf(i).plan[0].nframes);
         }
-        size_t bytes = 0;
+        std::vector<size_t> bytes((size_t)ndev_, 0);
         for (Group &g : groups_) {
             g.ns = g.ids.size();
             const size_t x = g.ns * g.maxF * g.ch * g.N * sizeof(float), q = g.ns * g.maxF;
-            bytes += 2 * align256(x) + 3 * align256(q * 4) + align256(q);
+            bytes[(size_t)g.dev] += 2 * align256(x) + 3 * align256(q * 4) + align256(q);
         }
-        char *base = (char *)arena_(bytes);
+        std::vector<char *> bases((size_t)ndev_, nullptr);
+        for (int d = 0; d < ndev_; d++)
+            if (bytes[(size_t)d]) bases[(size_t)d] = (char *)arena_(d, bytes[(size_t)d]);
         for (size_t gi = 0; gi < groups_.size(); gi++) {
             Group &g = groups_[gi];
+            char *&base = bases[(size_t)g.dev];
             const size_t x = g.ns * g.maxF * g.ch * g.N * sizeof(float), q = g.ns * g.maxF;
             g.freq = (float *)base; base += align256(x);
             g.out = (float *)base; base += align256(x);
@@ -436,22 +446,23 @@ private:
         for (size_t k = p.k0; k < p.k1; k++)
             if (progress_[g.ids[k]].load(std::memory_order_acquire) < target) return;
         p.inFlight = true;
-        ready_.push_back(pi);
-        cv_.notify_one();
+        ready_[(size_t)g.dev].push_back(pi);
+        cv_.notify_all();                                       // (the feeders of every device wait on this one condition)
     }
 
     // pass 2: one feeder thread = one GPU context; slices of one piece go in order (the decoder state of the piece
     // travels with them on the host), different pieces side by side
     void feederLoop(int which) {
         nyq_ctx *ctx = (nyq_ctx *)ctxs_[which];
+        std::deque<size_t> &mine = ready_[(size_t)(which / feedersPerDev_)];   // the pieces of this feeder's device
         for (;;) {
             size_t pi;
             {
                 std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return !ready_.empty() || finishedPieces_ == pieces_.size(); });
-                if (ready_.empty()) return;
-                pi = ready_.front();
-                ready_.pop_front();
+                cv_.wait(lk, [&] { return !mine.empty() || finishedPieces_ == pieces_.size(); });
+                if (mine.empty()) return;
+                pi = mine.front();
+                mine.pop_front();
             }
             Piece &p = pieces_[pi];
             const Group &g = groups_[p.group];
@@ -668,8 +679,8 @@ private:
     std::vector<DecodedStream> &out_;
     const std::vector<size_t> &members_;
     void *const *ctxs_;
-    const int nfeeders_, threads_;
-    const std::function<void *(size_t)> &arena_;
+    const int ndev_, feedersPerDev_, nfeeders_, threads_;
+    const std::function<void *(int, size_t)> &arena_;
 
     std::vector<StreamFrames *> sfp_;                  // flattened elementary streams
     std::vector<size_t> firstSub_, fileOf_;            // file -> first flat index; flat index -> file
@@ -684,7 +695,7 @@ private:
 
     std::mutex mu_;                                    // scheduler: ready queue, Piece::{nextSlice, inFlight, appendTurn}
     std::condition_variable cv_, cvAppend_;
-    std::deque<size_t> ready_;
+    std::vector<std::deque<size_t>> ready_;   // per device
     size_t finishedPieces_ = 0;
     std::string gpuError_;
     std::vector<double> gpuBusy_;
@@ -692,47 +703,70 @@ private:
 
 }  // namespace
 
-BatchOpusDecoder::BatchOpusDecoder(int device) {
-    for (int k = 0; k < kFeeders; k++) {
-        nyq_ctx *c = nullptr;
-        if (nyq_ctx_create(&c, device) != NYQ_OK) {
-            for (int j = 0; j < k; j++) nyq_ctx_destroy((nyq_ctx *)ctx_[j]);
-            throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(nullptr));
+BatchOpusDecoder::BatchOpusDecoder(int device) : BatchOpusDecoder(std::vector<int>{device}) {}
+
+BatchOpusDecoder::BatchOpusDecoder(const std::vector<int> &devices) : devices_(devices) {
+    if (devices_.empty()) throw std::runtime_error("BatchOpusDecoder: empty device list");
+    arenas_.resize(devices_.size());
+    for (size_t d = 0; d < devices_.size(); d++)
+        for (int k = 0; k < kFeeders; k++) {
+            nyq_ctx *c = nullptr;
+            if (nyq_ctx_create(&c, devices_[d]) != NYQ_OK) {
+                for (void *p : ctx_) nyq_ctx_destroy((nyq_ctx *)p);
+                ctx_.clear();
+                throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(nullptr));
+            }
+            ctx_.push_back(c);
         }
-        ctx_[k] = c;
-    }
 }
 
 BatchOpusDecoder::~BatchOpusDecoder() {
-    if (arena_) (pinned_ ? nyq_host_free(arena_) : std::free(arena_));
-    for (int k = kFeeders - 1; k >= 0; k--) nyq_ctx_destroy((nyq_ctx *)ctx_[k]);
+    for (Arena &a : arenas_)
+        if (a.p) (a.pinned ? nyq_host_free(a.p) : std::free(a.p));
+    for (size_t k = ctx_.size(); k-- > 0;) nyq_ctx_destroy((nyq_ctx *)ctx_[k]);
 }
 
 void BatchOpusDecoder::trim(size_t keepBytes) {
-    if (arena_ && arenaBytes_ > keepBytes) {
-        pinned_ ? nyq_host_free(arena_) : std::free(arena_);
-        arena_ = nullptr;
-        arenaBytes_ = 0;
+    for (Arena &a : arenas_)
+        if (a.p && a.bytes > keepBytes) {
+            a.pinned ? nyq_host_free(a.p) : std::free(a.p);
+            a = Arena();
+        }
+    size_t kept = 0;                                           // pooled sample buffers: keep what fits the same bound
+    for (auto it = pool_.begin(); it != pool_.end();) {
+        if (kept + it->capacity() * sizeof(float) > keepBytes) it = pool_.erase(it);
+        else { kept += it->capacity() * sizeof(float); ++it; }
     }
 }
 
-// page-locked staging memory, kept from call to call (grow only); pageable memory if pinning fails
-void *BatchOpusDecoder::arena(size_t bytes) {
-    if (bytes <= arenaBytes_) return arena_;
-    if (arena_) (pinned_ ? nyq_host_free(arena_) : std::free(arena_));
-    arena_ = nullptr;
-    arenaBytes_ = 0;
+// page-locked staging memory of one device, kept from call to call (grow only); pageable memory if pinning fails
+void *BatchOpusDecoder::arena(int dev, size_t bytes) {
+    Arena &a = arenas_[(size_t)dev];
+    if (bytes <= a.bytes) return a.p;
+    if (a.p) (a.pinned ? nyq_host_free(a.p) : std::free(a.p));
+    a = Arena();
     const size_t want = bytes + bytes / 8;
-    arena_ = nyq_host_alloc(want);
-    pinned_ = arena_ != nullptr;
-    if (!arena_) arena_ = std::aligned_alloc(4096, (want + 4095) & ~(size_t)4095);
-    if (!arena_) throw std::bad_alloc();
-    arenaBytes_ = want;
-    return arena_;
+    a.p = nyq_host_alloc(want);
+    a.pinned = a.p != nullptr;
+    if (!a.p) a.p = std::aligned_alloc(4096, (want + 4095) & ~(size_t)4095);
+    if (!a.p) throw std::bad_alloc();
+    a.bytes = want;
+    return a.p;
 }
 
 void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &files, std::vector<DecodedStream> &out,
                               BatchStats *stats, int threads) {
+    decodeImpl(files, out, nullptr, stats, threads);
+}
+
+void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &files, const StreamSink &sink, BatchStats *stats,
+                              int threads) {
+    std::vector<DecodedStream> out;
+    decodeImpl(files, out, &sink, stats, threads);
+}
+
+void BatchOpusDecoder::decodeImpl(const std::vector<const std::vector<uint8_t> *> &files, std::vector<DecodedStream> &out,
+                                  const StreamSink *sink, BatchStats *stats, int threads) {
     const size_t nfiles = files.size();
     out.assign(nfiles, DecodedStream());
     std::vector<FileJob> jobs(nfiles);
@@ -791,21 +825,48 @@ void BatchOpusDecoder::decode(const std::vector<const std::vector<uint8_t> *> &f
     }
     double cpuSecs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), tailSecs = 0, busySecs = 0;
     long totalFrames = 0;
-    const std::function<void *(size_t)> arenaFn = [this](size_t bytes) { return arena(bytes); };
+    const std::function<void *(int, size_t)> arenaFn = [this](int dev, size_t bytes) { return arena(dev, bytes); };
+    auto settle = [&](size_t i) {
+        if (!jobs[i].error.empty()) {
+            out[i].error = jobs[i].error;
+            out[i].pcm.clear();                            // no partial audio of a file that failed half way
+        }
+    };
     for (const std::vector<size_t> &members : batches) {
-        SubBatch sb(jobs, out, members, ctx_, kFeeders, threads, arenaFn);
+        if (sink)                                          // sample buffers out of the pool (largest first: long files get them)
+            for (size_t i : members)
+                if (!pool_.empty()) {
+                    out[i].pcm = std::move(pool_.back());
+                    pool_.pop_back();
+                    out[i].pcm.clear();
+                }
+        SubBatch sb(jobs, out, members, ctx_.data(), (int)devices_.size(), kFeeders, threads, arenaFn);
         sb.run();
         cpuSecs += sb.cpuSeconds;
         tailSecs += sb.tailSeconds;
         busySecs += sb.busySeconds;
         totalFrames += sb.frames.load();
+        if (sink)
+            for (size_t i : members) {
+                settle(i);
+                (*sink)(i, out[i]);
+                if (out[i].pcm.capacity()) pool_.push_back(std::move(out[i].pcm));
+                out[i] = DecodedStream();
+            }
     }
-    for (size_t i = 0; i < nfiles; i++)
-        if (!jobs[i].error.empty()) {
-            out[i].error = jobs[i].error;
-            out[i].pcm.clear();                            // no partial audio of a file that failed half way
+    std::vector<char> inBatch(nfiles, 0);
+    for (const std::vector<size_t> &members : batches)
+        for (size_t i : members) inBatch[i] = 1;
+    for (size_t i = 0; i < nfiles; i++) {
+        if (!sink) {
+            settle(i);
+        } else if (!inBatch[i]) {                          // a file that failed the scan is in no sub-batch
+            settle(i);
+            (*sink)(i, out[i]);
         }
+    }
     if (stats) {
+        stats->wallSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         stats->cpuSeconds = cpuSecs;
         stats->gpuSeconds = tailSecs;
         stats->gpuBusySeconds = busySecs;

@@ -10,6 +10,7 @@
 // Replaces the per-packet loop of src/OpusDecoder.cpp:95-122 (op_read_float).
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -27,34 +28,57 @@ struct DecodedStream {
 };
 
 struct BatchStats {
-    double cpuSeconds = 0;             // wall time of pass 1
-    double gpuSeconds = 0;             // wall time after pass 1: GPU work not hidden behind it, and pass 3
+    double wallSeconds = 0;            // the whole decode() call, first instruction to return (the figure to quote)
+    double cpuSeconds = 0;             // breakdown: wall time of pass 0 + pass 1
+    double gpuSeconds = 0;             // breakdown: wall time after pass 1: GPU work not hidden behind it, and pass 3
     double gpuBusySeconds = 0;         // time the feeder threads spent inside GPU calls (PCIe included), summed
     long frames = 0;                   // channel-independent frame count over all streams
     int threads = 0;
 };
 
+// Receives every file of a batch once, complete (or with its error set), in an unspecified order but never concurrently;
+// the stream's storage goes back to the decoder's pool when the callback returns (move `pcm` out to keep it).
+using StreamSink = std::function<void(size_t index, DecodedStream &stream)>;
+
 class BatchOpusDecoder {
 public:
     explicit BatchOpusDecoder(int device = 0);
+    // One decoder over several GPUs of the node (BASELINE config 4 "batch-sharded 1 -> 8 GPUs"):
+    // elementary stream number s of a (channels, frame size) class goes to devices[s mod G]; every device has its own
+    // feeder threads, contexts and page-locked staging arena; no data moves between devices, results stay on the host
+    // side of each device's PCIe link until they are handed over.
+    explicit BatchOpusDecoder(const std::vector<int> &devices);
     ~BatchOpusDecoder();
     BatchOpusDecoder(const BatchOpusDecoder &) = delete;
     BatchOpusDecoder &operator=(const BatchOpusDecoder &) = delete;
     // files[i] = a whole Ogg Opus file in memory
     void decode(const std::vector<const std::vector<uint8_t> *> &files, std::vector<DecodedStream> &out,
                 BatchStats *stats = nullptr, int threads = 0);
+    // The same, results streamed to `sink` sub-batch by sub-batch out of POOLED sample buffers (kept by the decoder from
+    // call to call: a big job does not allocate, first-touch and unmap gigabytes of output per call -- the shape of the
+    // reference's own loop, src/OpusDecoder.cpp:82-87 inside a caller that drops each AudioData after use).
+    void decode(const std::vector<const std::vector<uint8_t> *> &files, const StreamSink &sink, BatchStats *stats = nullptr,
+                int threads = 0);
+    int deviceCount() const { return (int)devices_.size(); }
 
     // give the page-locked staging memory back if it has grown beyond `keepBytes` (a pooled decoder should not sit
     // on gigabytes of pinned memory after one big job)
     void trim(size_t keepBytes);
 
 private:
-    void *arena(size_t bytes);
-    static constexpr int kFeeders = 6;        // GPU contexts / feeder threads: pieces in flight at once
-    void *ctx_[kFeeders] = {nullptr};         // nyq_ctx*
-    void *arena_ = nullptr;            // staging memory of the groups, kept between calls
-    size_t arenaBytes_ = 0;
-    bool pinned_ = false;
+    void decodeImpl(const std::vector<const std::vector<uint8_t> *> &files, std::vector<DecodedStream> &out, const StreamSink *sink,
+                    BatchStats *stats, int threads);
+    void *arena(int dev, size_t bytes);
+    static constexpr int kFeeders = 6;        // GPU contexts / feeder threads PER DEVICE: pieces in flight at once
+    struct Arena {                            // page-locked staging memory of one device's groups, kept between calls
+        void *p = nullptr;
+        size_t bytes = 0;
+        bool pinned = false;
+    };
+    std::vector<int> devices_;
+    std::vector<void *> ctx_;                 // nyq_ctx*, device d's feeders at [d * kFeeders, (d + 1) * kFeeders)
+    std::vector<Arena> arenas_;
+    std::vector<std::vector<float>> pool_;    // sample buffers of the sink form, capacity kept
 };
 
 }  // namespace nyq_host

@@ -72,5 +72,8 @@ private:
 // feeding GPU pieces as they complete.  out[i] is filled exactly as NyquistIO::Load would fill it for
 // buffers[i]; a file that fails makes the call throw after the others have been decoded.
 void BatchLoad(std::vector<AudioData> &out, const std::vector<std::vector<uint8_t>> &buffers, int device = 0);
+// The same over several GPUs of the node: elementary stream s of a shape class is decoded on devices[s mod G]
+// (independent streams, no exchange between devices); the results are identical to the one-device call.
+void BatchLoad(std::vector<AudioData> &out, const std::vector<std::vector<uint8_t>> &buffers, const std::vector<int> &devices);
 
 }  // namespace nqr

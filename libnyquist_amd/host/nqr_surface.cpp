@@ -80,16 +80,17 @@ void nqr::OpusDecoder::LoadFromPath(AudioData *data, const std::string &path) {
 namespace {
 struct DecoderPool {
     std::mutex mu;
-    std::map<int, std::vector<nyq_host::BatchOpusDecoder *>> idle;
+    std::map<std::vector<int>, std::vector<nyq_host::BatchOpusDecoder *>> idle;   // by device list
 };
 DecoderPool &decoderPool() {
     static DecoderPool *p = new DecoderPool;
     return *p;
 }
 struct DecoderLease {
-    int device;
+    std::vector<int> device;
     nyq_host::BatchOpusDecoder *dec = nullptr;
-    explicit DecoderLease(int d) : device(d) {
+    explicit DecoderLease(int d) : DecoderLease(std::vector<int>{d}) {}
+    explicit DecoderLease(const std::vector<int> &d) : device(d) {
         {
             std::lock_guard<std::mutex> lk(decoderPool().mu);
             auto &v = decoderPool().idle[d];
@@ -127,7 +128,11 @@ void nqr::OpusDecoder::LoadFromBuffer(AudioData *data, const std::vector<uint8_t
 std::vector<std::string> nqr::OpusDecoder::GetSupportedFileExtensions() { return {"opus"}; }
 
 void nqr::BatchLoad(std::vector<AudioData> &out, const std::vector<std::vector<uint8_t>> &buffers, int device) {
-    DecoderLease lease(device);
+    BatchLoad(out, buffers, std::vector<int>{device});
+}
+
+void nqr::BatchLoad(std::vector<AudioData> &out, const std::vector<std::vector<uint8_t>> &buffers, const std::vector<int> &devices) {
+    DecoderLease lease(devices);
     std::vector<const std::vector<uint8_t> *> files;
     for (const auto &b : buffers) files.push_back(&b);
     std::vector<nyq_host::DecodedStream> dec_out;

@@ -1,6 +1,9 @@
 // nyq_host_capi.cpp -- plain-C entry points of libnyquist_host.so used by the tests (ctypes) and
 // by tools: the CPU entropy stage on its own, and the mode tables for cross-checking.
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "batch_decoder.hpp"
@@ -121,29 +124,81 @@ long nyqh_nyquistio_load_buffer(const unsigned char *file, long size, float *sam
     }
 }
 
-// `count` copies of one file decoded as ONE batch (config 4 shape: many concurrent streams).
-// Copies the first and the last decoded stream out for checking; stats = {cpu_s, gpu_s, frames, threads}.
-long nyqh_batch_decode(const unsigned char *file, long size, long count, int threads, float *first, float *last,
-                       long capacity, double *stats) {
+// The C entry points below share ONE decoder per device set, created on first use and kept for the life of the process
+// (its page-locked staging memory and pooled sample buffers are reused; never destroyed, so no HIP call runs from a
+// static destructor after the runtime has shut down).  Calls are serialised: decode() is not re-entrant.
+static std::mutex g_capi_mu;
+static nyq_host::BatchOpusDecoder *g_capi_dec = nullptr;
+static std::vector<int> g_capi_devs;
+
+// devices from NYQ_DEVICES ("0,1,2": one decoder over several GPUs) or NYQ_DEVICE (one), default device 0
+static std::vector<int> capiDevices() {
+    std::vector<int> v;
+    if (const char *e = std::getenv("NYQ_DEVICES")) {
+        for (const char *p = e; *p;) {
+            v.push_back(std::atoi(p));
+            while (*p && *p != ',') p++;
+            if (*p == ',') p++;
+        }
+    } else if (const char *e1 = std::getenv("NYQ_DEVICE")) {
+        v.push_back(std::atoi(e1));
+    }
+    if (v.empty()) v.push_back(0);
+    return v;
+}
+
+static nyq_host::BatchOpusDecoder &capiDecoder() {               // call with g_capi_mu held
+    const std::vector<int> want = capiDevices();
+    if (!g_capi_dec || want != g_capi_devs) {
+        delete g_capi_dec;
+        g_capi_dec = nullptr;
+        g_capi_dec = new nyq_host::BatchOpusDecoder(want);
+        g_capi_devs = want;
+    }
+    return *g_capi_dec;
+}
+
+// `count` copies of one file decoded as ONE batch (config 4 shape: many concurrent streams).  The results go through
+// the sink form (every stream is looked at once and its buffer returns to the pool: what the reference's loop does
+// with each AudioData), the first and the last decoded stream are copied out for checking.
+// stats6 = {cpu_s, not_hidden_s, frames, threads, wall_s, devices}: wall_s is the whole call measured in here.
+long nyqh_batch_decode_timed(const unsigned char *file, long size, long count, int threads, float *first, float *last,
+                             long capacity, double *stats) {
     try {
+        const auto t0 = std::chrono::steady_clock::now();
+        std::lock_guard<std::mutex> lk(g_capi_mu);
         std::vector<uint8_t> buf(file, file + size);
         std::vector<const std::vector<uint8_t> *> files((size_t)count, &buf);
-        // kept for the life of the process (its page-locked staging memory is reused; never destroyed, so no
-        // HIP call runs from a static destructor after the runtime has shut down)
-        static nyq_host::BatchOpusDecoder &dec = *new nyq_host::BatchOpusDecoder(0);
-        std::vector<nyq_host::DecodedStream> out;
+        nyq_host::BatchOpusDecoder &dec = capiDecoder();
         nyq_host::BatchStats st;
-        dec.decode(files, out, &st, threads);
-        for (auto &o : out)
-            if (!o.error.empty()) return -1;
+        long nsamp = -1;
+        bool failed = false;
+        dec.decode(files, [&](size_t i, nyq_host::DecodedStream &d) {
+            if (!d.error.empty()) { failed = true; return; }
+            const long n = (long)d.pcm.size();
+            if (i == 0) {
+                nsamp = n;
+                if (first && capacity >= n) std::memcpy(first, d.pcm.data(), (size_t)n * sizeof(float));
+            }
+            if (i + 1 == (size_t)count && last && capacity >= n) std::memcpy(last, d.pcm.data(), (size_t)n * sizeof(float));
+        }, &st, threads);
+        if (failed) return -1;
         stats[0] = st.cpuSeconds; stats[1] = st.gpuSeconds; stats[2] = (double)st.frames; stats[3] = st.threads;
-        const long nsamp = (long)out[0].pcm.size();
-        if (first && capacity >= nsamp) std::memcpy(first, out[0].pcm.data(), nsamp * sizeof(float));
-        if (last && capacity >= nsamp) std::memcpy(last, out.back().pcm.data(), nsamp * sizeof(float));
+        stats[4] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        stats[5] = (double)dec.deviceCount();
         return nsamp;
     } catch (const std::exception &) {
         return -1;
     }
+}
+
+// the same with the original four-element stats = {cpu_s, not_hidden_s, frames, threads}
+long nyqh_batch_decode(const unsigned char *file, long size, long count, int threads, float *first, float *last,
+                       long capacity, double *stats) {
+    double st6[6] = {0, 0, 0, 0, 0, 0};
+    const long n = nyqh_batch_decode_timed(file, size, count, threads, first, last, capacity, st6);
+    if (stats) std::memcpy(stats, st6, 4 * sizeof(double));
+    return n;
 }
 
 // A batch of DIFFERENT files (mixed shapes: channel counts, frame sizes, lengths, multistream) as one call.
@@ -152,13 +207,14 @@ long nyqh_batch_decode(const unsigned char *file, long size, long count, int thr
 long nyqh_batch_decode_files(const unsigned char *const *files, const long *sizes, long count, int threads, long *nsamples,
                              float *out, long capacity) {
     try {
+        std::lock_guard<std::mutex> lk(g_capi_mu);
         std::vector<std::vector<uint8_t>> bufs((size_t)count);
         std::vector<const std::vector<uint8_t> *> ptrs((size_t)count);
         for (long i = 0; i < count; i++) {
             bufs[i].assign(files[i], files[i] + sizes[i]);
             ptrs[i] = &bufs[i];
         }
-        static nyq_host::BatchOpusDecoder &dec = *new nyq_host::BatchOpusDecoder(0);
+        nyq_host::BatchOpusDecoder &dec = capiDecoder();
         std::vector<nyq_host::DecodedStream> res;
         dec.decode(ptrs, res, nullptr, threads);
         long total = 0;

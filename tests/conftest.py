@@ -20,6 +20,42 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# The 2-rank rehearsal of bench.py (tests/test_sharding.py::test_bench_two_ranks_on_one_gpu) has to be STARTED before this
+# process touches the GPU: a process that has initialised the HIP runtime must not spawn-and-exec GPU programs on the
+# pool's boxes.  So the GPU tier launches it here, at session start, as a background child, and the test only collects
+# its output.  (The CPU tier never starts it.)
+REHEARSAL = {"proc": None, "out": None, "err": None}
+
+
+def pytest_sessionstart(session):
+    import subprocess
+    expr = (session.config.getoption("-m") or "").strip()
+    if expr != "gpu" or os.environ.get("NYQ_NO_REHEARSAL"):
+        return
+    try:
+        import torch
+        if torch.cuda.device_count() < 1:          # (counting devices does not initialise the runtime)
+            return
+    except Exception:
+        return
+    port = 29600 + (os.getpid() % 300)
+    REHEARSAL["out"] = open(os.path.join(ROOT, "gpurun_out", "rehearsal_stdout.txt") if os.path.isdir(os.path.join(ROOT, "gpurun_out"))
+                            else os.path.join("/tmp", "nyq_rehearsal_stdout.txt"), "w+")
+    REHEARSAL["err"] = open(os.path.join("/tmp", "nyq_rehearsal_stderr.txt"), "w+")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    REHEARSAL["proc"] = subprocess.Popen(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--dist-backend", "gloo",
+         "--rows", "65536", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+        cwd=ROOT, env=env, stdout=REHEARSAL["out"], stderr=REHEARSAL["err"])
+
+
+def pytest_sessionfinish(session, exitstatus):
+    p = REHEARSAL["proc"]
+    if p is not None and p.poll() is None:
+        p.kill()                                   # (exactly the child started above)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

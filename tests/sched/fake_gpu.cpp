@@ -4,6 +4,7 @@
 // "PCM" of a frame is a checksum-like function of that frame's coefficients, its parameters, and a running
 // per-(stream, channel) state that is carried exactly like the real decoder state -- so any slice delivered out
 // of order, twice, or with the wrong state changes the output.  Never linked into the product.
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -15,9 +16,17 @@ struct nyq_ctx {
     int device;
 };
 
+// The stand-in exposes kFakeDevices "GPUs": contexts of any other index are refused like a missing device, and
+// every call is counted against its context's device (fake_gpu_calls) so that a test can see the sharding.
+static constexpr int kFakeDevices = 4;
+static std::atomic<long> g_calls[kFakeDevices];
+
 extern "C" {
 
+long fake_gpu_calls(int device) { return device >= 0 && device < kFakeDevices ? g_calls[device].load() : -1; }
+
 int nyq_ctx_create(nyq_ctx **out, int device) {
+    if (device < 0 || device >= kFakeDevices) return NYQ_ERR_NO_DEVICE;
     *out = new nyq_ctx{device};
     return NYQ_OK;
 }
@@ -31,10 +40,11 @@ size_t nyq_celt_state_floats(size_t nstreams, int channels) {
     return nsc * (60 + 1088 + 1) + nstreams * 6;
 }
 
-int nyq_celt_frames_to_pcm_window(nyq_ctx *, int LM, const float *freq, const unsigned char *transient, const int *pf_pitch,
+int nyq_celt_frames_to_pcm_window(nyq_ctx *ctx, int LM, const float *freq, const unsigned char *transient, const int *pf_pitch,
                                   const float *pf_gain, const int *pf_tapset, float *out, float *state, size_t nstreams,
                                   size_t nframes, int channels, size_t frames_per_stream) {
     const size_t N = (size_t)120 << LM, nsc = nstreams * channels;
+    g_calls[ctx->device]++;
     for (size_t s = 0; s < nstreams; s++)
         for (int c = 0; c < channels; c++) {
             // the running state lives where the real overlap state lives: first float of the stream-channel's 60

@@ -11,6 +11,8 @@
 
 #include "batch_decoder.hpp"
 
+extern "C" long fake_gpu_calls(int device);   // tests/sched/fake_gpu.cpp
+
 using nyq_host::BatchOpusDecoder;
 using nyq_host::DecodedStream;
 
@@ -60,6 +62,33 @@ int main(int argc, char **argv) {
                 }
             }
         }
+    }
+    // One decoder over TWO devices of the stand-in (and the sink form): elementary streams go to device s mod 2, each
+    // with its own feeders and staging arena; every file must equal its stand-alone, one-device result bit for bit, and
+    // both devices must have been given work.
+    if (std::getenv("SCHED_DEVICES")) {
+        BatchOpusDecoder two(listOf("SCHED_DEVICES", {0, 1}));
+        const long before0 = fake_gpu_calls(0), before1 = fake_gpu_calls(1);
+        std::vector<const std::vector<uint8_t> *> batch;
+        std::vector<size_t> which;
+        for (int r = 0; r < 3; r++)
+            for (size_t i = 0; i < files.size(); i++) {
+                batch.push_back(&files[(i * 5 + r) % files.size()]);
+                which.push_back((i * 5 + r) % files.size());
+            }
+        size_t seen = 0;
+        two.decode(batch, [&](size_t k, DecodedStream &b) {
+            seen++;
+            const DecodedStream &a = alone[which[k]];
+            if (a.error.empty() != b.error.empty() || a.pcm != b.pcm || a.totalSamples != b.totalSamples) {
+                std::printf("MISMATCH file %zu on two devices\n", which[k]);
+                bad++;
+            }
+        }, nullptr, 4);
+        runs++;
+        const long d0 = fake_gpu_calls(0) - before0, d1 = fake_gpu_calls(1) - before1;
+        std::printf("two devices: %zu of %zu files delivered, calls per device %ld / %ld\n", seen, batch.size(), d0, d1);
+        if (seen != batch.size() || d0 <= 0 || d1 <= 0) bad++;
     }
     std::printf("%d batches, %d mismatches\n", runs, bad);
     return bad ? 1 : 0;

@@ -32,6 +32,8 @@ def load_host():
     H.nyqh_batch_decode.argtypes = [C.c_char_p, C.c_long, C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_long,
                                     np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")]
     H.nyqh_batch_decode.restype = C.c_long
+    H.nyqh_batch_decode_timed.argtypes = H.nyqh_batch_decode.argtypes
+    H.nyqh_batch_decode_timed.restype = C.c_long
     H.nyqh_batch_decode_files.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_long), C.c_long, C.c_int, C.POINTER(C.c_long), C.c_void_p, C.c_long]
     H.nyqh_batch_decode_files.restype = C.c_long
     return H

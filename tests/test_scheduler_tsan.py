@@ -35,6 +35,17 @@ def test_mixed_batches_small_budget(harness):
     assert "6 batches" in out
 
 
+def test_two_devices_equal_one_device(harness):
+    """One BatchOpusDecoder over two devices of the stand-in (streams shard s mod 2, a feeder set and a staging arena
+    per device, results through the sink form out of pooled buffers): bit-identical to the one-device results, both
+    devices used, no race."""
+    out = run(harness, ["corpus/st_20ms_32k.opus", "corpus/mono_5ms_64k.opus", "corpus/surround51_10ms_192k.opus",
+                        "corpus/twosize_st_20ms_then_10ms_10s.opus", "short.opus", "corpus/st_2p5ms_128k.opus"],
+              SCHED_THREADS="4", SCHED_REPS="1", SCHED_DEVICES="0,1", NYQ_BATCH_BYTES="60000000")
+    assert "two devices: 18 of 18 files delivered" in out
+    assert "2 batches" in out
+
+
 def test_long_streams_in_time_slices(harness):
     """a 224 s stream is walked in time slices next to short ones"""
     out = run(harness, ["sb-reverie.opus", "corpus/st_20ms_32k.opus", "corpus/twosize_st_20ms_then_10ms_10s.opus", "short.opus"],

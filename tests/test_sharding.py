@@ -1,7 +1,9 @@
-"""CPU tier: the N>1 path of bench.py -- row sharding, barrier and max-over-ranks timing --
-exercised with two gloo ranks.  The compute leg is stubbed by the oracle (the checker), because
-this tier has no GPU; what is under test is the partition/aggregation logic, which has no
-data-path collective."""
+"""The N>1 path of bench.py.
+CPU tier: bench.shard_rows (the partition bench.main applies to the global batch) and the barrier / MAX-over-ranks
+reduction with two gloo ranks; the compute leg is stubbed by the oracle because this tier has no GPU.
+GPU tier: bench.py itself under torch.distributed.run with two ranks sharing the box's one GPU (started by
+tests/conftest.py before this process touches the GPU): the real kernels, one context per rank, the gloo fallback,
+the per-rank file-decode leg, the whole-job aggregation."""
 import os
 import sys
 
@@ -10,7 +12,9 @@ import pytest
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import ROOT
+import json
+
+from conftest import REHEARSAL, ROOT
 
 sys.path.insert(0, ROOT)
 from bench import shard_rows  # noqa: E402
@@ -66,3 +70,30 @@ def test_two_rank_gloo_sharding():
     assert tmax == 1.5                      # max over ranks, not rank 0's own time
     assert same                             # shards tile the batch exactly
     assert spans == [(0, 19), (19, 37)]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 --rehearse-on-one-gpu --dist-backend gloo
+    --rows 65536 --steps 2` must print ONE JSON line with n_gpus 2, both shards in the global batch, a parity figure from
+    the oracle, a whole-job Opus chain rate and the per-rank file-decode leg aggregated over both ranks."""
+    p = REHEARSAL["proc"]
+    if p is None:
+        pytest.skip("rehearsal child not started (needs `-m gpu` and a GPU at session start)")
+    rc = p.wait(timeout=600)
+    REHEARSAL["out"].seek(0)
+    REHEARSAL["err"].seek(0)
+    out, err = REHEARSAL["out"].read(), REHEARSAL["err"].read()
+    assert rc == 0, (rc, out[-800:], err[-2500:])
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-1500:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak"
+    assert j["config"]["global_rows"] == 2 * 65536 and j["config"]["rows_per_gpu"] == 65536
+    assert j["config"]["rank0_rows"] == [0, 65536]
+    assert j["value"] > 0 and j["parity_rel_rms_vs_oracle"] <= 1e-5
+    assert j["opus_frame_synthesis"]["n_gpus"] == 2
+    assert j["opus_frame_synthesis"]["whole_job_stereo_frames_per_sec_synthesis_plus_post_filter"] > 0
+    leg = j["opus_file_decode"]
+    assert leg["whole_job"]["n_gpus"] == 2 and leg["whole_job"]["files"] == 2 * leg["files"]
+    assert leg["whole_job"]["slowest_rank_wall_seconds"] >= leg["wall_seconds"] * 0.999

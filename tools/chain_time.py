@@ -32,9 +32,35 @@ pcm = torch.empty((ns * ch, nf * n), device=dev)
 work = torch.empty(ctx.celt_synth_work_floats(ns, nf, ch), device=dev)
 
 
+state = torch.zeros((ns * ch, 60), device=dev)
+WITH_STATE = os.environ.get("CHAIN_STATE") == "1"
+
+
 def run():
-    ctx.celt_chain_dev(3, freq.data_ptr(), trans.data_ptr(), pitch.data_ptr(), gain.data_ptr(), tap.data_ptr(), 0, 0, 0, 0, 0,
-                       out.data_ptr(), pcm.data_ptr(), work.data_ptr(), ns, nf, ch)
+    ctx.celt_chain_dev(3, freq.data_ptr(), trans.data_ptr(), pitch.data_ptr(), gain.data_ptr(), tap.data_ptr(), 0, 0,
+                       state.data_ptr() if WITH_STATE else 0, 0, 0, out.data_ptr(), pcm.data_ptr(), work.data_ptr(), ns, nf, ch)
+
+
+def timed(fn, reps=10):
+    fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(stream)
+    for _ in range(reps):
+        fn()
+    b.record(stream)
+    torch.cuda.synchronize(dev)
+    return a.elapsed_time(b) / reps
+
+
+if os.environ.get("CHAIN_SPLIT") == "1":
+    # the two stages timed alone (loops of 10 of the same launch) next to the chain timed as a unit
+    os.environ["NYQ_CHAIN_FUSED"] = "0"
+    t_s = timed(lambda: ctx.celt_synth_dev(3, freq.data_ptr(), trans.data_ptr(), pcm.data_ptr(), state.data_ptr() if WITH_STATE else 0,
+                                           work.data_ptr(), ns, nf, ch))
+    t_p = timed(lambda: ctx.celt_post_dev(3, pcm.data_ptr(), pitch.data_ptr(), gain.data_ptr(), tap.data_ptr(), 0, 0, 0, 0, out.data_ptr(), ns, nf, ch))
+    t_c = timed(run)
+    print(json.dumps({"synth_alone_ms": t_s, "post_alone_ms": t_p, "sum_ms": t_s + t_p, "chain_as_a_unit_ms": t_c, "with_state": WITH_STATE}))
+    sys.exit(0)
 
 
 res = {}
