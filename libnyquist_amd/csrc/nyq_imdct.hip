@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -934,8 +935,13 @@ extern "C" int nyq_celt_frames_to_pcm_window(nyq_ctx *ctx, int LM, const float *
 }
 
 // ---- the reference's operator names (cuda/mdct_cuda.hpp:79-103) --------------------
+// State of the drop-in entry points.  The reference keeps an unsynchronised global map keyed by a sum of buffer sizes
+// (mdct_cuda.cu:558-584); here one mutex serialises the calls (the interface is synchronous and moves ~8 KB per call:
+// there is nothing to win from concurrency inside it, and a decoder thread per stream simply takes turns), and the
+// uploaded tables are identified by CONTENT -- a caller that refills the same buffer gets its new tables.
+static std::mutex g_shim_mu;
 static nyq_ctx *g_shim_ctx = nullptr;
-static const float *g_shim_trig = nullptr, *g_shim_window = nullptr;
+static bool g_shim_tables_set = false;
 
 [[noreturn]] static void shim_die(const char *who, const char *what) {
     // reference behaviour on device failure is fprintf + exit(1) (mdct_cuda.cu:11-19)
@@ -943,17 +949,18 @@ static const float *g_shim_trig = nullptr, *g_shim_window = nullptr;
     std::abort();
 }
 
-static nyq_ctx *shim_ctx(const char *who, const float *trig, const float *window) {
+static nyq_ctx *shim_ctx(const char *who, const float *trig, const float *window) {   // call with g_shim_mu held
     if (!g_shim_ctx) {
         const char *dev = std::getenv("NYQ_DEVICE");
         if (nyq_ctx_create(&g_shim_ctx, dev ? std::atoi(dev) : 0) != NYQ_OK) shim_die(who, nyq_last_error(nullptr));
+        g_shim_tables_set = false;
     }
-    // the reference uploads trig/window once per state (mdct_cuda.cu:577-579); same here,
-    // re-uploading only if the caller hands over different tables
-    if (trig != g_shim_trig || window != g_shim_window) {
+    // the reference uploads trig/window once per state (mdct_cuda.cu:577-579); here whenever their CONTENT differs from
+    // what the context holds (2.4 KB compared per call)
+    if (!g_shim_tables_set || std::memcmp(g_shim_ctx->h_trig, trig, sizeof g_shim_ctx->h_trig) != 0 ||
+        std::memcmp(g_shim_ctx->h_window, window, sizeof g_shim_ctx->h_window) != 0) {
         if (nyq_ctx_set_tables(g_shim_ctx, trig, window) != NYQ_OK) shim_die(who, nyq_last_error(g_shim_ctx));
-        g_shim_trig = trig;
-        g_shim_window = window;
+        g_shim_tables_set = true;
     }
     return g_shim_ctx;
 }
@@ -974,6 +981,7 @@ static void shim_rows(const char *who, int nch, const float *const *input, float
                       int N, int shift, int stride, int overlap, const float *window) {
     if (shift < 0 || shift > 3 || N != (NYQ_MDCT_N >> shift) || overlap != NYQ_OVERLAP || stride < 1 || !trig || !window)
         shim_die(who, "unsupported call: only the static 48 kHz mode (mdct.n 1920, overlap 120, shift 0..3) exists");
+    std::lock_guard<std::mutex> lk(g_shim_mu);
     nyq_ctx *ctx = shim_ctx(who, trig, window);
     if (!g_shim_pin) {
         g_shim_pin = static_cast<ShimPinned *>(nyq_host_alloc(sizeof(ShimPinned)));
@@ -1013,11 +1021,12 @@ extern "C" void processMDCTCudaB1C2(const float *input[2], float *output[2], con
 }
 
 extern "C" void cleanupCudaBuffers(void) {
+    std::lock_guard<std::mutex> lk(g_shim_mu);
     if (g_shim_pin) nyq_host_free(g_shim_pin);
     g_shim_pin = nullptr;
     if (g_shim_ctx) nyq_ctx_destroy(g_shim_ctx);
     g_shim_ctx = nullptr;
-    g_shim_trig = g_shim_window = nullptr;
+    g_shim_tables_set = false;
 }
 
 extern "C" void printCudaVersion(void) {

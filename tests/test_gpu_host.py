@@ -147,8 +147,20 @@ def test_reference_ctest_criteria(host, name, want_int_sum):
         s = np.cumsum(np.concatenate([[s], pcm[:, c]]).astype(np.float32), dtype=np.float32)[-1]
     assert int(s) == want_int_sum
     assert np.isfinite(out).all() and np.abs(out).max() <= 1.5
+    # ... and against the reference decoder's own PCM, ALWAYS: block digests made here from the reference build
+    # (oracle/gen_reverie_digest.py -> tests/golden/sb_reverie_digest.npz), plus, where the reference build itself
+    # travelled with the snapshot (oracle/_ref/libref_decode.so), every sample.
+    dg = np.load(os.path.join(GOLDEN, "sb_reverie_digest.npz"))
+    k = "a" if name == "sb-reverie.opus" else "b"
+    assert str(dg[k + "_file"]) == name
+    assert np.abs(pcm[:9600] - dg[k + "_head"]).max() <= 4e-6 and np.abs(pcm[-2000:] - dg[k + "_tail"]).max() <= 4e-6
+    assert np.abs(pcm[::997] - dg[k + "_every997"]).max() <= 4e-6
+    nb = dg[k + "_block_sum"].shape[0]
+    blk = pcm[: nb * 4800].astype(np.float64).reshape(nb, 4800, 2)
+    assert np.abs(blk.sum(axis=1) - dg[k + "_block_sum"]).max() <= 4800 * 4e-6
+    assert np.abs((blk ** 2).sum(axis=1) - dg[k + "_block_sq"]).max() <= 1e-5 * max(1.0, float(dg[k + "_block_sq"].max()))
     ref = os.path.join(ROOT, "oracle", "_ref", "libref_decode.so")
-    if os.path.exists(ref):                              # and sample for sample against the reference build
+    if os.path.exists(ref):
         R = C.CDLL(ref)
         R.ref_decode_pcm.restype = C.c_long
         R.ref_decode_pcm.argtypes = [C.c_char_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p]
@@ -157,6 +169,53 @@ def test_reference_ctest_criteria(host, name, want_int_sum):
         assert np.abs(out - full).max() <= 4e-6
         d = out.astype(np.float64) - full
         assert np.sqrt((d ** 2).mean()) <= 1e-5 * np.sqrt((full.astype(np.float64) ** 2).mean())
+
+
+@pytest.mark.gpu
+def test_reference_decoder_built_with_use_cuda_runs_on_this_library():
+    """INTEGRATION.md section 1, executed: the reference's OWN decoder (src/OpusDependencies.c + src/*.cpp) compiled with
+    plain gcc and -DUSE_CUDA -- so that third_party/opus/celt/mdct.c:219-254 forwards every clt_mdct_backward[_B1_C2] call
+    to processMDCTCuda[B1C2] (cuda/mdct_cuda.hpp:89-94) -- and linked against libnyq_imdct.so (oracle/Makefile target
+    libref_decode_dropin.so).  short.opus through THAT build must give the plain reference build's 421,930 samples
+    within 1e-5 relative RMS: long frames (B1_C2, stride 1) and transient frames (eight stride-8 B1_C2 calls) alike.
+    Both are reference builds made in the build container; they travel with the snapshot."""
+    base = os.path.join(ROOT, "oracle", "_ref")
+    plain, dropin = os.path.join(base, "libref_decode.so"), os.path.join(base, "libref_decode_dropin.so")
+    if not (os.path.exists(plain) and os.path.exists(dropin)):
+        pytest.skip("reference builds not in the snapshot (make -C oracle needs /root/reference)")
+    raw = open(os.path.join(GOLDEN, "short.opus"), "rb").read()
+    n = 421930
+    got = {}
+    for key, path in (("plain", plain), ("dropin", dropin)):
+        R = C.CDLL(path)
+        R.ref_decode_pcm.restype = C.c_long
+        R.ref_decode_pcm.argtypes = [C.c_char_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p]
+        a = np.zeros(n, np.float32)
+        assert R.ref_decode_pcm(raw, len(raw), a.ctypes.data_as(C.c_void_p), n, None) == n, key
+        got[key] = a
+    d = got["dropin"].astype(np.float64) - got["plain"]
+    rel = np.sqrt((d ** 2).mean()) / np.sqrt((got["plain"].astype(np.float64) ** 2).mean())
+    assert rel <= 1e-5, rel
+    assert np.abs(d).max() <= 4e-6
+    assert np.abs(got["dropin"]).max() > 0.05           # (real audio came out, not silence)
+
+
+@pytest.mark.gpu
+def test_config4_thousand_real_streams(host):
+    """BASELINE config 4 at its stated stream count on REAL packets: 1000 copies of short.opus (221 frames each,
+    1.7 GB of decoded audio) as one batch through nyqh_batch_decode -- the first and the last stream (and the frame
+    count) must equal the reference decoder's output for the file (short_opus_digest.npz)."""
+    raw = open(os.path.join(GOLDEN, "short.opus"), "rb").read()
+    d = np.load(os.path.join(GOLDEN, "short_opus_digest.npz"))
+    n = 421930
+    first, last = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    stats = np.zeros(6, np.float64)
+    got = host.nyqh_batch_decode_timed(raw, len(raw), 1000, 16, first.ctypes.data_as(C.c_void_p), last.ctypes.data_as(C.c_void_p), n, stats)
+    assert got == n
+    assert int(stats[2]) == 1000 * 221
+    want = d["final"].reshape(-1)
+    assert np.abs(first - want).max() <= 2e-6 and np.abs(last - want).max() <= 2e-6
+    assert np.array_equal(first, last)
 
 
 @pytest.mark.gpu

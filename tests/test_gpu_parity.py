@@ -214,6 +214,57 @@ def test_dropin_shims_vs_reference_strided_fixture(ref_tables):
     lib.cleanupCudaBuffers()
 
 
+def test_dropin_shims_tables_by_content_and_threads(ref_tables, oracle):
+    """The reference-named entry points keep process-wide state (one context, the uploaded tables).  (1) Tables are
+    identified by CONTENT: a caller that refills the SAME buffers with another window gets results for the new window
+    (pointer identity would serve stale tables).  (2) Calls from several threads at once are serialised by the library:
+    every thread gets the result of its own input."""
+    import threading
+    import libnyquist_amd as nyq
+    lib = nyq.load()
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    trig = np.ascontiguousarray(ref_tables["trig"]).copy()
+    win = np.ascontiguousarray(ref_tables["window"]).copy()
+    sine0 = np.float32(2) * np.float32(3.141592653) * np.float32(.125) / np.float32(1920)
+    rng = np.random.default_rng(8)
+    x = (rng.standard_normal(960) * 30).astype(np.float32)
+    carry = (rng.standard_normal(60) * 30).astype(np.float32)
+
+    def call(xx):
+        mem = np.zeros(960 + 60, np.float32)
+        mem[:60] = carry
+        lib.processMDCTCuda(P(xx), P(mem), P(trig), 1920, 0, 1, sine0, 120, P(win))
+        return mem
+
+    a = call(x)
+    win[:] = win[::-1].copy()                                  # same buffer, other content
+    b = call(x)
+    want_b = np.zeros(960 + 60, np.float32)
+    want_b[:60] = carry
+    from oracle.pyoracle import Oracle
+    orig = tuple(np.array(t, copy=True) for t in oracle.tables())
+    try:                                                       # (the C restatement's tables are process-wide: put them back)
+        Oracle((trig, win, orig[2])).imdct(x, want_b, 0)
+    finally:
+        Oracle(orig)
+    assert rel_rms(b, want_b) <= 1e-6 and rel_rms(a[:120], b[:120]) > 1e-3   # (only the mirrored head depends on the window)
+    win[:] = ref_tables["window"]
+    xs = [(rng.standard_normal(960) * 30).astype(np.float32) for _ in range(6)]
+    want = [call(xx) for xx in xs]
+    bad = []
+
+    def worker(k):
+        for _ in range(40):
+            if not np.array_equal(call(xs[k]), want[k]):
+                bad.append(k)
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not bad
+    lib.cleanupCudaBuffers()
+
+
 # ---- device-resident API at BASELINE.json's full size: properties ------------------------
 def test_full_size_device_resident_properties(ctx, oracle):
     """2^20 rows of nfft-480 (config C3) through nyq_imdct_batch_dev: a sampled parity check,
