@@ -251,11 +251,11 @@ struct FrameLongRows {
         fin0 = A.pcm + (sc * A.nframes + f0) * (long)N;
         tail0 = A.tails + (sc * (A.nframes + 1) + f0 + 1) * (long)kHalfOv;
         longmask = 0;
-        const unsigned char *t = A.transient + s * A.nframes;
+        const unsigned char *t = A.transient ? A.transient + s * A.nframes : nullptr;   // (no arithmetic on a null pointer)
 #pragma unroll
         for (int g = -1; g <= G; g++) {
             const long f = f0 + g;
-            if (f >= 0 && f < A.nframes && !(A.transient && t[f])) longmask |= 1u << (g + 1);
+            if (f >= 0 && f < A.nframes && !(t && t[f])) longmask |= 1u << (g + 1);
         }
     }
     NYQ_HD bool any() const { return (longmask & (((1u << G) - 1u) << 1)) != 0; }

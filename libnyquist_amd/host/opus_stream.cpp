@@ -37,7 +37,7 @@ OggOpusFile parseOggOpus(const uint8_t *data, size_t size) {
     bool havePending = false;
     int packetIndex = 0;
     size_t pos = 0;
-    uint32_t serial = 0;
+    uint32_t serial = 0, nextSeq = 0;
     bool haveSerial = false;
     while (pos + 27 <= size) {
         if (std::memcmp(data + pos, "OggS", 4) != 0) {   // resynchronise on garbage
@@ -55,12 +55,19 @@ OggOpusFile parseOggOpus(const uint8_t *data, size_t size) {
         const uint8_t *body = h + 27 + nsegs;
         if (body + bodyLen > data + size) break;
         // page checksum (RFC 3533 section 6: CRC-32, polynomial 0x04c11db7, over the page with the field zeroed).
-        // libogg drops a damaged page and the reference conceals the hole; there is no concealment here, so a
-        // damaged page is reported instead of being decoded into noise.
-        if (oggCrc(h, 27 + (size_t)nsegs, body, bodyLen) != rd32(h + 22))
-            throw std::runtime_error("Ogg page checksum mismatch (damaged file)");
-        if (!haveSerial) { serial = ser; haveSerial = true; }
+        // As libogg does (ogg_sync_pageseek), a capture whose checksum fails is NOT a page: skip one byte and look for
+        // the next capture pattern -- stray "OggS" bytes in trailing junk and damaged pages of other logical streams
+        // then do no harm.  A page of the selected stream that is lost this way shows as a gap in the page sequence
+        // numbers below, which is where the reference gives up too (opusfile reports OP_HOLE, OpusDecoder.cpp:108-112
+        // returns 0 and the load throws): there is no concealment in either build.
+        if (oggCrc(h, 27 + (size_t)nsegs, body, bodyLen) != rd32(h + 22)) {
+            pos++;
+            continue;
+        }
+        if (!haveSerial) { serial = ser; haveSerial = true; nextSeq = rd32(h + 18); }
         if (ser == serial) {                               // first logical stream only
+            if (rd32(h + 18) != nextSeq) throw std::runtime_error("Ogg page missing from the stream (damaged file)");
+            nextSeq++;
             if (!(headerType & 1) && havePending) {        // a fresh packet starts: drop the dangling one
                 pending.clear();
                 havePending = false;

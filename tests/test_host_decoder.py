@@ -5,6 +5,8 @@ import ctypes as C
 import os
 import subprocess
 
+import sys
+
 import numpy as np
 import pytest
 
@@ -95,6 +97,42 @@ def test_entropy_stage_matches_reference_decoder_on_short_opus(host):
     err = np.abs(freq[lo:hi] - ref).max() / np.abs(ref).max()
     assert err <= 1e-6
     assert (freq[lo:hi] == ref).mean() > 0.8          # most coefficients are bit-identical
+
+
+def test_bad_crc_captures_are_skipped_like_libogg_does(host):
+    """libogg (ogg_sync_pageseek) treats a capture pattern whose checksum fails as NOT a page and resynchronises; the
+    reference therefore loads files with stray "OggS" bytes in trailing junk and with damaged pages of OTHER logical
+    streams.  Same here: identical frames to the clean file.  A lost page of the SELECTED stream is a hole in the page
+    sequence: the reference gives up (OP_HOLE -> OpusDecoder.cpp:108-112), and so does this build."""
+    import struct
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from oggopus import ogg_crc, page
+    raw = open(os.path.join(GOLDEN, "short.opus"), "rb").read()
+    rc0, freq0, flags0, gain0, rng0, info0 = entropy_decode(host, raw)
+    assert rc0 == 0 and info0[2] == 220
+    # (1) trailing junk with a fake capture pattern and a plausible header
+    junk = b"\x00" * 7 + b"OggS" + bytes([0, 0]) + struct.pack("<qIII", 12345, 0xDEAD, 7, 0x1234) + bytes([2, 10, 10]) + b"x" * 20 + b"OggS"
+    rc1, freq1, flags1, gain1, rng1, info1 = entropy_decode(host, raw + junk)
+    assert rc1 == 0 and np.array_equal(rng1, rng0) and np.array_equal(freq1, freq0)
+    # (2) a page of a foreign logical stream with a WRONG checksum in the middle of the file
+    foreign = bytearray(page(0x0BADBEEF, 3, 999, b"not our stream" * 10, 0))
+    foreign[22] ^= 0xFF
+    pos, pages = 0, []
+    while pos + 27 <= len(raw) and raw[pos:pos + 4] == b"OggS":
+        nseg = raw[pos + 26]
+        ln = 27 + nseg + sum(raw[pos + 27:pos + 27 + nseg])
+        pages.append(raw[pos:pos + ln])
+        pos += ln
+    mixed = b"".join(pages[:5]) + bytes(foreign) + b"".join(pages[5:])
+    rc2, freq2, flags2, gain2, rng2, info2 = entropy_decode(host, mixed)
+    assert rc2 == 0 and np.array_equal(rng2, rng0) and np.array_equal(freq2, freq0)
+    # (3) one of OUR audio pages damaged (checksum no longer matches): the page is dropped, the hole is an error
+    hurt = bytearray(raw)
+    off = sum(len(p) for p in pages[:6]) + 27 + pages[6][26] + 40      # inside the body of page 6
+    hurt[off] ^= 0x55
+    assert ogg_crc(bytes(pages[6])) is not None
+    rc3 = entropy_decode(host, bytes(hurt))[0]
+    assert rc3 == -10
 
 
 def test_malformed_inputs_are_rejected(host):
