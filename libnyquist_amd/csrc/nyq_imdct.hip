@@ -46,6 +46,10 @@ struct nyq_ctx {
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev_block = nullptr;       // hipEventBlockingSync: host waits on it sleep instead of spinning
+    // frame synthesis runs its transient-frame kernel BESIDE the long-frame kernel (fork / join with two events: the two
+    // touch disjoint frames; capturable into a hipGraph)
+    hipStream_t s_side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int res_imdct[4] = {0, 0, 0, 0};   // resident blocks per kernel instance (occupancy query, cached)
     int res_ifft[4] = {0, 0, 0, 0};
     int res_synth_long[4] = {0, 0, 0, 0};
@@ -136,6 +140,9 @@ extern "C" int nyq_ctx_create(nyq_ctx **out, int device) {
     hipDeviceProp_t prop;
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->s_side, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess ||
         (e = hipMalloc(&ctx->d_trig, sizeof ctx->h_trig)) != hipSuccess ||
         (e = hipMalloc(&ctx->d_window, sizeof ctx->h_window)) != hipSuccess) {
         std::string m = std::string("nyq_ctx_create: ") + hipGetErrorString(e);
@@ -170,6 +177,9 @@ extern "C" void nyq_ctx_destroy(nyq_ctx *ctx) {
     if (ctx->s_d2h) { (void)hipStreamSynchronize(ctx->s_d2h); (void)hipStreamDestroy(ctx->s_d2h); }
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->ev_block) (void)hipEventDestroy(ctx->ev_block);
+    if (ctx->s_side) { (void)hipStreamSynchronize(ctx->s_side); (void)hipStreamDestroy(ctx->s_side); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_vtab) (void)hipFree(ctx->d_vtab);
     if (ctx->d_trig) (void)hipFree(ctx->d_trig);
@@ -343,22 +353,28 @@ static int synth_core(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned 
     A.nframes = (long)nframes;
     A.channels = channels;
     int rc, chain_frames;
+    const size_t units = nsc * nframes;
+    // transient frames: their own kernel, forked onto the side stream so that it runs beside the long-frame kernel (the
+    // two write disjoint frames and disjoint tails slots; the fix-up below joins them)
+    if (A.transient) {
+        NYQ_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+        NYQ_HIP(ctx, hipStreamWaitEvent(ctx->s_side, ctx->ev_fork, 0));
+        const int res = resident_blocks(ctx, synth_short_kernel<Cfg>, &ctx->res_synth_short);
+        const size_t need = (units + kWave * kWavesPerBlock - 1) / (kWave * kWavesPerBlock);
+        const unsigned grid = (unsigned)(need < (size_t)res ? need : (size_t)res);
+        hipLaunchKernelGGL((synth_short_kernel<Cfg>), dim3(grid), dim3(kWave * kWavesPerBlock), 0, ctx->s_side, A, 1 << LM,
+                           ctx->d_trig, ctx->d_window);
+        NYQ_HIP(ctx, hipGetLastError());
+        NYQ_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->s_side));
+    }
     switch (LM) {
     case 3: rc = launch_synth_long<32>(ctx, A); chain_frames = Geo<32>::CHAIN_FRAMES; break;
     case 2: rc = launch_synth_long<16>(ctx, A); chain_frames = Geo<16>::CHAIN_FRAMES; break;
     case 1: rc = launch_synth_long<8>(ctx, A); chain_frames = Geo<8>::CHAIN_FRAMES; break;
     default: rc = launch_synth_long<4>(ctx, A); chain_frames = Geo<4>::CHAIN_FRAMES; break;
     }
+    if (A.transient) NYQ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     if (rc != NYQ_OK) return rc;
-    const size_t units = nsc * nframes;
-    if (A.transient) {
-        const int res = resident_blocks(ctx, synth_short_kernel<Cfg>, &ctx->res_synth_short);
-        const size_t need = (units + kWave * kWavesPerBlock - 1) / (kWave * kWavesPerBlock);
-        const unsigned grid = (unsigned)(need < (size_t)res ? need : (size_t)res);
-        hipLaunchKernelGGL((synth_short_kernel<Cfg>), dim3(grid), dim3(kWave * kWavesPerBlock), 0, ctx->stream, A, 1 << LM,
-                           ctx->d_trig, ctx->d_window);
-        NYQ_HIP(ctx, hipGetLastError());
-    }
     const size_t per_block = (size_t)kWave * kFixupWaves;
     hipLaunchKernelGGL(synth_fixup_kernel, dim3((unsigned)((units + per_block - 1) / per_block)),
                        dim3(kWave * kFixupWaves), 0, ctx->stream, A, 120 << LM, chain_frames, ctx->d_window);

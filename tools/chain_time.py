@@ -59,7 +59,16 @@ if os.environ.get("CHAIN_SPLIT") == "1":
                                            work.data_ptr(), ns, nf, ch))
     t_p = timed(lambda: ctx.celt_post_dev(3, pcm.data_ptr(), pitch.data_ptr(), gain.data_ptr(), tap.data_ptr(), 0, 0, 0, 0, out.data_ptr(), ns, nf, ch))
     t_c = timed(run)
-    print(json.dumps({"synth_alone_ms": t_s, "post_alone_ms": t_p, "sum_ms": t_s + t_p, "chain_as_a_unit_ms": t_c, "with_state": WITH_STATE}))
+    st2 = torch.zeros_like(state)
+
+    def two_calls():
+        ctx.celt_synth_dev(3, freq.data_ptr(), trans.data_ptr(), pcm.data_ptr(), state.data_ptr() if WITH_STATE else 0, work.data_ptr(), ns, nf, ch)
+        ctx.celt_post_dev(3, pcm.data_ptr(), pitch.data_ptr(), gain.data_ptr(), tap.data_ptr(), 0, 0, 0, 0, out.data_ptr(), ns, nf, ch)
+    t_2 = timed(two_calls)
+    state.zero_()
+    t_c0 = timed(run)
+    print(json.dumps({"synth_alone_ms": t_s, "post_alone_ms": t_p, "sum_ms": t_s + t_p, "chain_as_a_unit_ms": t_c, "two_api_calls_as_a_unit_ms": t_2,
+                      "chain_again_after_zeroing_state_ms": t_c0, "state_abs_max": float(state.abs().max()), "with_state": WITH_STATE}))
     sys.exit(0)
 
 
