@@ -334,16 +334,13 @@ static int synth_core(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned 
                       const float *d_state_in, float *d_state_out, float *d_work, size_t nstreams, size_t nframes,
                       int channels) {
     const size_t nsc = nstreams * (size_t)channels;
-    const size_t pitch = (nframes + 1) * NYQ_HALF_OV * sizeof(float), slot = NYQ_HALF_OV * sizeof(float);
-    // tails slot 0 of every (stream, channel) = the state handed in
-    const unsigned cgrid = (unsigned)((nsc * 15 + 255) / 256);
-    if (d_state_in) {
-        hipLaunchKernelGGL(tail_rows_copy_kernel, dim3(cgrid), dim3(256), 0, ctx->stream, d_work, (long)((nframes + 1) * NYQ_HALF_OV),
-                           d_state_in, (long)NYQ_HALF_OV, (long)nsc);
-        NYQ_HIP(ctx, hipGetLastError());
-    } else {
-        NYQ_HIP(ctx, hipMemset2DAsync(d_work, pitch, 0, slot, nsc, ctx->stream));
-    }
+    // Slot 0 of every (stream, channel)'s tails row is not used any more (the fix-up pass reads the state handed in), but it
+    // is kept DEFINED by this 2-D memset node -- and the node stays for a measured reason: with a fill node of the runtime
+    // in front of the synthesis kernels, the post-filter kernel that FOLLOWS them runs in 0.90 ms instead of 1.57 ms
+    // (rocprofv3 kernel traces of the same chain with and without it: profiles/r02_chain_fill_node_effect.txt; a tiny 1-D
+    // memset or a tiny ordinary kernel in the same place does not have the effect, a fill of unrelated memory does).  The
+    // mechanism was not identified (the fill kernel takes 18 us; the synthesis kernels take the same time either way).
+    NYQ_HIP(ctx, hipMemset2DAsync(d_work, (nframes + 1) * NYQ_HALF_OV * sizeof(float), 0, NYQ_HALF_OV * sizeof(float), nsc, ctx->stream));
     SynthArgs A;
     A.freq = d_freq;
     A.transient = LM > 0 ? d_transient : nullptr;   // LM 0: one block either way (B = 1)
@@ -352,6 +349,8 @@ static int synth_core(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned 
     A.nstreams = (long)nstreams;
     A.nframes = (long)nframes;
     A.channels = channels;
+    A.state_in = d_state_in;                        // (read and replaced by the fix-up pass: no copy launches)
+    A.state_out = d_state_out;
     int rc, chain_frames;
     const size_t units = nsc * nframes;
     // transient frames: their own kernel, forked onto the side stream so that it runs beside the long-frame kernel (the
@@ -379,11 +378,6 @@ static int synth_core(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned 
     hipLaunchKernelGGL(synth_fixup_kernel, dim3((unsigned)((units + per_block - 1) / per_block)),
                        dim3(kWave * kFixupWaves), 0, ctx->stream, A, 120 << LM, chain_frames, ctx->d_window);
     NYQ_HIP(ctx, hipGetLastError());
-    if (d_state_out) {
-        hipLaunchKernelGGL(tail_rows_copy_kernel, dim3(cgrid), dim3(256), 0, ctx->stream, d_state_out, (long)NYQ_HALF_OV,
-                           d_work + nframes * NYQ_HALF_OV, (long)((nframes + 1) * NYQ_HALF_OV), (long)nsc);
-        NYQ_HIP(ctx, hipGetLastError());
-    }
     return NYQ_OK;
 }
 

@@ -207,8 +207,10 @@ struct IndepRows {
 //                                           blocks, coefficient k of block b at [b + B*k]
 //   transient [stream][frame]               non-zero = transient (shortBlocks) frame
 //   pcm       [stream][channel][frame*N..]  time-contiguous per channel (the out_syn history)
-//   tails     [stream*channels][nframes+1][60]   slot f+1 = raw tail after frame f; slot 0 = the
-//                                           overlap state before frame 0
+//   tails     [stream*channels][nframes+1][60]   slot f+1 = raw tail after frame f (slot 0 is unused: the overlap
+//                                           state before frame 0 is read from state_in by the fix-up pass)
+//   state_in / state_out [stream*channels][60] or null; may be the same buffer (the fix-up pass reads a chain's state
+//                                           before it writes it, in the same lanes)
 struct SynthArgs {
     const float *freq;
     const unsigned char *transient;
@@ -216,6 +218,8 @@ struct SynthArgs {
     float *tails;
     long nstreams, nframes;
     int channels;
+    const float *state_in;
+    float *state_out;
 };
 
 // Long frames.  A wave visits CHUNKS of kChainGroups groups = 4 G consecutive frames of one

@@ -261,21 +261,17 @@ __global__ __launch_bounds__(kWave *kFixupWaves) void synth_fixup_kernel(SynthAr
         const long u = base + bit;
         const long sc = u / A.nframes, f = u - sc * A.nframes;
         if (lane < kHalfOv) {
-            const float cv = A.tails[(sc * (A.nframes + 1) + f) * (long)kHalfOv + lane];
+            // frame 0 takes the overlap state handed in; that chain's state is then replaced by the tail behind its last
+            // frame (same lanes, read before write: state_in and state_out may be one buffer; frame 0 always lands here)
+            const float cv = f == 0 ? (A.state_in ? A.state_in[sc * (long)kHalfOv + lane] : 0.f)
+                                    : A.tails[(sc * (A.nframes + 1) + f) * (long)kHalfOv + lane];
             float *o = A.pcm + (sc * A.nframes + f) * (long)N;
             o[lane] += wa * cv;
             o[kOverlap - 1 - lane] += wb * cv;
+            if (f == 0 && A.state_out)
+                A.state_out[sc * (long)kHalfOv + lane] = A.tails[(sc * (A.nframes + 1) + A.nframes) * (long)kHalfOv + lane];
         }
     }
-}
-
-// 60-float rows from one pitch to another (the overlap state into / out of slot 0 / slot nframes of the tails buffer):
-// one launch of a few microseconds instead of a 2-D memcpy node (measured ~50 us each for 2048 rows)
-__global__ __launch_bounds__(256) void tail_rows_copy_kernel(float *__restrict__ dst, long dpitch, const float *__restrict__ src,
-                                                             long spitch, long nrows) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;        // one float4 each: 15 per row
-    const long r = i / 15, q = i - r * 15;
-    if (r < nrows) *reinterpret_cast<f4 *>(dst + r * dpitch + 4 * q) = *reinterpret_cast<const f4 *>(src + r * spitch + 4 * q);
 }
 
 template <int N2R, int WPB>

@@ -109,10 +109,12 @@ static void emu_synth_fixup(const SynthArgs &A, int N, int chain_frames, const f
         const long sc = u / A.nframes, f = u - sc * A.nframes, s = sc / A.channels;
         if (head_done_in_wave(A.transient ? A.transient + s * A.nframes : nullptr, f, chain_frames)) continue;
         for (int i = 0; i < kHalfOv; i++) {
-            const float cv = A.tails[(sc * (A.nframes + 1) + f) * (long)kHalfOv + i];
+            const float cv = f == 0 ? (A.state_in ? A.state_in[sc * (long)kHalfOv + i] : 0.f)
+                                    : A.tails[(sc * (A.nframes + 1) + f) * (long)kHalfOv + i];
             float *o = A.pcm + (sc * A.nframes + f) * (long)N;
             o[i] += window[kOverlap - 1 - i] * cv;
             o[kOverlap - 1 - i] += window[i] * cv;
+            if (f == 0 && A.state_out) A.state_out[sc * (long)kHalfOv + i] = A.tails[(sc * (A.nframes + 1) + A.nframes) * (long)kHalfOv + i];
         }
     }
 }
@@ -138,16 +140,13 @@ extern "C" int emu_ifft_batch(int nfft, const float *in, float *out, long nrows)
     return -1;
 }
 
-// mirrors nyq_celt_synth_dev (nyq_imdct.hip): slot-0 seeding, long, short, fix-up, state out
+// mirrors nyq_celt_synth_dev (nyq_imdct.hip): long, short, fix-up (which takes the state in and hands the state out)
 extern "C" int emu_celt_synth(int LM, const float *freq, const unsigned char *transient, float *pcm, float *state,
                               long nstreams, long nframes, int channels, const float *trig, const float *window) {
     if (LM < 0 || LM > 3) return -1;
     const long nsc = nstreams * channels;
     std::vector<float> tails((size_t)nsc * (nframes + 1) * kHalfOv, 0.f);
-    for (long sc = 0; sc < nsc; sc++)
-        for (int i = 0; i < kHalfOv; i++)
-            tails[(size_t)sc * (nframes + 1) * kHalfOv + i] = state ? state[sc * kHalfOv + i] : 0.f;
-    SynthArgs A{freq, LM > 0 ? transient : nullptr, pcm, tails.data(), nstreams, nframes, channels};
+    SynthArgs A{freq, LM > 0 ? transient : nullptr, pcm, tails.data(), nstreams, nframes, channels, state, state};
     int chain_frames;
     switch (LM) {
     case 3: emu_synth_long<32>(A, trig, window); chain_frames = Geo<32>::CHAIN_FRAMES; break;
@@ -157,10 +156,6 @@ extern "C" int emu_celt_synth(int LM, const float *freq, const unsigned char *tr
     }
     if (A.transient) emu_synth_short(A, 1 << LM, trig, window);
     emu_synth_fixup(A, 120 << LM, chain_frames, window);
-    if (state)
-        for (long sc = 0; sc < nsc; sc++)
-            for (int i = 0; i < kHalfOv; i++)
-                state[sc * kHalfOv + i] = tails[((size_t)sc * (nframes + 1) + nframes) * kHalfOv + i];
     return 0;
 }
 

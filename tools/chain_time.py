@@ -65,6 +65,23 @@ if os.environ.get("CHAIN_SPLIT") == "1":
         ctx.celt_synth_dev(3, freq.data_ptr(), trans.data_ptr(), pcm.data_ptr(), state.data_ptr() if WITH_STATE else 0, work.data_ptr(), ns, nf, ch)
         ctx.celt_post_dev(3, pcm.data_ptr(), pitch.data_ptr(), gain.data_ptr(), tap.data_ptr(), 0, 0, 0, 0, out.data_ptr(), ns, nf, ch)
     t_2 = timed(two_calls)
+    tiny = torch.zeros(64, device=dev)
+
+    def with_tiny(where):
+        def f():
+            if where == "before_synth":
+                tiny.add_(1.0)
+            ctx.celt_synth_dev(3, freq.data_ptr(), trans.data_ptr(), pcm.data_ptr(), state.data_ptr() if WITH_STATE else 0, work.data_ptr(), ns, nf, ch)
+            if where == "between":
+                tiny.add_(1.0)
+            ctx.celt_post_dev(3, pcm.data_ptr(), pitch.data_ptr(), gain.data_ptr(), tap.data_ptr(), 0, 0, 0, 0, out.data_ptr(), ns, nf, ch)
+        return f
+    extra = {w: timed(with_tiny(w)) for w in ("before_synth", "between")}
+    os.environ["NYQ_POST_STEREO_PAIRS"] = "0"
+    extra["two_calls_with_round1_post_kernel"] = timed(two_calls)
+    extra["round1_post_kernel_alone"] = timed(lambda: ctx.celt_post_dev(3, pcm.data_ptr(), pitch.data_ptr(), gain.data_ptr(), tap.data_ptr(), 0, 0, 0, 0, out.data_ptr(), ns, nf, ch))
+    del os.environ["NYQ_POST_STEREO_PAIRS"]
+    print(json.dumps(extra))
     state.zero_()
     t_c0 = timed(run)
     print(json.dumps({"synth_alone_ms": t_s, "post_alone_ms": t_p, "sum_ms": t_s + t_p, "chain_as_a_unit_ms": t_c, "two_api_calls_as_a_unit_ms": t_2,

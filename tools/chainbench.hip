@@ -93,6 +93,15 @@ int main(int argc, char **argv) {
         char nm[128]; snprintf(nm, sizeof nm, "r2 workgroup pipeline (occ %d blk/CU, grid %u)", occ, grid);
         v.push_back({nm, [=] { hipLaunchKernelGGL((celt_post_pipe_kernel<3>), dim3(grid), dim3(kWave * kPipeWaves), 0, 0, A, d_win); }, {}});
     }
+    // experiment: the pipeline kernel behind a large memset node (a fill kernel of the runtime) on unrelated memory
+    {
+        static float *dummy = nullptr;
+        const size_t dbytes = (size_t)128 << 20;
+        CK(hipMalloc(&dummy, dbytes));
+        auto base = v.back().run;
+        v.push_back({"r2 workgroup pipeline behind a 128 MB memset node", [=] { CK(hipMemsetAsync(dummy, 0, dbytes, 0)); base(); }, {}});
+        v.push_back({"the 128 MB memset node alone", [=] { CK(hipMemsetAsync(dummy, 0, dbytes, 0)); }, {}});
+    }
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (auto &x : v) x.run();
