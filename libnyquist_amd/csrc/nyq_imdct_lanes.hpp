@@ -244,7 +244,25 @@ struct FrameLongRows {
     int qq;             // group inside the chunk
     // chunk ci = sc * chunks_per_channel + k covers frames 4Gk .. 4Gk+4G-1 of channel sc
     NYQ_HD static long chunks_per_channel(long nframes) { return (nframes + kChainFrames - 1) / kChainFrames; }
-    NYQ_HD FrameLongRows(const SynthArgs &A, long ci, int qq_) {
+    // Bit i + 1 of the chunk's transient mask <=> frame (first frame of the chunk) + i is transient, i = -1 .. 4 G
+    // (frames outside the stream count as not transient; `valid` checks the range).  The kernel fetches the mask
+    // ONCE per chunk (one byte per lane + a ballot) instead of G + 2 flag bytes in front of every group's loads.
+    NYQ_HD static unsigned long long chunk_transient_mask(const SynthArgs &A, long ci) {
+        const long cpc = chunks_per_channel(A.nframes);
+        const long sc = ci / cpc, k = ci - sc * cpc;
+        const long s = sc / A.channels;
+        unsigned long long m = 0;
+        if (A.transient) {
+            const unsigned char *t = A.transient + s * A.nframes;
+            for (int i = -1; i <= kChainFrames; i++) {
+                const long f = k * kChainFrames + i;
+                if (i + 1 < 64 && f >= 0 && f < A.nframes && t[f]) m |= 1ull << (i + 1);   // (4 G + 2 <= 64 whenever flags exist: LM >= 1)
+            }
+        }
+        return m;
+    }
+    NYQ_HD FrameLongRows(const SynthArgs &A, long ci, int qq_) : FrameLongRows(A, ci, qq_, chunk_transient_mask(A, ci)) {}
+    NYQ_HD FrameLongRows(const SynthArgs &A, long ci, int qq_, unsigned long long tmask) {
         const long cpc = chunks_per_channel(A.nframes);
         const long sc = ci / cpc, k = ci - sc * cpc;
         const long s = sc / A.channels, c = sc - s * A.channels;
@@ -255,11 +273,12 @@ struct FrameLongRows {
         fin0 = A.pcm + (sc * A.nframes + f0) * (long)N;
         tail0 = A.tails + (sc * (A.nframes + 1) + f0 + 1) * (long)kHalfOv;
         longmask = 0;
-        const unsigned char *t = A.transient ? A.transient + s * A.nframes : nullptr;   // (no arithmetic on a null pointer)
 #pragma unroll
         for (int g = -1; g <= G; g++) {
             const long f = f0 + g;
-            if (f >= 0 && f < A.nframes && !(t && t[f])) longmask |= 1u << (g + 1);
+            const int bit = qq_ * G + g + 1;
+            const bool tr = bit < 64 && ((tmask >> bit) & 1ull);
+            if (f >= 0 && f < A.nframes && !tr) longmask |= 1u << (g + 1);
         }
     }
     NYQ_HD bool any() const { return (longmask & (((1u << G) - 1u) << 1)) != 0; }

@@ -175,10 +175,25 @@ __global__ __launch_bounds__(kWave *Cfg::WPB) void synth_long_kernel(SynthArgs A
 
     const long nchunks = A.nstreams * A.channels * FrameLongRows<N2R>::chunks_per_channel(A.nframes);
     const long nwaves = (long)gridDim.x * Cfg::WPB;
+    // The transient flags of a chunk in one go -- lane i holds frame (chunk start - 1 + i), a ballot makes the mask --
+    // and one chunk AHEAD: the flag bytes of the next chunk are on their way while this one is transformed.
+    auto flag_of = [&](long ci) {
+        bool tr = false;
+        if (A.transient && ci < nchunks) {
+            const long cpc = FrameLongRows<N2R>::chunks_per_channel(A.nframes);
+            const long sc = ci / cpc, k = ci - sc * cpc;
+            const long f = k * FrameLongRows<N2R>::kChainFrames - 1 + lane;
+            if (lane <= FrameLongRows<N2R>::kChainFrames + 1 && f >= 0 && f < A.nframes) tr = A.transient[(sc / A.channels) * A.nframes + f] != 0;
+        }
+        return tr;
+    };
+    bool tr_next = flag_of((long)blockIdx.x * Cfg::WPB + wv);
     for (long ci = (long)blockIdx.x * Cfg::WPB + wv; ci < nchunks; ci += nwaves) {
+        const unsigned long long tmask = __ballot(tr_next);
+        tr_next = flag_of(ci + nwaves);
 #pragma unroll 1
         for (int qq = 0; qq < kChainGroups; qq++) {
-            FrameLongRows<N2R> rows(A, ci, qq);
+            FrameLongRows<N2R> rows(A, ci, qq, tmask);
             if (!rows.any()) continue;   // four transient (or out-of-range) frames: nothing to do here
             StageRegs<N2R> R;
             stage_in_load<N2R, Cfg::NT_LD>(R, lane, rows);
