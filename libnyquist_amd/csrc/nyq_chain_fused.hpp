@@ -92,11 +92,6 @@ struct FusedShortRows {
     __device__ float *tail(int g) const { return (g & 7) == 7 ? tails + (g >> 3) * kHalfOv : nullptr; }
 };
 
-__device__ __forceinline__ int opaque(int v) {   // the value, but not a loop invariant to the optimiser
-    asm volatile("" : "+v"(v));
-    return v;
-}
-
 __global__ __launch_bounds__(kWave *kFuseWaves, NYQ_FUSE_MINWAVES) void celt_chain_fused_kernel(ChainArgs A, const float *__restrict__ trig,
                                                                                  const float *__restrict__ window) {
     constexpr int N = kFuseN, NV = N / 4, NLD = 4;

@@ -334,13 +334,9 @@ static int synth_core(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned 
                       const float *d_state_in, float *d_state_out, float *d_work, size_t nstreams, size_t nframes,
                       int channels) {
     const size_t nsc = nstreams * (size_t)channels;
-    // Slot 0 of every (stream, channel)'s tails row is not used any more (the fix-up pass reads the state handed in), but it
-    // is kept DEFINED by this 2-D memset node -- and the node stays for a measured reason: with a fill node of the runtime
-    // in front of the synthesis kernels, the post-filter kernel that FOLLOWS them runs in 0.90 ms instead of 1.57 ms
-    // (rocprofv3 kernel traces of the same chain with and without it: profiles/r02_chain_fill_node_effect.txt; a tiny 1-D
-    // memset or a tiny ordinary kernel in the same place does not have the effect, a fill of unrelated memory does).  The
-    // mechanism was not identified (the fill kernel takes 18 us; the synthesis kernels take the same time either way).
-    NYQ_HIP(ctx, hipMemset2DAsync(d_work, (nframes + 1) * NYQ_HALF_OV * sizeof(float), 0, NYQ_HALF_OV * sizeof(float), nsc, ctx->stream));
+    // (slot 0 of every (stream, channel)'s tails row is unused: the fix-up pass reads the state handed in instead.  Round 2
+    // kept a memset node here because the post-filter kernel behind the synthesis ran 0.9 instead of 1.6 ms with it; the
+    // cause turned out to be workgroup placement of that kernel -- nyq_post_pipe.hpp, kPipeHist -- and is fixed there.)
     SynthArgs A;
     A.freq = d_freq;
     A.transient = LM > 0 ? d_transient : nullptr;   // LM 0: one block either way (B = 1)
@@ -1046,3 +1042,10 @@ extern "C" void printCudaVersion(void) {
     (void)hipGetDeviceCount(&ndev);
     std::printf("HIP runtime %d, driver %d, %d device(s) [libnyq_imdct, gfx950]\n", rt, drv, ndev);
 }
+
+#ifdef NYQ_PIPE_STAMPS
+// diagnostic build only (tools/placement_trace.py): the post-filter pipeline's per-workgroup placement trace
+extern "C" int nyq_debug_pipe_wg(void *out, size_t bytes) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(nyq::g_pipe_wg), bytes < sizeof(nyq::g_pipe_wg) ? bytes : sizeof(nyq::g_pipe_wg)) == hipSuccess ? 0 : 1;
+}
+#endif

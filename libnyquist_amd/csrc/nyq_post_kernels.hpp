@@ -59,6 +59,13 @@ __device__ __forceinline__ void comb_gains(float g, int tapset, float &a, float 
     c = g * t2;
 }
 
+// the value, but not a loop invariant to the optimiser: per-lane offsets derived from an opaque copy of the lane id are
+// recomputed where they are used (a few VALU operations) instead of being hoisted out of the frame loop and kept alive
+__device__ __forceinline__ int opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 #define NYQ_POST_SYNC()                                          \
     do {                                                         \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \

@@ -47,6 +47,18 @@ __device__ unsigned long long g_pipe_stamps[16];
             for (int st_i = 0; st_i < 6; st_i++) atomicAdd(&g_pipe_stamps[(base) + st_i], st_acc[st_i]); \
     } while (0)
 __device__ unsigned long long g_stamp_mid_t;   // (unused placeholder: keeps the macro below self-contained)
+// placement trace: per workgroup {HW_ID, XCC_ID, first cycle, last cycle} (which CU it ran on, when it started / ended)
+__device__ unsigned long long g_pipe_wg[4096][4];
+#define NYQ_WG_TRACE(slot)                                                                                \
+    do {                                                                                                  \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) {                                                      \
+            if ((slot) == 2) {                                                                            \
+                g_pipe_wg[blockIdx.x][0] = __builtin_amdgcn_s_getreg(63492);                              \
+                g_pipe_wg[blockIdx.x][1] = __builtin_amdgcn_s_getreg(63508);                              \
+            }                                                                                             \
+            g_pipe_wg[blockIdx.x][slot] = __builtin_amdgcn_s_memrealtime();                               \
+        }                                                                                                 \
+    } while (0)
 #define NYQ_STAMP_MID()                                                  \
     do {                                                                 \
         if (stm) {                                                       \
@@ -57,11 +69,18 @@ __device__ unsigned long long g_stamp_mid_t;   // (unused placeholder: keeps the
     } while (0)
 #else
 #define NYQ_STAMP_MID() do { } while (0)
+#define NYQ_WG_TRACE(slot) do { } while (0)
 #define NYQ_STAMP_DECL() do { } while (0)
 #define NYQ_STAMP(slot) do { } while (0)
 #define NYQ_STAMP_FLUSH(base) do { } while (0)
 #endif
 constexpr int kPipeUnits = 2;          // chains per workgroup
+// History in front of the frame inside an LDS buffer: >= COMBFILTER_MAXPERIOD + 2 + 3 (the 16-byte tap reads start up to three
+// floats early) = 1029, and small enough that a workgroup's LDS (4 buffers of 1040 + 960 floats + 544 B = 32544 B) stays under
+// 32 KB = a FIFTH of the CU's 160 KB although only four workgroups per CU are wanted: with the 1088 floats of the state
+// hand-over (33312 B) four fit only when the CU's LDS is handed out from offset 0, and after other kernels it is not -- some
+// CUs then take three workgroups for the whole launch (measurements: see the launch bounds of the kernel below).
+constexpr int kPipeHist = 1040;
 
 // copy cur[i0, i0+n) -> mir[i0, i0+n) (n, i0 multiples of 4), whole wave
 template <bool MIR>
@@ -459,14 +478,32 @@ struct PipeParams {
     int pad;
 };
 
+// Four waves per SIMD, i.e. at most 128 VGPRs -- NOT for occupancy (the LDS admits four workgroups = 12 waves per CU, three
+// per SIMD) but for PLACEMENT, like kPipeHist above: a workgroup lives for the whole launch, so one that cannot be placed at
+// once waits ~0.8 ms for a retiring one and holds up every workgroup queued behind it on its XCD.  Measured with
+// tools/placement_trace.py (s_memrealtime + HW_ID per workgroup, behind synthesis kernels / fills / itself):
+//   168 VGPRs (3 waves fill a SIMD's file exactly), 33312 B LDS (4 fill the CU's LDS but for 30 KB): 4-40 of 1024
+//        workgroups 0.72-0.85 ms late in most launches that follow another kernel -> 1.6 instead of 0.95 ms
+//   121 VGPRs, 33312 B: the same;   137 VGPRs, 32544 B: the same;   119 VGPRs, 32544 B (this build): none, any predecessor.
+// Both allocators evidently hand out space from wherever the previous kernels left off, so "exactly four fit" only holds
+// from offset zero; with one more wave's registers and one more workgroup's LDS to spare four always fit.
+#ifndef NYQ_PIPE_MINWAVES
+#define NYQ_PIPE_MINWAVES 4
+#endif
+#pragma clang diagnostic ignored "-Wpass-failed"   // ("occupancy target 4, final occupancy 3": the LDS bound, intended -- see above)
 template <int LM>
-__global__ __launch_bounds__(kWave *kPipeWaves, 3) void celt_post_pipe_kernel(PostArgs A, const float *__restrict__ window) {
+#ifdef NYQ_PIPE_NUM_VGPR
+__attribute__((amdgpu_num_vgpr(NYQ_PIPE_NUM_VGPR)))
+#endif
+__global__ __launch_bounds__(kWave *kPipeWaves, NYQ_PIPE_MINWAVES) void celt_post_pipe_kernel(PostArgs A, const float *__restrict__ window) {
     constexpr int N = 120 << LM;
     constexpr int NV = N / 4;
     constexpr int NLD = (NV + kWave - 1) / kWave;   // float4 per lane and frame (4, 2, 1, 1)
-    constexpr int R0 = kPostHist;                   // frame start inside a buffer
-    constexpr int KEEP = kPostHist - N;             // history samples that survive a frame: cur[N, 1088) -> nxt[0, KEEP)
-    __shared__ __attribute__((aligned(16))) float bufs[kPipeUnits][2][kPostRing];
+    constexpr int R0 = kPipeHist;                   // frame start inside a buffer
+    constexpr int KEEP = kPipeHist - N;             // history samples that survive a frame: cur[N, R0) -> nxt[0, KEEP)
+    constexpr int OLD = kPostHist - kPipeHist;      // samples of the handed-over history (1088) that are older than the buffer's
+    static_assert(N >= OLD, "the previous buffer still holds the history the state hand-over needs");
+    __shared__ __attribute__((aligned(16))) float bufs[kPipeUnits][2][kPipeHist + N];
     __shared__ __attribute__((aligned(16))) float win2[kOverlap];
     __shared__ __attribute__((aligned(16))) PipeParams pslot[kPipeUnits][2];
     for (int i = threadIdx.x; i < kOverlap; i += kWave * kPipeWaves) win2[i] = window[i] * window[i];
@@ -475,6 +512,7 @@ __global__ __launch_bounds__(kWave *kPipeWaves, 3) void celt_post_pipe_kernel(Po
     const long nunits = A.nstreams * A.channels;
     const long npairs = (nunits + kPipeUnits - 1) / kPipeUnits;
     const long nfr = A.nframes;
+    NYQ_WG_TRACE(2);
     __syncthreads();
 
     // The two roles are two separate loops over the same workgroup units (the register allocator then sees two
@@ -544,6 +582,9 @@ __global__ __launch_bounds__(kWave *kPipeWaves, 3) void celt_post_pipe_kernel(Po
 #endif
 #ifndef NYQ_PIPE_DBG_NO_IO
     if (wave >= kPipeUnits) {
+#ifdef NYQ_PIPE_IO_PRIO
+        __builtin_amdgcn_s_setprio(NYQ_PIPE_IO_PRIO);
+#endif
         DeConst D;
         deemph_init<N>(D, lane);
         for (long pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
@@ -574,13 +615,14 @@ __global__ __launch_bounds__(kWave *kPipeWaves, 3) void celt_post_pipe_kernel(Po
                 for (int q = 0; q < NLD; q++) nx[k][q] = vf4{0, 0, 0, 0};
             }
             auto fetch = [&](long fidx) {                      // frame fidx and its parameters -> registers
+                const int ln = opaque(lane);
 #pragma unroll
                 for (int k = 0; k < kPipeUnits; k++) {
                     if (!live[k]) continue;
                     const vf4 *fr = src[k] + fidx * NV;
 #pragma unroll
                     for (int q = 0; q < NLD; q++) {
-                        const int v = lane + q * kWave;
+                        const int v = ln + q * kWave;
                         nx[k][q] = fr[v < NV ? v : NV - 1]; // lanes past the frame re-read its last vector
                     }
                     const long pi = sU[k] * nfr + fidx;
@@ -589,16 +631,18 @@ __global__ __launch_bounds__(kWave *kPipeWaves, 3) void celt_post_pipe_kernel(Po
                     pS[k] = A.pf_tapset[pi];
                 }
             };
-            auto land = [&](long fidx, int b) {                // registers -> frame region of buffer b, parameter slot fidx & 1
+            // registers -> frame region of buffer b (float4 columns q0 .. q1-1 of the lane), parameter slot fidx & 1
+            auto land = [&](long fidx, int b, int q0, int q1) {
+                const int ln = opaque(lane);
 #pragma unroll
                 for (int k = 0; k < kPipeUnits; k++) {
                     if (!live[k]) continue;
 #pragma unroll
                     for (int q = 0; q < NLD; q++) {
-                        const int v = lane + q * kWave;
-                        if (v < NV) sts4(bufs[k][b], R0 + 4 * v, nx[k][q]);
+                        const int v = ln + q * kWave;
+                        if (q >= q0 && q < q1 && v < NV) sts4(bufs[k][b], R0 + 4 * v, nx[k][q]);
                     }
-                    if (lane == 0) {
+                    if (q0 == 0 && ln == 0) {
                         PipeParams *ps = &pslot[k][fidx & 1];
                         ps->T = pT[k];
                         ps->g = pG[k];
@@ -611,11 +655,11 @@ __global__ __launch_bounds__(kWave *kPipeWaves, 3) void celt_post_pipe_kernel(Po
             for (int k = 0; k < kPipeUnits; k++) {
                 if (!live[k]) continue;
 #pragma unroll 1
-                for (int j = lane; j < kPostHist; j += kWave) bufs[k][0][j] = A.hist ? A.hist[(u0 + k) * kPostHist + j] : 0.f;
+                for (int j = lane; j < kPipeHist; j += kWave) bufs[k][0][j] = A.hist ? A.hist[(u0 + k) * kPostHist + OLD + j] : 0.f;
             }
             if (nfr > 0) {
                 fetch(0);
-                land(0, 0);
+                land(0, 0, 0, NLD);
                 if (nfr > 1) fetch(1);
             }
             __syncthreads();
@@ -629,79 +673,116 @@ __global__ __launch_bounds__(kWave *kPipeWaves, 3) void celt_post_pipe_kernel(Po
                     for (int k = 0; k < kPipeUnits; k++)
                         if (live[k]) pipe_copy<true>(bufs[k][cb] + N, bufs[k][nb], lane, 0, KEEP);
                 }
+                __builtin_amdgcn_sched_barrier(0);             // (or the copy's writes sink to the end of the iteration, registers held)
                 NYQ_STAMP(0);                                  // slot 0: history carry-over
                 // frame f-1 is final in cur[1088 - N, 1088): de-emphasis, staged in nxt's frame region, picked up again
                 // in the output's interleaved order (registers) -- before the raw frame f+1 lands in that region
-                vf4 sv[2 * NLD];
+                // The pick-up / land / store sequence runs in HALVES of the frame (long frames): the interleaved output of
+                // one half is picked up into registers, the raw frame f+1 lands over exactly that half of the stage, the
+                // half is stored -- 16 instead of 32 registers of output in flight (the kernel has to stay at 128 VGPRs:
+                // see the launch bounds).
+                constexpr int HALVES = NLD % 2 == 0 ? 2 : 1;
+                constexpr int QH = NLD / HALVES;               // float4 columns of a unit's frame per half
+                const float *const dstg[kPipeUnits] = {bufs[0][nb] + R0, bufs[1][nb] + R0};
                 if (f >= 1) {
                     const float *const dsrc[kPipeUnits] = {bufs[0][cb] + R0 - N, bufs[1][cb] + R0 - N};
-                    float *const dstg[kPipeUnits] = {bufs[0][nb] + R0, bufs[1][nb] + R0};
-                    deemph_frames<N, kPipeUnits>(dsrc, dstg, mem, live, lane, D);
+                    float *const dst[kPipeUnits] = {bufs[0][nb] + R0, bufs[1][nb] + R0};
+#ifndef NYQ_PIPE_DEEMPH_PAIRED   // (one unit after the other: 15 fewer registers; the I/O wave has the time)
+#pragma unroll
+                    for (int k = 0; k < kPipeUnits; k++) {
+                        const float *const s1[1] = {dsrc[k]};
+                        float *const d1[1] = {dst[k]};
+                        float m1[1] = {mem[k]};
+                        const bool l1[1] = {live[k]};
+                        deemph_frames<N, 1>(s1, d1, m1, l1, opaque(lane), D);
+                        mem[k] = m1[0];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#else
+                    deemph_frames<N, kPipeUnits>(dsrc, dst, mem, live, opaque(lane), D);
+#endif
                     NYQ_POST_SYNC();
-                    if (pairOut) {
-                        // float4 v = {L[2v], R[2v], L[2v+1], R[2v+1]}
-#pragma unroll
-                        for (int q = 0; q < 2 * NLD; q++) {
-                            const int v = lane + q * kWave, vv = v < 2 * NV ? v : 0;
-                            const float2 l = *reinterpret_cast<const float2 *>(dstg[0] + 2 * vv);
-                            const float2 r = *reinterpret_cast<const float2 *>(dstg[1] + 2 * vv);
-                            sv[q] = vf4{l.x, r.x, l.y, r.y};
-                        }
-                    } else if (A.channels == 1) {
-#pragma unroll
-                        for (int k = 0; k < kPipeUnits; k++)
-#pragma unroll
-                            for (int q = 0; q < NLD; q++) {
-                                const int v = lane + q * kWave;
-                                sv[k * NLD + q] = *reinterpret_cast<const vf4 *>(dstg[k] + 4 * (v < NV ? v : 0));
-                            }
-                    } else {
+                    if (!pairOut && A.channels != 1) {
                         // any other channel count: strided 4-byte stores straight from the stage (rare shapes)
 #pragma unroll
                         for (int k = 0; k < kPipeUnits; k++) {
                             if (!live[k]) continue;
-                            float *dst = A.out + (sU[k] * nfr * N + (f - 1) * N) * A.channels + cU[k];
+                            float *o = A.out + (sU[k] * nfr * N + (f - 1) * N) * A.channels + cU[k];
+                            const int lg = opaque(lane);       // (no per-lane 64-bit induction variables kept over the frame loop)
 #pragma unroll 2
-                            for (int j = lane; j < N; j += kWave) dst[(long)j * A.channels] = dstg[k][j];
+                            for (int j = lg; j < N; j += kWave) o[(long)j * A.channels] = dstg[k][j];
                         }
+                        NYQ_POST_SYNC();
                     }
-                    NYQ_POST_SYNC();
                 }
-                NYQ_STAMP(1);                                  // slot 1: de-emphasis + pick-up
-                if (f + 1 < nfr) land(f + 1, nb);
-                NYQ_STAMP(2);                                  // slot 2: prefetched frame -> LDS (waits for its loads)
-                if (f >= 1) {
-                    const long t0 = (f - 1) * N;               // first sample of the frame
-                    if (pairOut) {
-                        vf4 *d4 = reinterpret_cast<vf4 *>(A.out + (sU[0] * nfr * N + t0) * 2);
+                __builtin_amdgcn_sched_barrier(0);
+                NYQ_STAMP(1);                                  // slot 1: de-emphasis
 #pragma unroll
-                        for (int q = 0; q < 2 * NLD; q++) {
-                            const int v = lane + q * kWave;
-                            if (v < 2 * NV) d4[v] = sv[q];
+                for (int h = 0; h < HALVES; h++) {
+                    __builtin_amdgcn_sched_barrier(0);         // (phases stay apart: their registers are not live together)
+                    vf4 sv[2 * QH];
+                    const int lh = opaque(lane);
+                    if (f >= 1) {
+                        if (pairOut) {
+                            // float4 v = {L[2v], R[2v], L[2v+1], R[2v+1]}: columns 2 QH h .. of the interleaved frame read
+                            // floats [256 QH h, 256 QH (h+1)) of both stages -- what land(.., QH h, QH (h+1)) overwrites
+#pragma unroll
+                            for (int q = 0; q < 2 * QH; q++) {
+                                const int v = lh + (2 * QH * h + q) * kWave, vv = v < 2 * NV ? v : 0;
+                                const float2 l = *reinterpret_cast<const float2 *>(dstg[0] + 2 * vv);
+                                const float2 r = *reinterpret_cast<const float2 *>(dstg[1] + 2 * vv);
+                                sv[q] = vf4{l.x, r.x, l.y, r.y};
+                            }
+                        } else if (A.channels == 1) {
+#pragma unroll
+                            for (int k = 0; k < kPipeUnits; k++)
+#pragma unroll
+                                for (int q = 0; q < QH; q++) {
+                                    const int v = lh + (QH * h + q) * kWave;
+                                    sv[k * QH + q] = *reinterpret_cast<const vf4 *>(dstg[k] + 4 * (v < NV ? v : 0));
+                                }
                         }
-                    } else if (A.channels == 1) {
+                        NYQ_POST_SYNC();
+                    }
+                    if (f + 1 < nfr) land(f + 1, nb, QH * h, QH * (h + 1));   // (waits for the prefetched loads)
+                    if (f >= 1) {
+                        const long t0 = (f - 1) * N;           // first sample of the frame
+                        if (pairOut) {
+                            vf4 *d4 = reinterpret_cast<vf4 *>(A.out + (sU[0] * nfr * N + t0) * 2);
 #pragma unroll
-                        for (int k = 0; k < kPipeUnits; k++) {
-                            if (!live[k]) continue;
-                            vf4 *d4 = reinterpret_cast<vf4 *>(A.out + sU[k] * nfr * N + t0);
+                            for (int q = 0; q < 2 * QH; q++) {
+                                const int v = lh + (2 * QH * h + q) * kWave;
+                                if (v < 2 * NV) d4[v] = sv[q];
+                            }
+                        } else if (A.channels == 1) {
 #pragma unroll
-                            for (int q = 0; q < NLD; q++) {
-                                const int v = lane + q * kWave;
-                                if (v < NV) d4[v] = sv[k * NLD + q];
+                            for (int k = 0; k < kPipeUnits; k++) {
+                                if (!live[k]) continue;
+                                vf4 *d4 = reinterpret_cast<vf4 *>(A.out + sU[k] * nfr * N + t0);
+#pragma unroll
+                                for (int q = 0; q < QH; q++) {
+                                    const int v = lh + (QH * h + q) * kWave;
+                                    if (v < NV) d4[v] = sv[k * QH + q];
+                                }
                             }
                         }
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                NYQ_STAMP(2);                                  // slot 2: pick-up, frame f+1 -> LDS, stores of frame f-1
                 if (f + 2 < nfr) fetch(f + 2);
-                NYQ_STAMP(3);                                  // slot 3: global stores of frame f-1, fetch of frame f+2
+                NYQ_STAMP(3);                                  // slot 3: fetch of frame f+2
                 if (f == nfr) {
                     // state for the next call: cur = [history in front of the next frame | ...]
 #pragma unroll
                     for (int k = 0; k < kPipeUnits; k++) {
                         if (!live[k]) continue;
-                        if (A.hist)
+                        // the last 1088 outputs: 1040 are cur's history region, the 48 before them sit in the other
+                        // buffer's history region (what preceded the last frame), N - 48 samples in; no frames: unchanged
+                        if (A.hist && nfr > 0)
 #pragma unroll 1
-                            for (int j = lane; j < kPostHist; j += kWave) A.hist[(u0 + k) * kPostHist + j] = bufs[k][cb][j];
+                            for (int j = lane; j < kPostHist; j += kWave)
+                                A.hist[(u0 + k) * kPostHist + j] = j < OLD ? bufs[k][nb][N - OLD + j] : bufs[k][cb][j - OLD];
                         if (A.deemph && lane == 0) A.deemph[u0 + k] = mem[k];
                     }
                 }
@@ -712,6 +793,7 @@ __global__ __launch_bounds__(kWave *kPipeWaves, 3) void celt_post_pipe_kernel(Po
         }
     }
 #endif
+    NYQ_WG_TRACE(3);
 }
 
 }  // namespace nyq

@@ -110,15 +110,46 @@ int main(int argc, char **argv) {
     {
         unsigned long long z[16] = {0};
         CK(hipMemcpyToSymbol(HIP_SYMBOL(g_pipe_stamps), z, sizeof z));
-        v.back().run();
+        v[2].run();
         CK(hipDeviceSynchronize());
         CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_pipe_stamps), sizeof z));
         const double nwg = (double)((ns * ch + 1) / 2), per = nwg * nf;   // per workgroup-frame (comb: wave 0 only)
         printf("cycles per frame (s_memtime ticks, mean over workgroups), case %s\n", cs);
         printf("  comb wave : set-up %.0f  first-120 %.0f  cross-fade %.0f  constant part %.0f  barrier wait %.0f\n", z[2] / per, z[3] / per,
                z[4] / per, z[0] / per, z[1] / per);
-        printf("  I/O  wave : keep-copy %.0f  de-emphasis %.0f  store %.0f  land+fetch %.0f  tail %.0f  barrier wait %.0f\n",
+        printf("  I/O  wave : keep-copy %.0f  de-emphasis %.0f  pick-up + land + store %.0f  fetch %.0f  tail %.0f  barrier wait %.0f\n",
                z[8] / per, z[9] / per, z[10] / per, z[11] / per, z[12] / per, z[13] / per);
+        // placement trace: where and when every workgroup of the pipeline kernel ran, alone and behind the memset node
+        auto placement = [&](const char *what, std::function<void()> run) {
+            static unsigned long long wg[4096][4];
+            CK(hipDeviceSynchronize());
+            run();
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpyFromSymbol(wg, HIP_SYMBOL(g_pipe_wg), sizeof wg));
+            const int n = (int)std::min<long>(4096, (ns * ch + 1) / 2);
+            std::vector<int> percu(8 * 64, 0);
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (int i = 0; i < n; i++) t0 = std::min(t0, wg[i][2]), t1 = std::max(t1, wg[i][3]);
+            std::vector<double> st, du;
+            for (int i = 0; i < n; i++) {
+                const unsigned hw = (unsigned)wg[i][0], xcc = (unsigned)wg[i][1] & 15;
+                const unsigned cu = (hw >> 8) & 15, sh = (hw >> 12) & 1, se = (hw >> 13) & 3;
+                percu[xcc * 64 + se * 16 + sh * 8 * 0 + cu + sh * 0] += 1;   // (sh is always 0 on this part)
+                st.push_back((wg[i][2] - t0) * 0.01);
+                du.push_back((wg[i][3] - wg[i][2]) * 0.01);
+            }
+            int hist[16] = {0}, used = 0;
+            for (int v : percu) { if (v) used++; hist[std::min(v, 15)]++; }
+            std::sort(st.begin(), st.end());
+            std::sort(du.begin(), du.end());
+            printf("placement, %s: %d workgroups on %d CUs; workgroups per CU:", what, n, used);
+            for (int k = 1; k < 16; k++) if (hist[k]) printf(" %d x%d", k, hist[k]);
+            printf("\n   start after first [us]: p50 %.1f p90 %.1f p99 %.1f max %.1f; lifetime [us]: min %.1f p50 %.1f max %.1f; span %.1f us\n",
+                   st[n / 2], st[n * 9 / 10], st[n * 99 / 100], st[n - 1], du[0], du[n / 2], du[n - 1], (t1 - t0) * 0.01);
+        };
+        placement("alone", v[2].run);
+        placement("behind a 128 MB memset node", v[3].run);
+        placement("alone again", v[2].run);
     }
 #endif
     for (int r = 0; r < rounds; r++)
