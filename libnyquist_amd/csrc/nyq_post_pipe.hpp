@@ -257,7 +257,13 @@ __device__ __forceinline__ void pipe_comb_call(float *ring, float *mir, int lane
     int tmin = 4 * kWave + 2;
     if (g0 != 0.f && T0 < tmin) tmin = T0;
     if (g1 != 0.f && T1 < tmin) tmin = T1;
-    if (T0 == T1 && g0 != 0.f && g1 != 0.f && T1 - 2 <= kWave) {
+    if (T0 == T1 && g0 == g1 && ts0 == ts1 && T1 - 2 <= kWave) {
+        // the same tap set on both sides -- a frame's first 120 samples from the second frame on (celt_decoder_clean.c:678-683
+        // makes old = current).  The reference still evaluates the cross-fade expression (celt.c:139-160), whose weights
+        // (1-f) g + f g add up to the constant filter's g: run as comb_filter_const, equal to it up to rounding (the
+        // parity tests hold the chain to 1e-5 against the oracle, which cross-fades) at half the arithmetic per step
+        pipe_run_dpp<MIR, false>(ring, mir, lane, r0, kOverlap, T1, gb, gb, win2);
+    } else if (T0 == T1 && g0 != 0.f && g1 != 0.f && T1 - 2 <= kWave) {
         // both tap sets on one short period (always the case for the first 120 samples of a frame once the filter
         // runs: celt_decoder_clean.c:678-683 makes old = current): recursion in registers
         pipe_run_dpp<MIR, true>(ring, mir, lane, r0, kOverlap, T1, ga, gb, win2);
@@ -377,6 +383,19 @@ struct DeConst {
     float pwEnd;      // q^NL
 };
 
+// c^j, j = 0 .. 15 (c = the de-emphasis coefficient), as compile-time constants
+struct DeemphPow {
+    float p[16];
+    constexpr DeemphPow() : p{} {
+        float v = 1.f;
+        for (int j = 0; j < 16; j++) {
+            p[j] = v;
+            v *= kPreemph;
+        }
+    }
+};
+constexpr DeemphPow kDeemphPow{};
+
 template <int N>
 __device__ __forceinline__ void deemph_init(DeConst &D, int lane) {
     constexpr int CH = DeGeo<N>::CH, NL = DeGeo<N>::NL;
@@ -424,18 +443,29 @@ __device__ __forceinline__ void deemph_frames(const float *const (&src)[K], floa
             for (int j = 0; j < CH; j++) loc[k][j] = src[k][li * CH + j];
         }
     }
+    // lane-local recurrence with a zero carry-in, run as TWO independent half chains (samples [0, H) and [H, CH)) that are
+    // joined afterwards (hi[j] += c^(j-H+1) lo[H-1]): the dependent chain of the I/O wave is half as long
+    constexpr int H = CH / 2;
     float e[K];
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        float acc = 0.f;
+        float lo = 0.f, hi = 0.f;
         if (on[k]) {
 #pragma unroll
-            for (int j = 0; j < CH; j++) {
-                acc = (loc[k][j] + 1e-30f) + kPreemph * acc;  // + VERY_SMALL
-                loc[k][j] = acc;
+            for (int j = 0; j < CH - H; j++) {
+                if (j < H) {
+                    lo = (loc[k][j] + 1e-30f) + kPreemph * lo;    // + VERY_SMALL
+                    loc[k][j] = lo;
+                }
+                hi = (loc[k][H + j] + 1e-30f) + kPreemph * hi;
+                loc[k][H + j] = hi;
+            }
+            if (H > 0) {
+#pragma unroll
+                for (int j = H; j < CH; j++) loc[k][j] += kDeemphPow.p[j - H + 1] * lo;
             }
         }
-        e[k] = lane < NL ? acc : 0.f;                          // e[l] -> sum_{i<=l} q^(l-i) acc[i]
+        e[k] = lane < NL ? loc[k][CH - 1] : 0.f;               // e[l] -> sum_{i<=l} q^(l-i) acc[i]
     }
 #pragma unroll
     for (int k = 0; k < K; k++) {
@@ -451,12 +481,9 @@ __device__ __forceinline__ void deemph_frames(const float *const (&src)[K], floa
         if (!on[k]) continue;
         // value entering lane l's chunk: c t[l CH - 1] = c e[l-1] + q^l mem, with mem = c t[-1]
         const float prevEnd = dpp_shr1(0.f, e[k]);
-        float cp = kPreemph * prevEnd + D.pw * mem[k];         // (lane 0: prevEnd = 0, pw = 1)
+        const float cp = kPreemph * prevEnd + D.pw * mem[k];   // (lane 0: prevEnd = 0, pw = 1)
 #pragma unroll
-        for (int j = 0; j < CH; j++) {
-            loc[k][j] = (loc[k][j] + cp) * (1.f / 32768.f);
-            cp *= kPreemph;
-        }
+        for (int j = 0; j < CH; j++) loc[k][j] = (loc[k][j] + cp * kDeemphPow.p[j]) * (1.f / 32768.f);   // (independent of each other)
         if (lane < NL) {
             if constexpr (CH % 4 == 0) {
 #pragma unroll
