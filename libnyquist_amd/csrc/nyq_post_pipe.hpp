@@ -146,10 +146,12 @@ __device__ __forceinline__ float dpp_quad_bcast(float v) {   // every lane of a 
 // miss are the LAST four outputs of the step before that -- read from LDS one step ahead, so that no LDS round trip
 // is left on the dependency chain (the LDS form costs write -> read -> wait per step).  Outputs still go to ring[]
 // and mir[] (later frames, the wide forms and the de-emphasis read them there).
-//   XF = false: comb_filter_const (celt.c:87-110), gains ga[0..2]
-//   XF = true : the cross-fade loop of comb_filter (celt.c:139-160) when BOTH tap sets have this period: window
-//               weights from win2[wofs + i], set 0 gains ga, set 1 gains gb (same order of operations as the LDS form)
-template <bool MIR, bool XF>
+//   XF = 0: comb_filter_const (celt.c:87-110), gains ga[0..2]
+//   XF = 1: the cross-fade loop of comb_filter (celt.c:139-160) when BOTH tap sets have this period: window
+//           weights from win2[i], set 0 gains ga, set 1 gains gb (same order of operations as the LDS form)
+//   XF = 2: the cross-fade loop when set 0 is switched off (gain 0: the filter fades IN on set 1's period T)
+//   XF = 3: the cross-fade loop when set 1 is switched off (the filter fades OUT on set 0's period T)
+template <bool MIR, int XF>
 __device__ __forceinline__ void pipe_run_dpp(float *ring, float *mir, int lane, int i0, int n, int T, const float (&ga)[3],
                                              const float (&gb)[3], const float *win2) {
     const int w = T - 2;
@@ -168,25 +170,33 @@ __device__ __forceinline__ void pipe_run_dpp(float *ring, float *mir, int lane, 
         if (XF) { fa = wp[0]; fb = wp[w]; }
     }
     float Ra = rc[-w - 4], Rb = rc[-4];
+    // the taps of one output (Y = the previous step's outputs, S1..S4 = its one- to four-lane shifts), by mode -- the
+    // one-sided modes are the cross-fade with the switched-off side's zero terms left out (adding them changes nothing)
+    auto taps = [&](float &y, float f, float S1, float S2, float S3, float S4) {
+        if (XF == 1 || XF == 3) {
+            const float nf = 1.0f - f;
+            y += (nf * ga[0]) * S2;
+            y += (nf * ga[1]) * (S1 + S3);
+            y += (nf * ga[2]) * (Y + S4);
+        }
+        if (XF == 1 || XF == 2) {
+            y += (f * gb[0]) * S2;
+            y += (f * gb[1]) * (S1 + S3);
+            y += (f * gb[2]) * (Y + S4);
+        }
+        if (XF == 0) {
+            y += ga[0] * S2;
+            y += ga[1] * (S1 + S3);
+            y += ga[2] * (Y + S4);
+        }
+    };
     // one step at offset `o` floats from rc (o = 0 or w), operands (x, f, R); returns with Y = its outputs
     auto step = [&](int o, float x, float f, float R) {
         // (the quad broadcast needs lanes 0..3 active; whole steps have >= 13 lanes, the remainder spreads beforehand)
         const float S1 = dpp_shr1(dpp_quad_bcast<3>(R), Y), S2 = dpp_shr1(dpp_quad_bcast<2>(R), S1),
                     S3 = dpp_shr1(dpp_quad_bcast<1>(R), S2), S4 = dpp_shr1(dpp_quad_bcast<0>(R), S3);
         float y = x;
-        if (XF) {
-            const float nf = 1.0f - f;
-            y += (nf * ga[0]) * S2;
-            y += (nf * ga[1]) * (S1 + S3);
-            y += (nf * ga[2]) * (Y + S4);
-            y += (f * gb[0]) * S2;
-            y += (f * gb[1]) * (S1 + S3);
-            y += (f * gb[2]) * (Y + S4);
-        } else {
-            y += ga[0] * S2;
-            y += ga[1] * (S1 + S3);
-            y += ga[2] * (Y + S4);
-        }
+        taps(y, f, S1, S2, S3, S4);
         rc[o] = y;
         if (MIR) mc[o] = y;
         Y = y;
@@ -206,6 +216,8 @@ __device__ __forceinline__ void pipe_run_dpp(float *ring, float *mir, int lane, 
             NYQ_POST_SYNC();
             rc += 2 * w; mc += 2 * w; wp += 2 * w;
         }
+        // (tried: peeling the first pair so that the s_waitcnt at the loop top is exact, plus scheduling barriers between the
+        // two steps -- precise waits, 2 % slower: the scheduler's interleaving of the two steps' DPP chains is worth more)
         if (done < nfull) {                                    // odd count: one more whole step, then b is the next set
             step(0, xa, fa, Ra);
             NYQ_POST_SYNC();
@@ -218,19 +230,7 @@ __device__ __forceinline__ void pipe_run_dpp(float *ring, float *mir, int lane, 
     if (lane < rem) {
         const float S1 = dpp_shr1(Q1, Y), S2 = dpp_shr1(Q2, S1), S3 = dpp_shr1(Q3, S2), S4 = dpp_shr1(Q4, S3);
         float y = xa;
-        if (XF) {
-            const float nf = 1.0f - fa;
-            y += (nf * ga[0]) * S2;
-            y += (nf * ga[1]) * (S1 + S3);
-            y += (nf * ga[2]) * (Y + S4);
-            y += (fa * gb[0]) * S2;
-            y += (fa * gb[1]) * (S1 + S3);
-            y += (fa * gb[2]) * (Y + S4);
-        } else {
-            y += ga[0] * S2;
-            y += ga[1] * (S1 + S3);
-            y += ga[2] * (Y + S4);
-        }
+        taps(y, fa, S1, S2, S3, S4);
         rc[0] = y;
         if (MIR) mc[0] = y;
     }
@@ -262,11 +262,24 @@ __device__ __forceinline__ void pipe_comb_call(float *ring, float *mir, int lane
         // makes old = current).  The reference still evaluates the cross-fade expression (celt.c:139-160), whose weights
         // (1-f) g + f g add up to the constant filter's g: run as comb_filter_const, equal to it up to rounding (the
         // parity tests hold the chain to 1e-5 against the oracle, which cross-fades) at half the arithmetic per step
-        pipe_run_dpp<MIR, false>(ring, mir, lane, r0, kOverlap, T1, gb, gb, win2);
+        pipe_run_dpp<MIR, 0>(ring, mir, lane, r0, kOverlap, T1, gb, gb, win2);
+    } else if (T0 == T1 && g0 == g1 && ts0 == ts1) {
+        // the same, long period: four adjacent outputs per lane (one step covers the 120 samples from period 122 on)
+        const int w1 = (T1 - 2 < 4 * kWave ? T1 - 2 : 4 * kWave) & ~3;
+        switch ((r0 - T1 - 2) & 3) {
+            case 0: pipe_const_wide<MIR, 0>(ring, mir, lane, r0, kOverlap, T1, g10, g11, g12, w1); break;
+            case 1: pipe_const_wide<MIR, 1>(ring, mir, lane, r0, kOverlap, T1, g10, g11, g12, w1); break;
+            case 2: pipe_const_wide<MIR, 2>(ring, mir, lane, r0, kOverlap, T1, g10, g11, g12, w1); break;
+            default: pipe_const_wide<MIR, 3>(ring, mir, lane, r0, kOverlap, T1, g10, g11, g12, w1); break;
+        }
     } else if (T0 == T1 && g0 != 0.f && g1 != 0.f && T1 - 2 <= kWave) {
         // both tap sets on one short period (always the case for the first 120 samples of a frame once the filter
         // runs: celt_decoder_clean.c:678-683 makes old = current): recursion in registers
-        pipe_run_dpp<MIR, true>(ring, mir, lane, r0, kOverlap, T1, ga, gb, win2);
+        pipe_run_dpp<MIR, 1>(ring, mir, lane, r0, kOverlap, T1, ga, gb, win2);
+    } else if (g0 == 0.f && T1 - 2 <= kWave) {
+        pipe_run_dpp<MIR, 2>(ring, mir, lane, r0, kOverlap, T1, ga, gb, win2);   // fading in: only set 1 has taps
+    } else if (g1 == 0.f && T0 - 2 <= kWave) {
+        pipe_run_dpp<MIR, 3>(ring, mir, lane, r0, kOverlap, T0, ga, gb, win2);   // fading out: only set 0 has taps
     } else if (tmin - 2 <= kWave) {
         // short periods: one output per lane
         const int w = tmin - 2;
@@ -351,7 +364,7 @@ __device__ __forceinline__ void pipe_comb_call(float *ring, float *mir, int lane
     }
     if (T1 - 2 <= kWave) {
         // short periods (the common case in real streams): one output per lane, recursion in registers
-        pipe_run_dpp<MIR, false>(ring, mir, lane, i0, nc, T1, gb, gb, win2);
+        pipe_run_dpp<MIR, 0>(ring, mir, lane, i0, nc, T1, gb, gb, win2);
         return;
     }
     const int w1 = (T1 - 2 < 4 * kWave ? T1 - 2 : 4 * kWave) & ~3;
