@@ -415,6 +415,11 @@ static int launch_post(nyq_ctx *ctx, const PostArgs &A) {
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, celt_post_kernel<LM, kPostWavesPerBlock, NC>,
                                                                     kWave * kPostWavesPerBlock, 0);
         if (e != hipSuccess || per_cu < 1) per_cu = 1;
+        // one workgroup per CU fewer than what fits on paper, four at most (the design point: 8 chains per CU).  A
+        // workgroup lives for the whole launch, and "exactly what fits" only fits when the CU's LDS and register
+        // allocators start from zero -- see kPipeHist in nyq_post_pipe.hpp; 1280 stereo streams at five per CU: 1.75 ms,
+        // two rounds for some CUs, where 1024 take 1.0
+        per_cu = per_cu > 4 ? 4 : per_cu > 1 ? per_cu - 1 : 1;
         res = per_cu * ctx->cus;
     }
     const size_t need = (nunits + kPostWavesPerBlock - 1) / kPostWavesPerBlock;
@@ -435,6 +440,11 @@ static int launch_post_pipe(nyq_ctx *ctx, const PostArgs &A) {
         int per_cu = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, celt_post_pipe_kernel<LM>, kWave * kPipeWaves, 0);
         if (e != hipSuccess || per_cu < 1) per_cu = 1;
+        // one workgroup per CU fewer than what fits on paper, four at most (the design point: 8 chains per CU).  A
+        // workgroup lives for the whole launch, and "exactly what fits" only fits when the CU's LDS and register
+        // allocators start from zero -- see kPipeHist in nyq_post_pipe.hpp; 1280 stereo streams at five per CU: 1.75 ms,
+        // two rounds for some CUs, where 1024 take 1.0
+        per_cu = per_cu > 4 ? 4 : per_cu > 1 ? per_cu - 1 : 1;
         res = per_cu * ctx->cus;
     }
     const unsigned grid = (unsigned)(npairs < (size_t)res ? npairs : (size_t)res);
