@@ -85,20 +85,30 @@ def test_fused_chain_vs_oracle_and_two_kernel_chain(ctx, oracle, ns, nf, ptr):
     assert rel_rms(gov, gov2) <= 1e-6 and rel_rms(gh, gh2) <= 1e-6
 
 
-def test_fused_chain_continues_from_its_own_state(ctx, oracle):
-    """Two calls with the state of the first handed to the second == one call over both halves."""
+@pytest.mark.parametrize("fused,lm,h", [(True, 3, 11), (False, 3, 11), (False, 3, 1), (False, 2, 7), (False, 1, 5), (False, 0, 3)])
+def test_chain_continues_from_its_own_state(ctx, oracle, fused, lm, h):
+    """Two calls with the state of the first handed to the second == one call over both halves -- the fused kernel and the
+    shipped two-kernel chain (whose post-filter keeps 1040 samples of history in LDS and assembles the 1088 of the
+    hand-over from both of its buffers), every frame size, a first call as short as one frame."""
     ctx.set_tables(*oracle.tables()[:2])
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + lm)
     ns, nf = 6, 24
-    freq, tr, pitch, gain, taps, pst, ov, hist, dm = _case(rng, ns, nf, 0.1)
-    whole = _run_chain(ctx, 3, freq, tr, pitch, gain, taps, pst, ov, hist, dm, 2, fused=True)
-    h = 11
-    a = _run_chain(ctx, 3, freq[:, :h], tr[:, :h], pitch[:, :h], gain[:, :h], taps[:, :h], pst, ov, hist, dm, 2, fused=True)
-    b = _run_chain(ctx, 3, freq[:, h:], tr[:, h:], pitch[:, h:], gain[:, h:], taps[:, h:], a[1], a[2], a[3], a[4], 2, fused=True)
+    freq, tr, pitch, gain, taps, pst, ov, hist, dm = _case(rng, ns, nf, 0.1, lm=lm)
+    whole = _run_chain(ctx, lm, freq, tr, pitch, gain, taps, pst, ov, hist, dm, 2, fused=fused)
+    a = _run_chain(ctx, lm, freq[:, :h], tr[:, :h], pitch[:, :h], gain[:, :h], taps[:, :h], pst, ov, hist, dm, 2, fused=fused)
+    b = _run_chain(ctx, lm, freq[:, h:], tr[:, h:], pitch[:, h:], gain[:, h:], taps[:, h:], a[1], a[2], a[3], a[4], 2, fused=fused)
     got = np.concatenate([a[0], b[0]], axis=1)
-    assert np.array_equal(got, whole[0])
-    for x, y in zip(b[1:], whole[1:]):
-        assert np.array_equal(x, y)
+    if fused or h % 16 == 0:
+        assert np.array_equal(got, whole[0])
+        for x, y in zip(b[1:], whole[1:]):
+            assert np.array_equal(x, y)
+    else:
+        # the synthesis stage chains heads in-wave inside 16-frame chunks and fixes the others up afterwards: a cut that
+        # is not a multiple of the chunk length moves a few heads from one form to the other (same value, other rounding)
+        assert rel_rms(got, whole[0]) <= 1e-6
+        assert np.array_equal(b[1], whole[1])
+        for x, y in zip(b[2:], whole[2:]):
+            assert rel_rms(x, y) <= 1e-6
 
 
 def test_other_shapes_run_the_two_kernel_chain(ctx, oracle):
