@@ -140,100 +140,109 @@ __device__ __forceinline__ float dpp_quad_bcast(float v) {   // every lane of a 
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), Q * 0x55, 0xf, 0xf, true));
 }
 
-// A run of n outputs ring[i0, i0+n) of ONE period T with w = T-2 <= 64 outputs per step, the recursion kept in
-// REGISTERS: lane l of a step needs y[base_prev + l - 4 .. base_prev + l] = the previous step's outputs of lanes
-// l-4 .. l, i.e. four one-lane shifts of the register that holds them (v_mov_b32_dpp wave_shr:1); what lanes 0..3
-// miss are the LAST four outputs of the step before that -- read from LDS one step ahead, so that no LDS round trip
-// is left on the dependency chain (the LDS form costs write -> read -> wait per step).  Outputs still go to ring[]
-// and mir[] (later frames, the wide forms and the de-emphasis read them there).
+// A run of n outputs ring[i0, i0+n) of ONE period T with w = T-2 <= 60 outputs per step, the recursion kept in
+// REGISTERS.  What bounds the comb waves is the SIMD's VALU issue rate (one wave64 instruction per 4 cycles, shared by the
+// two comb waves and the I/O wave of a SIMD), so the step is built from as few VALU instructions as possible:
+//   * lane L >= 4 owns output L-4 of a step; lanes 0..3 of the register Y that holds the previous step's outputs carry the
+//     four outputs in FRONT of them.  The five taps y[n-T+2 .. n-T-2] of every owning lane are then Y and four plain
+//     one-lane shifts of it (v_mov_b32_dpp wave_shr:1, lane 0 <- 0): no lane has to be fed from elsewhere.
+//   * the four carry lanes of the NEXT step are the last four outputs of the previous one, final since its write: one
+//     ds_read_b32 issued right behind that write (lanes 0..3 read ring[base-4 ..]; the same address expression as the
+//     raw-sample read of that step, which the other lanes issued a step earlier) and ONE DPP move (row 0, bank 0) that
+//     drops them into lanes 0..3 at the end of the step.  Lanes 0..3 run the arithmetic with zero gains and store what they
+//     hold: they rewrite four outputs with their own values (also where the I/O wave copies or reads the same words
+//     meanwhile: same values), so no lane mask changes inside the loop.
+//   * raw samples and window weights are read two steps ahead into alternating register sets.
+// 11 VALU instructions per constant-filter step (the first register form: 22); outputs still go to ring[] and mir[].
 //   XF = 0: comb_filter_const (celt.c:87-110), gains ga[0..2]
 //   XF = 1: the cross-fade loop of comb_filter (celt.c:139-160) when BOTH tap sets have this period: window
 //           weights from win2[i], set 0 gains ga, set 1 gains gb (same order of operations as the LDS form)
 //   XF = 2: the cross-fade loop when set 0 is switched off (gain 0: the filter fades IN on set 1's period T)
 //   XF = 3: the cross-fade loop when set 1 is switched off (the filter fades OUT on set 0's period T)
+constexpr int kDppMaxW = kWave - 4;
+
+__device__ __forceinline__ float dpp_shr1z(float v) {            // lane l >= 1 receives v[l-1], lane 0 receives 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_low4(float keep, float v) {  // lanes 0..3 receive v's, every other lane keeps `keep`
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep), __builtin_bit_cast(int, v), 0xE4, 0x1, 0x1, false));
+}
+
 template <bool MIR, int XF>
 __device__ __forceinline__ void pipe_run_dpp(float *ring, float *mir, int lane, int i0, int n, int T, const float (&ga)[3],
                                              const float (&gb)[3], const float *win2) {
     const int w = T - 2;
     const int nfull = n / w, rem = n - nfull * w;
-    float *rc = ring + (i0 + lane);
-    float *mc = mir + (i0 + lane);
-    const float *wp = win2 + lane;
-    // Operands of a step that do not depend on the recursion -- the raw sample x, the window weight f, and R (lanes
-    // 0..3: the four outputs in front of the previous step's, final since the step before) -- are read TWO steps
-    // ahead into two alternating register sets (a: even steps, b: odd steps), right behind the write they follow.
+    float *rc = ring + (i0 + lane - 4);
+    float *mc = mir + (i0 + lane - 4);
+    const float *wp = win2 + (lane - 4);
+    // per-lane gains: zero in the carry lanes
+    const float own = lane >= 4 ? 1.f : 0.f;
+    const float a0 = ga[0] * own, a1 = ga[1] * own, a2 = ga[2] * own, b0 = gb[0] * own, b1 = gb[1] * own, b2 = gb[2] * own;
     float Y = 0.f, xa = 0.f, fa = 0.f, xb = 0.f, fb = 0.f;
-    if (lane < w) {
+    if (lane < w + 4) {
         Y = rc[-w];
-        xa = rc[0];
+        xa = rc[0];                                            // (lanes 0..3: the four outputs in front of the run)
         xb = rc[w];
         if (XF) { fa = wp[0]; fb = wp[w]; }
     }
-    float Ra = rc[-w - 4], Rb = rc[-4];
-    // the taps of one output (Y = the previous step's outputs, S1..S4 = its one- to four-lane shifts), by mode -- the
-    // one-sided modes are the cross-fade with the switched-off side's zero terms left out (adding them changes nothing)
+    float Ra = xa, Rb = 0.f;
     auto taps = [&](float &y, float f, float S1, float S2, float S3, float S4) {
         if (XF == 1 || XF == 3) {
             const float nf = 1.0f - f;
-            y += (nf * ga[0]) * S2;
-            y += (nf * ga[1]) * (S1 + S3);
-            y += (nf * ga[2]) * (Y + S4);
+            y += (nf * a0) * S2;
+            y += (nf * a1) * (S1 + S3);
+            y += (nf * a2) * (Y + S4);
         }
         if (XF == 1 || XF == 2) {
-            y += (f * gb[0]) * S2;
-            y += (f * gb[1]) * (S1 + S3);
-            y += (f * gb[2]) * (Y + S4);
+            y += (f * b0) * S2;
+            y += (f * b1) * (S1 + S3);
+            y += (f * b2) * (Y + S4);
         }
         if (XF == 0) {
-            y += ga[0] * S2;
-            y += ga[1] * (S1 + S3);
-            y += ga[2] * (Y + S4);
+            y += a0 * S2;
+            y += a1 * (S1 + S3);
+            y += a2 * (Y + S4);
         }
     };
-    // one step at offset `o` floats from rc (o = 0 or w), operands (x, f, R); returns with Y = its outputs
-    auto step = [&](int o, float x, float f, float R) {
-        // (the quad broadcast needs lanes 0..3 active; whole steps have >= 13 lanes, the remainder spreads beforehand)
-        const float S1 = dpp_shr1(dpp_quad_bcast<3>(R), Y), S2 = dpp_shr1(dpp_quad_bcast<2>(R), S1),
-                    S3 = dpp_shr1(dpp_quad_bcast<1>(R), S2), S4 = dpp_shr1(dpp_quad_bcast<0>(R), S3);
+    // one step at offset `o` floats from rc (o = 0 or w): x = its raw samples, f = its window weights, R = (lanes 0..3) the
+    // last four outputs of the step before it; returns with Y = the next step's input register
+    auto step = [&](int o, float x, float f, float R, float &Rnext) {
+        const float S1 = dpp_shr1z(Y), S2 = dpp_shr1z(S1), S3 = dpp_shr1z(S2), S4 = dpp_shr1z(S3);
         float y = x;
         taps(y, f, S1, S2, S3, S4);
+        y = dpp_low4(y, R);
         rc[o] = y;
-        if (MIR) mc[o] = y;
-        Y = y;
+        Rnext = rc[o + w];                                     // lanes 0..3: the last four outputs just written (first in
+        if (MIR) mc[o] = y;                                    // the LDS queue behind that write: it is the next step's
+        Y = y;                                                 // only LDS dependency)
     };
     int done = 0;
-    if (lane < w) {
+    if (lane < w + 4) {
         for (; done + 2 <= nfull; done += 2) {
-            step(0, xa, fa, Ra);
+            step(0, xa, fa, Ra, Rb);
             xa = rc[2 * w];                                    // (reads up to two steps past the run: inside the LDS, unused)
             if (XF) fa = wp[2 * w];
-            Ra = rc[w - 4];
             NYQ_POST_SYNC();
-            step(w, xb, fb, Rb);
+            step(w, xb, fb, Rb, Ra);
             xb = rc[3 * w];
             if (XF) fb = wp[3 * w];
-            Rb = rc[2 * w - 4];
             NYQ_POST_SYNC();
             rc += 2 * w; mc += 2 * w; wp += 2 * w;
         }
-        // (tried: peeling the first pair so that the s_waitcnt at the loop top is exact, plus scheduling barriers between the
-        // two steps -- precise waits, 2 % slower: the scheduler's interleaving of the two steps' DPP chains is worth more)
+        // (tried on the first register form: peeling the first pair so that the s_waitcnt at the loop top is exact, plus
+        // scheduling barriers between the two steps -- precise waits, 2 % slower; and here: the carry lanes merged at the
+        // START of the next step with the stores under a lane mask instead of the rewrite -- a branch per step, 7 % slower)
         if (done < nfull) {                                    // odd count: one more whole step, then b is the next set
-            step(0, xa, fa, Ra);
+            step(0, xa, fa, Ra, Rb);
             NYQ_POST_SYNC();
             rc += w; mc += w; wp += w;
-            xa = xb; fa = fb; Ra = Rb;
+            xa = xb; fa = fb;
+            Ra = Rb;
         }
     }
-    // remainder (fewer than w outputs, maybe fewer than four lanes: the quad broadcast of R runs on the whole wave first)
-    const float Q1 = dpp_quad_bcast<3>(Ra), Q2 = dpp_quad_bcast<2>(Ra), Q3 = dpp_quad_bcast<1>(Ra), Q4 = dpp_quad_bcast<0>(Ra);
-    if (lane < rem) {
-        const float S1 = dpp_shr1(Q1, Y), S2 = dpp_shr1(Q2, S1), S3 = dpp_shr1(Q3, S2), S4 = dpp_shr1(Q4, S3);
-        float y = xa;
-        taps(y, fa, S1, S2, S3, S4);
-        rc[0] = y;
-        if (MIR) mc[0] = y;
-    }
+    // remainder: fewer than w outputs (the shifts only read lanes below the last owning one: all enabled)
+    if (rem > 0 && lane < rem + 4) step(0, xa, fa, Ra, Rb);
     NYQ_POST_SYNC();
 }
 
@@ -257,7 +266,7 @@ __device__ __forceinline__ void pipe_comb_call(float *ring, float *mir, int lane
     int tmin = 4 * kWave + 2;
     if (g0 != 0.f && T0 < tmin) tmin = T0;
     if (g1 != 0.f && T1 < tmin) tmin = T1;
-    if (T0 == T1 && g0 == g1 && ts0 == ts1 && T1 - 2 <= kWave) {
+    if (T0 == T1 && g0 == g1 && ts0 == ts1 && T1 - 2 <= kDppMaxW) {
         // the same tap set on both sides -- a frame's first 120 samples from the second frame on (celt_decoder_clean.c:678-683
         // makes old = current).  The reference still evaluates the cross-fade expression (celt.c:139-160), whose weights
         // (1-f) g + f g add up to the constant filter's g: run as comb_filter_const, equal to it up to rounding (the
@@ -272,13 +281,13 @@ __device__ __forceinline__ void pipe_comb_call(float *ring, float *mir, int lane
             case 2: pipe_const_wide<MIR, 2>(ring, mir, lane, r0, kOverlap, T1, g10, g11, g12, w1); break;
             default: pipe_const_wide<MIR, 3>(ring, mir, lane, r0, kOverlap, T1, g10, g11, g12, w1); break;
         }
-    } else if (T0 == T1 && g0 != 0.f && g1 != 0.f && T1 - 2 <= kWave) {
+    } else if (T0 == T1 && g0 != 0.f && g1 != 0.f && T1 - 2 <= kDppMaxW) {
         // both tap sets on one short period (always the case for the first 120 samples of a frame once the filter
         // runs: celt_decoder_clean.c:678-683 makes old = current): recursion in registers
         pipe_run_dpp<MIR, 1>(ring, mir, lane, r0, kOverlap, T1, ga, gb, win2);
-    } else if (g0 == 0.f && T1 - 2 <= kWave) {
+    } else if (g0 == 0.f && T1 - 2 <= kDppMaxW) {
         pipe_run_dpp<MIR, 2>(ring, mir, lane, r0, kOverlap, T1, ga, gb, win2);   // fading in: only set 1 has taps
-    } else if (g1 == 0.f && T0 - 2 <= kWave) {
+    } else if (g1 == 0.f && T0 - 2 <= kDppMaxW) {
         pipe_run_dpp<MIR, 3>(ring, mir, lane, r0, kOverlap, T0, ga, gb, win2);   // fading out: only set 0 has taps
     } else if (tmin - 2 <= kWave) {
         // short periods: one output per lane
@@ -362,7 +371,7 @@ __device__ __forceinline__ void pipe_comb_call(float *ring, float *mir, int lane
         pipe_copy<MIR>(ring, mir, lane, i0, nc);
         return;
     }
-    if (T1 - 2 <= kWave) {
+    if (T1 - 2 <= kDppMaxW) {
         // short periods (the common case in real streams): one output per lane, recursion in registers
         pipe_run_dpp<MIR, 0>(ring, mir, lane, i0, nc, T1, gb, gb, win2);
         return;
