@@ -74,6 +74,12 @@ __device__ __forceinline__ void fft_passes(int lane, cpx *lds) {
 }
 
 // One group through phases A..D.  `R` holds the group's input registers (already loaded).
+// the value, but not a loop invariant or a common subexpression to the optimiser
+__device__ __forceinline__ int relane(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 template <int N2R, typename Cfg, class Rows>
 __device__ __forceinline__ void run_group(const LaneConst<N2R> &K, int lane, cpx *lds, float *ring,
                                           const Rows &rows, StageRegs<N2R> &R) {
@@ -82,10 +88,21 @@ __device__ __forceinline__ void run_group(const LaneConst<N2R> &K, int lane, cpx
     NYQ_WAVE_SYNC();
     fft_passes<N2R>(lane, lds);
     HeadRegs<N2R> H;
-    stage_out<N2R, Cfg::NT_ST>(K, lane, lds, ring, rows, H);
-    if constexpr (Rows::CHAINS) {
+    if constexpr (Rows::CHAINS && N2R == 8) {
+        // Chained 240-sample frame rows: the two output phases derive their per-lane row indices, masks and 64-bit
+        // addresses from a FRESH copy of the lane id.  Otherwise they are computed once per group, shared between the
+        // phases and kept alive across the FFT passes: synth_long_kernel<8> needed 260 registers that way -- ONE wave per
+        // SIMD, four resident waves per CU instead of six -- against 111 of imdct_rows_kernel<8>; now 156.  (The other
+        // sizes stay below two waves' worth either way and lose 3-8 % to the recomputation: left as they are.)
+        stage_out<N2R, Cfg::NT_ST>(K, relane(lane), lds, ring, rows, H);
+        NYQ_WAVE_SYNC();
+        stage_out_heads<N2R, Cfg::NT_ST>(K, relane(lane), ring, rows, H);
+    } else if constexpr (Rows::CHAINS) {
+        stage_out<N2R, Cfg::NT_ST>(K, lane, lds, ring, rows, H);
         NYQ_WAVE_SYNC();
         stage_out_heads<N2R, Cfg::NT_ST>(K, lane, ring, rows, H);
+    } else {
+        stage_out<N2R, Cfg::NT_ST>(K, lane, lds, ring, rows, H);
     }
 }
 
