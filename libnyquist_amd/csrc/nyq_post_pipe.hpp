@@ -15,14 +15,16 @@
 //                 frame f+1 into an LDS slot, carry-over of the history that survives
 //   one s_barrier per frame.
 //
-// LDS per chain: two buffers A, B of 2048 floats = [1088 filtered history | frame].  The comb wave filters
+// LDS per chain: two buffers A, B of [1040 filtered history | frame] floats (kPipeHist).  The comb wave filters
 // frame f in place in `cur` and writes every output a second time into `nxt`'s history region
 // (nxt[idx - N]); meanwhile the I/O wave fills the rest of `nxt` (the older part of the history from
 // `cur`, the raw frame f+1) -- so the next frame starts right after the barrier, nothing is moved on the
 // chain's critical path, and every tap address is the output's address minus a wave-uniform constant.
 // The de-emphasis of frame f-1 reads cur's history region (final since the previous barrier) and stages
 // its interleaved output in nxt's frame region before the raw frame f+1 lands there.
-// 32 KB of LDS per workgroup: four workgroups (8 chains, 12 waves) per CU.
+// 32 544 B of LDS and at most 128 VGPRs per workgroup: four workgroups (8 chains, 12 waves) per CU, with a fifth
+// workgroup's LDS and a fourth wave's registers per SIMD to spare -- the workgroups live for the whole launch and must
+// all be placed at once (kPipeHist, and the kernel's launch bounds, say why).
 #pragma once
 #include "nyq_post_kernels.hpp"
 
@@ -135,14 +137,10 @@ __device__ __forceinline__ float dpp_zero(float v) {   // lanes without a source
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, ROWMASK == 0xf));
 }
 
-template <int Q>
-__device__ __forceinline__ float dpp_quad_bcast(float v) {   // every lane of a quad receives the quad's lane Q
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), Q * 0x55, 0xf, 0xf, true));
-}
-
 // A run of n outputs ring[i0, i0+n) of ONE period T with w = T-2 <= 60 outputs per step, the recursion kept in
-// REGISTERS.  What bounds the comb waves is the SIMD's VALU issue rate (one wave64 instruction per 4 cycles, shared by the
-// two comb waves and the I/O wave of a SIMD), so the step is built from as few VALU instructions as possible:
+// REGISTERS.  What bounds a step is the latency of its dependent chain (three DPP moves, a DPP add, an FMA, the carry move:
+// about 110 cycles with no LDS instruction in the loop, measured) plus the waits on its two LDS loads; the layout keeps
+// both the chain and the instruction count (11 VALU per constant-filter step) as short as the one-lane DPP shift allows:
 //   * lane L >= 4 owns output L-4 of a step; lanes 0..3 of the register Y that holds the previous step's outputs carry the
 //     four outputs in FRONT of them.  The five taps y[n-T+2 .. n-T-2] of every owning lane are then Y and four plain
 //     one-lane shifts of it (v_mov_b32_dpp wave_shr:1, lane 0 <- 0): no lane has to be fed from elsewhere.
@@ -724,7 +722,7 @@ __global__ __launch_bounds__(kWave *kPipeWaves, NYQ_PIPE_MINWAVES) void celt_pos
                 }
                 __builtin_amdgcn_sched_barrier(0);             // (or the copy's writes sink to the end of the iteration, registers held)
                 NYQ_STAMP(0);                                  // slot 0: history carry-over
-                // frame f-1 is final in cur[1088 - N, 1088): de-emphasis, staged in nxt's frame region, picked up again
+                // frame f-1 is final in cur[R0 - N, R0): de-emphasis, staged in nxt's frame region, picked up again
                 // in the output's interleaved order (registers) -- before the raw frame f+1 lands in that region
                 // The pick-up / land / store sequence runs in HALVES of the frame (long frames): the interleaved output of
                 // one half is picked up into registers, the raw frame f+1 lands over exactly that half of the stage, the
