@@ -656,7 +656,11 @@ __global__ __launch_bounds__(kWave *kPipeWaves, NYQ_PIPE_MINWAVES) void celt_pos
                 sU[k] = live[k] ? u / A.channels : 0;
                 cU[k] = (int)(u - sU[k] * A.channels);
                 src[k] = reinterpret_cast<const vf4 *>(A.pcm + (live[k] ? u : 0) * nfr * N);
-                mem[k] = (live[k] && A.deemph) ? A.deemph[u] : 0.f;
+                // (through an SGPR: the value is wave-uniform, and the s_waitcnt for this load then sits HERE -- kept as
+                // a loaded VGPR across the frame loop, every iteration's first use of it waited for vmcnt(0), i.e. for the
+                // frame prefetch issued just before and the stores in flight)
+                mem[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(
+                             __builtin_bit_cast(int, (live[k] && A.deemph) ? A.deemph[u] : 0.f)));
                 pT[k] = 0; pS[k] = 0; pG[k] = 0.f;
 #pragma unroll
                 for (int q = 0; q < NLD; q++) nx[k][q] = vf4{0, 0, 0, 0};

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the frames -> PCM chain (nyq_celt_chain_dev) fused vs as two kernels, same process, interleaved; HIP events on
-the operator's stream.  usage: chain_time.py [nstreams] [nframes] [mix|short|long|off]"""
+the operator's stream.  usage: chain_time.py [nstreams] [nframes] [mix|short|long|off|real]"""
 import json
 import os
 import sys
@@ -23,10 +23,22 @@ g.manual_seed(4)
 ch, n = 2, 960
 freq = torch.randn((ns, nf, ch, n), generator=g, device=dev) * 30.0
 trans = (torch.rand((ns, nf), generator=g, device=dev) < 0.028).to(torch.uint8)
-lo, hi, on = {"mix": (15, 80, 0.7), "short": (15, 60, 1.0), "long": (300, 1000, 1.0), "off": (15, 80, 0.0)}[case]
-pitch = torch.randint(lo, hi, (ns, nf), generator=g, device=dev, dtype=torch.int32)
-gain = (torch.rand((ns, nf), generator=g, device=dev) < on).float() * (torch.randint(1, 9, (ns, nf), generator=g, device=dev) * 0.09375).float()
-tap = torch.randint(0, 3, (ns, nf), generator=g, device=dev, dtype=torch.int32)
+if case == "real":
+    # every stream = a window of sb-reverie.opus's own parameter sequence (tests/golden/sb_reverie_pf_params.npz)
+    import numpy as np
+    z = np.load(os.path.join(ROOT, "tests", "golden", "sb_reverie_pf_params.npz"))
+    tot = len(z["pf_pitch"])
+    off = (np.arange(ns) * 977) % (tot - nf)
+    idx = off[:, None] + np.arange(nf)[None, :]
+    pitch = torch.from_numpy(z["pf_pitch"][idx].astype(np.int32)).to(dev)
+    gain = torch.from_numpy(z["pf_gain_q"][idx].astype(np.float32) * 0.09375).to(dev)
+    tap = torch.from_numpy(z["pf_tapset"][idx].astype(np.int32)).to(dev)
+    trans = torch.from_numpy(z["transient"][idx].astype(np.uint8)).to(dev)
+else:
+    lo, hi, on = {"mix": (15, 80, 0.7), "short": (15, 60, 1.0), "long": (300, 1000, 1.0), "off": (15, 80, 0.0)}[case]
+    pitch = torch.randint(lo, hi, (ns, nf), generator=g, device=dev, dtype=torch.int32)
+    gain = (torch.rand((ns, nf), generator=g, device=dev) < on).float() * (torch.randint(1, 9, (ns, nf), generator=g, device=dev) * 0.09375).float()
+    tap = torch.randint(0, 3, (ns, nf), generator=g, device=dev, dtype=torch.int32)
 out = torch.empty((ns, nf * n, ch), device=dev)
 pcm = torch.empty((ns * ch, nf * n), device=dev)
 work = torch.empty(ctx.celt_synth_work_floats(ns, nf, ch), device=dev)

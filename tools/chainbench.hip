@@ -63,6 +63,14 @@ int main(int argc, char **argv) {
             pt[i] = (int)(g() % 3u);
             pg[i] = ((g() % 1000000u) / 1e6 < on) ? (1 + (int)(g() % 8u)) * 0.09375f : 0.f;
         }
+        if (!strncmp(cs, "file:", 5)) {
+            // parameters from a file: ns*nf int32 periods, ns*nf float gains, ns*nf int32 tapsets (tools/chain_time.py's
+            // 'real' case dumped with numpy: python tools/dump_real_params.py)
+            FILE *fp = fopen(cs + 5, "rb");
+            if (!fp || fread(pp.data(), 4, ns * nf, fp) != (size_t)(ns * nf) || fread(pg.data(), 4, ns * nf, fp) != (size_t)(ns * nf) ||
+                fread(pt.data(), 4, ns * nf, fp) != (size_t)(ns * nf)) { printf("cannot read %s\n", cs + 5); return 1; }
+            fclose(fp);
+        }
         CK(hipMemcpy(d_pitch, pp.data(), ns * nf * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(d_tap, pt.data(), ns * nf * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(d_gain, pg.data(), ns * nf * 4, hipMemcpyHostToDevice));
