@@ -448,7 +448,11 @@ static int launch_post_pipe(nyq_ctx *ctx, const PostArgs &A) {
         res = per_cu * ctx->cus;
     }
     const unsigned grid = (unsigned)(npairs < (size_t)res ? npairs : (size_t)res);
-    hipLaunchKernelGGL((celt_post_pipe_kernel<LM>), dim3(grid), dim3(kWave * kPipeWaves), 0, ctx->stream, A, ctx->d_window);
+    // (the occupancy figure above is that of the generic instance: the stereo one needs no more registers or LDS)
+    if (A.channels == 2)
+        hipLaunchKernelGGL((celt_post_pipe_kernel<LM, true>), dim3(grid), dim3(kWave * kPipeWaves), 0, ctx->stream, A, ctx->d_window);
+    else
+        hipLaunchKernelGGL((celt_post_pipe_kernel<LM, false>), dim3(grid), dim3(kWave * kPipeWaves), 0, ctx->stream, A, ctx->d_window);
     NYQ_HIP(ctx, hipGetLastError());
     return NYQ_OK;
 }

@@ -538,7 +538,9 @@ struct PipeParams {
 #define NYQ_PIPE_MINWAVES 4
 #endif
 #pragma clang diagnostic ignored "-Wpass-failed"   // ("occupancy target 4, final occupancy 3": the LDS bound, intended -- see above)
-template <int LM>
+// PAIR: stereo streams (channels == 2, so both units of every workgroup exist and are the channels of one stream): the
+// I/O wave's frame loop then carries none of the per-iteration tests for missing units and other channel counts
+template <int LM, bool PAIR = false>
 #ifdef NYQ_PIPE_NUM_VGPR
 __attribute__((amdgpu_num_vgpr(NYQ_PIPE_NUM_VGPR)))
 #endif
@@ -637,7 +639,7 @@ __global__ __launch_bounds__(kWave *kPipeWaves, NYQ_PIPE_MINWAVES) void celt_pos
         for (long pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
             const long u0 = pair * kPipeUnits;
             // ---------------- I/O wave for both units ----------------
-            const bool pairOut = A.channels == 2;              // both units are the channels of one stream: interleaved 16-byte stores
+            const bool pairOut = PAIR || A.channels == 2;      // both units are the channels of one stream: interleaved 16-byte stores
             bool live[kPipeUnits];
             long sU[kPipeUnits];
             int cU[kPipeUnits];
@@ -652,7 +654,7 @@ __global__ __launch_bounds__(kWave *kPipeWaves, NYQ_PIPE_MINWAVES) void celt_pos
 #pragma unroll
             for (int k = 0; k < kPipeUnits; k++) {
                 const long u = u0 + k;
-                live[k] = u < nunits;
+                live[k] = PAIR || u < nunits;
                 sU[k] = live[k] ? u / A.channels : 0;
                 cU[k] = (int)(u - sU[k] * A.channels);
                 src[k] = reinterpret_cast<const vf4 *>(A.pcm + (live[k] ? u : 0) * nfr * N);

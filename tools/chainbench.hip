@@ -96,10 +96,10 @@ int main(int argc, char **argv) {
     }
     {
         int occ = 0;
-        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, celt_post_pipe_kernel<3>, kWave * kPipeWaves, 0));
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, celt_post_pipe_kernel<3, true>, kWave * kPipeWaves, 0));
         const unsigned grid = (unsigned)std::min<long>((ns * ch + 1) / 2, (long)occ * cus);
         char nm[128]; snprintf(nm, sizeof nm, "r2 workgroup pipeline (occ %d blk/CU, grid %u)", occ, grid);
-        v.push_back({nm, [=] { hipLaunchKernelGGL((celt_post_pipe_kernel<3>), dim3(grid), dim3(kWave * kPipeWaves), 0, 0, A, d_win); }, {}});
+        v.push_back({nm, [=] { hipLaunchKernelGGL((celt_post_pipe_kernel<3, true>), dim3(grid), dim3(kWave * kPipeWaves), 0, 0, A, d_win); }, {}});
     }
     // experiment: the pipeline kernel behind a large memset node (a fill kernel of the runtime) on unrelated memory
     {
