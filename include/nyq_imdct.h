@@ -50,6 +50,9 @@ typedef struct nyq_ctx nyq_ctx; /* one per (device, host thread); not thread-saf
                                    reference's unsynchronised global state map, mdct_cuda.cu:558-559 */
 
 /* ---- context ----------------------------------------------------------- */
+/* number of HIP devices this process sees (0 if there is none or the runtime fails); valid device indices
+ * are 0 .. count-1.  (The reference's offload has no such call: it uses device 0 implicitly, mdct_cuda.cu:318.) */
+int  nyq_device_count(void);
 int  nyq_ctx_create(nyq_ctx **out, int device);
 void nyq_ctx_destroy(nyq_ctx *ctx);
 /* text of the last failure on ctx (ctx == NULL: last failure of ctx-less calls) */
@@ -68,6 +71,30 @@ int  nyq_ctx_set_tables(nyq_ctx *ctx, const float *trig481, const float *window1
 int  nyq_ctx_get_tables(nyq_ctx *ctx, float *trig481, float *window120);
 /* device properties the benchmark reports: compute units, waves resident per CU for `shift` */
 int  nyq_ctx_device_info(nyq_ctx *ctx, int *compute_units, char *name, size_t name_len);
+
+/* Per-context options (replace the process-environment switches of earlier builds: nothing in this library reads
+ * the environment at launch time).  Set between calls, from the thread that owns the context.
+ *   NYQ_OPT_BLOCKS_PER_CU   workgroups per compute unit of the persistent row kernels; 0 = the built-in choice
+ *                           (a profiling knob: the occupancy caches of the context are dropped when it changes)
+ *   NYQ_OPT_POST_FORM       kernel form of nyq_celt_post_dev: NYQ_POST_FORM_PIPELINE (default, the only form in the
+ *                           product build), NYQ_POST_FORM_WAVE_PER_CHANNEL, NYQ_POST_FORM_WAVE_PER_PAIR
+ *   NYQ_OPT_CHAIN_FUSED     nyq_celt_chain_dev: 1 = the one-launch kernel where nyq_celt_chain_fused_supported()
+ *   NYQ_OPT_CHAIN_WINDOW    nyq_celt_chain_dev: frames per time window of the two-kernel chain, rounded up to the frame
+ *                           size's chain length (16 / 32 / 32 / 64 frames for LM 3 / 2 / 1 / 0) so that the result is
+ *                           bit-identical to one window; 0 = the built-in choice
+ * The alternative forms (POST_FORM != pipeline, CHAIN_FUSED = 1) are measured-and-rejected designs kept for A/B
+ * runs: they exist only in the tools' build of this library (-DNYQ_AB_FORMS, tools/libnyq_imdct_ab.so);
+ * the product build answers NYQ_ERR_INVALID for them.  nyq_ab_forms_built() tells which build this is. */
+#define NYQ_OPT_BLOCKS_PER_CU 1
+#define NYQ_OPT_POST_FORM     2
+#define NYQ_OPT_CHAIN_FUSED   3
+#define NYQ_OPT_CHAIN_WINDOW  4
+#define NYQ_POST_FORM_PIPELINE         0
+#define NYQ_POST_FORM_WAVE_PER_CHANNEL 1
+#define NYQ_POST_FORM_WAVE_PER_PAIR    2
+int  nyq_ctx_set_option(nyq_ctx *ctx, int option, long value);
+int  nyq_ctx_get_option(nyq_ctx *ctx, int option, long *value);
+int  nyq_ab_forms_built(void);
 
 /* ---- device-resident batched operators (asynchronous on the context stream) ---- */
 /* All d_* pointers are device memory, 16-byte aligned, rows contiguous. No allocation,

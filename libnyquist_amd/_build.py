@@ -12,6 +12,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libnyq_imdct.so")
+LIB_AB = os.path.join(ROOT, "tools", "libnyq_imdct_ab.so")   # the same + the A/B kernel forms (-DNYQ_AB_FORMS): tools and tests only
 SOURCES = [os.path.join(CSRC, "nyq_imdct.hip")]
 DEPS = sorted(set(SOURCES + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.hip"))
                   + [os.path.join(ROOT, "include", "nyq_imdct.h")]))
@@ -24,10 +25,11 @@ def hipcc():
     raise RuntimeError("hipcc not found: libnyq_imdct.so cannot be built (no CPU fallback exists)")
 
 
-def stale():
-    if not os.path.exists(LIB):
+def stale(lib=None):
+    lib = lib or LIB
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
@@ -38,8 +40,21 @@ def build(force=False, verbose=False):
     # -fno-slp-vectorize: on gfx950 packed f32 VALU issues at half rate, so hipcc's SLP packing of
     # the butterflies buys nothing and costs ~480 v_mov plus 70 VGPRs (218 -> 148: 2 -> 3 waves/SIMD).
     cmd = [hipcc(), "-O3", "-fno-slp-vectorize", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
-           "-o", LIB] + SOURCES
+           "-Wl,-Bsymbolic-functions", "-o", LIB] + SOURCES
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
     return LIB
+
+
+def build_ab(force=False, verbose=False):
+    """Build tools/libnyq_imdct_ab.so: the product's sources with -DNYQ_AB_FORMS (round-1 post-filter kernels and the
+    fused chain kernel compiled in, selectable through nyq_ctx_set_option).  Not part of the product."""
+    if not force and not stale(LIB_AB):
+        return LIB_AB
+    cmd = [hipcc(), "-O3", "-fno-slp-vectorize", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-DNYQ_AB_FORMS",
+           "-Wl,-Bsymbolic-functions", "-o", LIB_AB] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_AB

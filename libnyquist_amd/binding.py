@@ -11,6 +11,10 @@ import numpy as np
 
 from . import _build
 
+# nyq_ctx_set_option (include/nyq_imdct.h)
+OPT_BLOCKS_PER_CU, OPT_POST_FORM, OPT_CHAIN_FUSED, OPT_CHAIN_WINDOW = 1, 2, 3, 4
+POST_FORM_PIPELINE, POST_FORM_WAVE_PER_CHANNEL, POST_FORM_WAVE_PER_PAIR = 0, 1, 2
+
 HALF_OV = 60
 OVERLAP = 120
 NYQ_OK = 0
@@ -18,6 +22,7 @@ ERRORS = {-1: "NYQ_ERR_INVALID", -2: "NYQ_ERR_NO_DEVICE", -3: "NYQ_ERR_HIP", -4:
 
 # every symbol include/nyq_imdct.h declares (tests check the .so exports all of them)
 EXPORTS = [
+    "nyq_device_count", "nyq_ctx_set_option", "nyq_ctx_get_option", "nyq_ab_forms_built",
     "nyq_ctx_create", "nyq_ctx_destroy", "nyq_last_error", "nyq_ctx_set_stream", "nyq_ctx_reset_stream", "nyq_ctx_get_stream",
     "nyq_ctx_synchronize", "nyq_ctx_set_tables", "nyq_ctx_get_tables", "nyq_ctx_device_info",
     "nyq_ifft_batch_dev", "nyq_imdct_batch_dev", "nyq_imdct_chain_dev",
@@ -61,6 +66,16 @@ class NyqError(RuntimeError):
 
 
 _lib = None
+_lib_ab = None
+
+
+def load_ab():
+    """The tools' build of the library (-DNYQ_AB_FORMS, tools/libnyq_imdct_ab.so): the product's kernels plus the
+    measured-and-rejected forms (round-1 post-filter kernels, fused chain) for A/B runs and their parity tests."""
+    global _lib_ab
+    if _lib_ab is None:
+        _lib_ab = load(_build.build_ab())
+    return _lib_ab
 
 
 def load(path=None):
@@ -88,6 +103,8 @@ def load(path=None):
     L = C.CDLL(p)
     vp, i, sz, fp = C.c_void_p, C.c_int, C.c_size_t, C.c_void_p
     L.nyq_ctx_create.argtypes = [C.POINTER(vp), i]
+    L.nyq_ctx_set_option.argtypes = [vp, i, C.c_long]
+    L.nyq_ctx_get_option.argtypes = [vp, i, C.POINTER(C.c_long)]
     L.nyq_ctx_destroy.argtypes = [vp]
     L.nyq_ctx_destroy.restype = None
     L.nyq_last_error.argtypes = [vp]
@@ -151,8 +168,9 @@ class Context:
     """nyq_ctx wrapper.  Host-buffer methods take/return numpy arrays; *_dev methods take
     raw device pointers (ints, e.g. torch.Tensor.data_ptr()) and are asynchronous."""
 
-    def __init__(self, device=0):
-        self.lib = load()
+    def __init__(self, device=0, ab=False):
+        """ab=True: a context of the tools' A/B build (load_ab) instead of the product library."""
+        self.lib = load_ab() if ab else load()
         h = C.c_void_p()
         rc = self.lib.nyq_ctx_create(C.byref(h), int(device))
         if rc != NYQ_OK:
@@ -176,6 +194,14 @@ class Context:
             raise NyqError(rc, (self.lib.nyq_last_error(self.h) or b"").decode())
 
     # -- context plumbing
+    def set_option(self, option, value):
+        self._ck(self.lib.nyq_ctx_set_option(self.h, int(option), int(value)))
+
+    def get_option(self, option):
+        v = C.c_long(0)
+        self._ck(self.lib.nyq_ctx_get_option(self.h, int(option), C.byref(v)))
+        return v.value
+
     def set_stream(self, stream_ptr):
         """Run on the given hipStream_t (int handle); 0 is HIP's default stream."""
         self._ck(self.lib.nyq_ctx_set_stream(self.h, C.c_void_p(stream_ptr or 0)))

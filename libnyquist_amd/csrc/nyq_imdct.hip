@@ -18,9 +18,13 @@
 #include "../../include/nyq_imdct.h"
 
 #include "nyq_kernels.hpp"
-#include "nyq_post_kernels.hpp"
-#include "nyq_post_pipe.hpp"
+#include "nyq_post_pipe.hpp"       // (includes nyq_post_kernels.hpp for the pieces both forms share)
+// The round-1 post-filter kernels (one wave per channel / per stereo pair) and the fused one-launch chain are measured-and-
+// rejected designs kept for A/B runs: they are compiled only into the tools' build of this library (-DNYQ_AB_FORMS,
+// tools/libnyq_imdct_ab.so) and selected through nyq_ctx_set_option; the product launches neither.
+#ifdef NYQ_AB_FORMS
 #include "nyq_chain_fused.hpp"
+#endif
 
 using namespace nyq;
 
@@ -58,6 +62,11 @@ struct nyq_ctx {
     int res_post_pipe[4] = {0, 0, 0, 0};
     int res_chain_fused = 0;
     int res_vorbis[12] = {0};
+    // options (nyq_ctx_set_option): nothing on a launch path reads the process environment
+    int opt_blocks_per_cu = 0;           // 0 = built-in choice
+    int opt_post_form = NYQ_POST_FORM_PIPELINE;
+    int opt_chain_fused = 0;
+    long opt_chain_window = 0;           // frames per window of the two-kernel chain; 0 = built-in choice
     float *d_vtab = nullptr;             // Vorbis rotation + twiddle tables of every block size, one allocation
     size_t vrot_off[12] = {0}, vtw_off[12] = {0};   // float offsets by log2(n/4)
     std::string err;
@@ -121,6 +130,63 @@ static int build_vorbis_tables(nyq_ctx *ctx) {
     NYQ_HIP(ctx, hipMemcpyAsync(ctx->d_vtab, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     NYQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return NYQ_OK;
+}
+
+extern "C" int nyq_device_count(void) {
+    int ndev = 0;
+    return hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 ? ndev : 0;
+}
+
+extern "C" int nyq_ab_forms_built(void) {
+#ifdef NYQ_AB_FORMS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+extern "C" int nyq_ctx_set_option(nyq_ctx *ctx, int option, long value) {
+    if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_ctx_set_option: ctx is NULL");
+    switch (option) {
+    case NYQ_OPT_BLOCKS_PER_CU:
+        if (value < 0 || value > 64) return fail(ctx, NYQ_ERR_INVALID, "nyq_ctx_set_option: NYQ_OPT_BLOCKS_PER_CU must be 0..64");
+        if ((int)value != ctx->opt_blocks_per_cu) {            // the cached grid sizes of the row kernels depend on it
+            for (int k = 0; k < 4; k++) ctx->res_imdct[k] = ctx->res_ifft[k] = ctx->res_synth_long[k] = 0;
+            ctx->res_synth_short = 0;
+        }
+        ctx->opt_blocks_per_cu = (int)value;
+        return NYQ_OK;
+    case NYQ_OPT_POST_FORM:
+        if (value != NYQ_POST_FORM_PIPELINE && value != NYQ_POST_FORM_WAVE_PER_CHANNEL && value != NYQ_POST_FORM_WAVE_PER_PAIR)
+            return fail(ctx, NYQ_ERR_INVALID, "nyq_ctx_set_option: unknown NYQ_OPT_POST_FORM value");
+        if (value != NYQ_POST_FORM_PIPELINE && !nyq_ab_forms_built())
+            return fail(ctx, NYQ_ERR_INVALID, "nyq_ctx_set_option: this build has only the pipeline form (the A/B forms live in tools/libnyq_imdct_ab.so)");
+        ctx->opt_post_form = (int)value;
+        return NYQ_OK;
+    case NYQ_OPT_CHAIN_FUSED:
+        if (value != 0 && value != 1) return fail(ctx, NYQ_ERR_INVALID, "nyq_ctx_set_option: NYQ_OPT_CHAIN_FUSED must be 0 or 1");
+        if (value == 1 && !nyq_ab_forms_built())
+            return fail(ctx, NYQ_ERR_INVALID, "nyq_ctx_set_option: this build has no fused chain kernel (tools/libnyq_imdct_ab.so has)");
+        ctx->opt_chain_fused = (int)value;
+        return NYQ_OK;
+    case NYQ_OPT_CHAIN_WINDOW:
+        if (value < 0) return fail(ctx, NYQ_ERR_INVALID, "nyq_ctx_set_option: NYQ_OPT_CHAIN_WINDOW must be >= 0");
+        ctx->opt_chain_window = value;         // (rounded up to the frame size's chain length at the call)
+        return NYQ_OK;
+    default:
+        return fail(ctx, NYQ_ERR_INVALID, "nyq_ctx_set_option: unknown option");
+    }
+}
+
+extern "C" int nyq_ctx_get_option(nyq_ctx *ctx, int option, long *value) {
+    if (!ctx || !value) return fail(ctx, NYQ_ERR_INVALID, "nyq_ctx_get_option: NULL argument");
+    switch (option) {
+    case NYQ_OPT_BLOCKS_PER_CU: *value = ctx->opt_blocks_per_cu; return NYQ_OK;
+    case NYQ_OPT_POST_FORM: *value = ctx->opt_post_form; return NYQ_OK;
+    case NYQ_OPT_CHAIN_FUSED: *value = ctx->opt_chain_fused; return NYQ_OK;
+    case NYQ_OPT_CHAIN_WINDOW: *value = ctx->opt_chain_window; return NYQ_OK;
+    default: return fail(ctx, NYQ_ERR_INVALID, "nyq_ctx_get_option: unknown option");
+    }
 }
 
 extern "C" int nyq_ctx_create(nyq_ctx **out, int device) {
@@ -245,10 +311,7 @@ static int resident_blocks(nyq_ctx *ctx, K kernel, int *cache) {
     if (e != hipSuccess || per_cu < 1) per_cu = 1;
     const int want = (NYQ_WAVES_PER_CU + kWavesPerBlock - 1) / kWavesPerBlock;   // see nyq_kernels.hpp
     if (per_cu > want) per_cu = want;
-    if (const char *o = std::getenv("NYQ_BLOCKS_PER_CU")) {   // tuning knob for profiling runs
-        int v = std::atoi(o);
-        if (v > 0) per_cu = v;
-    }
+    if (ctx->opt_blocks_per_cu > 0) per_cu = ctx->opt_blocks_per_cu;   // NYQ_OPT_BLOCKS_PER_CU: tuning knob for profiling runs
     *cache = per_cu * ctx->cus;
     return *cache;
 }
@@ -332,7 +395,7 @@ static int launch_synth_long(nyq_ctx *ctx, const SynthArgs &A) {
 // transient frames); arguments already validated
 static int synth_core(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned char *d_transient, float *d_pcm,
                       const float *d_state_in, float *d_state_out, float *d_work, size_t nstreams, size_t nframes,
-                      int channels) {
+                      int channels, size_t fstride = 0) {
     const size_t nsc = nstreams * (size_t)channels;
     // (slot 0 of every (stream, channel)'s tails row is unused: the fix-up pass reads the state handed in instead.  Round 2
     // kept a memset node here because the post-filter kernel behind the synthesis ran 0.9 instead of 1.6 ms with it; the
@@ -347,6 +410,7 @@ static int synth_core(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned 
     A.channels = channels;
     A.state_in = d_state_in;                        // (read and replaced by the fix-up pass: no copy launches)
     A.state_out = d_state_out;
+    A.fstride = (long)fstride;                      // 0: freq / transient are dense
     int rc, chain_frames;
     const size_t units = nsc * nframes;
     // transient frames: their own kernel, forked onto the side stream so that it runs beside the long-frame kernel (the
@@ -403,6 +467,9 @@ extern "C" int nyq_imdct_chain_dev(nyq_ctx *ctx, int shift, const float *d_in, c
 }
 
 // ---- post-filter + de-emphasis + interleave ---------------------------------------------
+#ifdef NYQ_AB_FORMS
+#include "nyq_post_kernels.hpp"
+// round-1 forms (A/B build only)
 template <int LM, int NC>
 static int launch_post(nyq_ctx *ctx, const PostArgs &A) {
     // 12 KB of LDS per channel a wave owns: two waves per block when a wave owns two channels, so that three
@@ -429,6 +496,8 @@ static int launch_post(nyq_ctx *ctx, const PostArgs &A) {
     NYQ_HIP(ctx, hipGetLastError());
     return NYQ_OK;
 }
+
+#endif   // NYQ_AB_FORMS
 
 // the workgroup-pipelined form (nyq_post_pipe.hpp): one workgroup of 2 comb waves + 1 I/O wave per two chains
 template <int LM>
@@ -457,18 +526,9 @@ static int launch_post_pipe(nyq_ctx *ctx, const PostArgs &A) {
     return NYQ_OK;
 }
 
-extern "C" int nyq_celt_post_dev(nyq_ctx *ctx, int LM, const float *d_pcm, const int *d_pf_pitch, const float *d_pf_gain,
-                                 const int *d_pf_tapset, const float *d_pf_state_in, float *d_pf_state_out,
-                                 float *d_hist, float *d_deemph, float *d_out, size_t nstreams, size_t nframes,
-                                 int channels) {
-    if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_celt_post_dev: ctx is NULL");
-    if (LM < 0 || LM > 3) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_post_dev: LM must be 0..3");
-    if (channels < 1 || channels > 255) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_post_dev: channels must be 1..255");
-    if (nstreams == 0 || nframes == 0) return NYQ_OK;
-    if (!d_pcm || !d_pf_pitch || !d_pf_gain || !d_pf_tapset || !d_out)
-        return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_post_dev: NULL pcm/parameters/out");
-    if (d_pf_state_in && d_pf_state_in == d_pf_state_out)
-        return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_post_dev: pf_state_in and pf_state_out must not alias");
+static int post_core(nyq_ctx *ctx, int LM, const float *d_pcm, const int *d_pf_pitch, const float *d_pf_gain,
+                     const int *d_pf_tapset, const float *d_pf_state_in, float *d_pf_state_out, float *d_hist, float *d_deemph,
+                     float *d_out, size_t nstreams, size_t nframes, int channels, size_t pstride) {
     PostArgs A;
     A.pcm = d_pcm;
     A.pf_pitch = d_pf_pitch;
@@ -482,31 +542,12 @@ extern "C" int nyq_celt_post_dev(nyq_ctx *ctx, int LM, const float *d_pcm, const
     A.nstreams = (long)nstreams;
     A.nframes = (long)nframes;
     A.channels = channels;
-    if (((uintptr_t)d_pcm | (uintptr_t)d_out) & 15)
-        return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_post_dev: pcm and out must be 16-byte aligned");
-    // a stereo stream is one wave's work (both channels in lock step); any other channel count: one wave per channel
-    // Stereo: one wave can own both channels of a stream (identical filter parameters, two dependency chains per
-    // step, full 16-byte interleaved stores) or one channel.  The comb recursion is bound by instruction issue, so
-    // what matters is how many waves a CU has to interleave: pairs win once there are enough streams to give every
-    // CU its six pair-waves (24 KB of LDS each), channel-waves win below that (same-process A/B).
-    // NYQ_POST_STEREO_PAIRS=0/1 overrides the choice for profiling.
-    // Default: the workgroup pipeline (a chain's wave issues only the recursion).  The round-1 forms
-    // (one wave per channel / per stereo pair doing everything) stay selectable for A/B runs and tests:
-    // NYQ_POST_STEREO_PAIRS=0 (wave per channel), =1 (wave per stereo pair), =2 or unset (pipeline).
-    bool pipe_mode = true, pair_mode = false;
-    if (const char *pairs = std::getenv("NYQ_POST_STEREO_PAIRS")) {
-        if (pairs[0] == '0' || pairs[0] == '1') pipe_mode = false;
-        pair_mode = channels == 2 && pairs[0] == '1';
-    }
-    if (pipe_mode) {
-        switch (LM) {
-            case 0: return launch_post_pipe<0>(ctx, A);
-            case 1: return launch_post_pipe<1>(ctx, A);
-            case 2: return launch_post_pipe<2>(ctx, A);
-            default: return launch_post_pipe<3>(ctx, A);
-        }
-    }
-    if (pair_mode) {
+    A.pstride = (long)pstride;                      // 0: pf_* / out are dense
+    // The workgroup pipeline (a chain's wave issues only the recursion) is the product's one form.  The
+    // round-1 forms -- one wave per channel, or per stereo pair, doing everything -- exist in the A/B build only and are
+    // chosen per context: nyq_ctx_set_option(ctx, NYQ_OPT_POST_FORM, ...).
+#ifdef NYQ_AB_FORMS
+    if (ctx->opt_post_form == NYQ_POST_FORM_WAVE_PER_PAIR && channels == 2) {
         switch (LM) {
             case 0: return launch_post<0, 2>(ctx, A);
             case 1: return launch_post<1, 2>(ctx, A);
@@ -514,16 +555,51 @@ extern "C" int nyq_celt_post_dev(nyq_ctx *ctx, int LM, const float *d_pcm, const
             default: return launch_post<3, 2>(ctx, A);
         }
     }
+    if (ctx->opt_post_form != NYQ_POST_FORM_PIPELINE) {
+        switch (LM) {
+            case 0: return launch_post<0, 1>(ctx, A);
+            case 1: return launch_post<1, 1>(ctx, A);
+            case 2: return launch_post<2, 1>(ctx, A);
+            default: return launch_post<3, 1>(ctx, A);
+        }
+    }
+#endif
     switch (LM) {
-        case 0: return launch_post<0, 1>(ctx, A);
-        case 1: return launch_post<1, 1>(ctx, A);
-        case 2: return launch_post<2, 1>(ctx, A);
-        default: return launch_post<3, 1>(ctx, A);
+        case 0: return launch_post_pipe<0>(ctx, A);
+        case 1: return launch_post_pipe<1>(ctx, A);
+        case 2: return launch_post_pipe<2>(ctx, A);
+        default: return launch_post_pipe<3>(ctx, A);
     }
 }
 
-// ---- freq[] -> PCM in one launch ---------------------------------------------------------------
+extern "C" int nyq_celt_post_dev(nyq_ctx *ctx, int LM, const float *d_pcm, const int *d_pf_pitch, const float *d_pf_gain,
+                                 const int *d_pf_tapset, const float *d_pf_state_in, float *d_pf_state_out,
+                                 float *d_hist, float *d_deemph, float *d_out, size_t nstreams, size_t nframes,
+                                 int channels) {
+    if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_celt_post_dev: ctx is NULL");
+    if (LM < 0 || LM > 3) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_post_dev: LM must be 0..3");
+    if (channels < 1 || channels > 255) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_post_dev: channels must be 1..255");
+    if (nstreams == 0 || nframes == 0) return NYQ_OK;
+    if (!d_pcm || !d_pf_pitch || !d_pf_gain || !d_pf_tapset || !d_out)
+        return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_post_dev: NULL pcm/parameters/out");
+    if (d_pf_state_in && d_pf_state_in == d_pf_state_out)
+        return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_post_dev: pf_state_in and pf_state_out must not alias");
+    if (((uintptr_t)d_pcm | (uintptr_t)d_out) & 15)
+        return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_post_dev: pcm and out must be 16-byte aligned");
+    return post_core(ctx, LM, d_pcm, d_pf_pitch, d_pf_gain, d_pf_tapset, d_pf_state_in, d_pf_state_out, d_hist, d_deemph, d_out,
+                     nstreams, nframes, channels, 0);
+}
+
+// ---- freq[] -> PCM: the chain as one operator ------------------------------------------------------
 extern "C" int nyq_celt_chain_fused_supported(int LM, int channels) { return LM == 3 && channels == 2; }
+
+static size_t round16f(size_t nfloats);
+
+// frames per time window of the two-kernel chain when the caller has not chosen (NYQ_OPT_CHAIN_WINDOW = 0)
+static size_t default_chain_window(size_t nstreams, size_t nframes, int channels, int LM) {
+    (void)nstreams; (void)channels; (void)LM;
+    return nframes;                                 // one window: see DESIGN.md 4.8 for the measurements behind it
+}
 
 extern "C" int nyq_celt_chain_dev(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned char *d_transient,
                                   const int *d_pf_pitch, const float *d_pf_gain, const int *d_pf_tapset,
@@ -540,43 +616,82 @@ extern "C" int nyq_celt_chain_dev(nyq_ctx *ctx, int LM, const float *d_freq, con
         return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_chain_dev: pf_state_in and pf_state_out must not alias");
     if (!aligned16(d_freq) || !aligned16(d_out) || !aligned16(d_overlap) || !aligned16(d_hist))
         return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_chain_dev: device pointers must be 16-byte aligned");
-    // The fused kernel is correct (tests/test_gpu_chain.py) but measured 3x SLOWER than the two launches (6.1 ms vs 1.9 ms
-    // for 1024 x 256 stereo frames, profiles/r02_*): one IMDCT wave per four chains cannot keep up with the comb waves, and
-    // the LDS that would hold more IMDCT slices is what keeps every chain resident.  It runs only on request (NYQ_CHAIN_FUSED=1).
-    const char *force = std::getenv("NYQ_CHAIN_FUSED");
-    const bool fused = nyq_celt_chain_fused_supported(LM, channels) && force && force[0] == '1';
-    if (!fused) {
-        if (!d_pcm || !d_work)
-            return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_chain_dev: this frame size / channel count runs as two kernels and needs d_pcm and d_work");
-        int rc = nyq_celt_synth_dev(ctx, LM, d_freq, d_transient, d_pcm, d_overlap, d_work, nstreams, nframes, channels);
+#ifdef NYQ_AB_FORMS
+    // The fused kernel (A/B build only) is correct (tests/test_gpu_chain.py) but measured 3x SLOWER than the two launches
+    // (6.1 ms vs 1.9 ms for 1024 x 256 stereo frames, profiles/r02_*): one IMDCT wave per four chains cannot keep up with
+    // the comb waves, and the LDS that would hold more IMDCT slices is what keeps every chain resident.
+    if (ctx->opt_chain_fused && nyq_celt_chain_fused_supported(LM, channels)) {
+        ChainArgs A;
+        A.freq = d_freq;
+        A.transient = d_transient;
+        A.ov_state = d_overlap;
+        A.pf_pitch = d_pf_pitch;
+        A.pf_gain = d_pf_gain;
+        A.pf_tapset = d_pf_tapset;
+        A.pf_state = d_pf_state_in;
+        A.pf_state_out = d_pf_state_out;
+        A.hist = d_hist;
+        A.deemph = d_deemph;
+        A.out = d_out;
+        A.nstreams = (long)nstreams;
+        A.nframes = (long)nframes;
+        if (ctx->res_chain_fused == 0) {
+            int per_cu = 0;
+            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, celt_chain_fused_kernel, kWave * kFuseWaves, 0);
+            if (e != hipSuccess || per_cu < 1) per_cu = 1;
+            ctx->res_chain_fused = per_cu * ctx->cus;
+        }
+        const size_t ngroups = (nstreams + 1) / 2;
+        const unsigned grid = (unsigned)(ngroups < (size_t)ctx->res_chain_fused ? ngroups : (size_t)ctx->res_chain_fused);
+        hipLaunchKernelGGL(celt_chain_fused_kernel, dim3(grid), dim3(kWave * kFuseWaves), 0, ctx->stream, A, ctx->d_trig, ctx->d_window);
+        NYQ_HIP(ctx, hipGetLastError());
+        return NYQ_OK;
+    }
+#endif
+    if (!d_pcm || !d_work)
+        return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_chain_dev: the two-kernel chain needs d_pcm and d_work");
+    if (!aligned16(d_pcm) || !aligned16(d_work))
+        return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_chain_dev: device pointers must be 16-byte aligned");
+    // Time windows (NYQ_OPT_CHAIN_WINDOW): synthesis and post-filter alternate over windows of W frames (a multiple of
+    // 64: the synthesis kernels' in-wave carry chains then restart at the same frames as in one call, so the result is
+    // bit-identical).  A window's time-domain frames live in the FIRST nsc * W * N floats of d_pcm, written by one launch
+    // and read by the next: sized to the 256 MB Infinity Cache they need not make the round trip through HBM that the
+    // whole-call form pays (DESIGN.md 4.8 for what that was measured to be worth).  The decoder states travel from window to
+    // window through the caller's state buffers, or -- where the caller passed NULL (fresh decoder, state discarded) --
+    // through the part of d_work that a window's synthesis does not use.
+    const size_t N = (size_t)120 << LM, nsc = nstreams * (size_t)channels;
+    size_t W = ctx->opt_chain_window > 0 ? (size_t)ctx->opt_chain_window : default_chain_window(nstreams, nframes, channels, LM);
+    const size_t chainlen = LM == 3 ? Geo<32>::CHAIN_FRAMES : LM == 2 ? Geo<16>::CHAIN_FRAMES : LM == 1 ? Geo<8>::CHAIN_FRAMES : Geo<4>::CHAIN_FRAMES;
+    W = (W + chainlen - 1) / chainlen * chainlen;   // windows start where the in-wave carry chains start: bit-identical to one window
+    if (W >= nframes || nframes - W < 20) {         // (the temporaries below need 20 frames' worth of d_work beyond a window's own)
+        int rc = synth_core(ctx, LM, d_freq, d_transient, d_pcm, d_overlap, d_overlap, d_work, nstreams, nframes, channels);
         if (rc != NYQ_OK) return rc;
-        return nyq_celt_post_dev(ctx, LM, d_pcm, d_pf_pitch, d_pf_gain, d_pf_tapset, d_pf_state_in, d_pf_state_out, d_hist,
-                                 d_deemph, d_out, nstreams, nframes, channels);
+        return post_core(ctx, LM, d_pcm, d_pf_pitch, d_pf_gain, d_pf_tapset, d_pf_state_in, d_pf_state_out, d_hist, d_deemph,
+                         d_out, nstreams, nframes, channels, 0);
     }
-    ChainArgs A;
-    A.freq = d_freq;
-    A.transient = d_transient;
-    A.ov_state = d_overlap;
-    A.pf_pitch = d_pf_pitch;
-    A.pf_gain = d_pf_gain;
-    A.pf_tapset = d_pf_tapset;
-    A.pf_state = d_pf_state_in;
-    A.pf_state_out = d_pf_state_out;
-    A.hist = d_hist;
-    A.deemph = d_deemph;
-    A.out = d_out;
-    A.nstreams = (long)nstreams;
-    A.nframes = (long)nframes;
-    if (ctx->res_chain_fused == 0) {
-        int per_cu = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, celt_chain_fused_kernel, kWave * kFuseWaves, 0);
-        if (e != hipSuccess || per_cu < 1) per_cu = 1;
-        ctx->res_chain_fused = per_cu * ctx->cus;
+    // temporaries behind the window's own share of d_work (nsc * (W + 1) * 60 floats of nsc * (nframes + 1) * 60):
+    // overlap [nsc][60], hist [nsc][1088], deemph [nsc], post-filter state ping / pong [nstreams][6] -- 1150 floats per
+    // (stream, channel) at most, and nframes - W >= 64 frames' worth (3840 floats each) are free
+    float *t_ov = d_work + round16f(nsc * (W + 1) * NYQ_HALF_OV), *t_hi = t_ov + round16f(nsc * NYQ_HALF_OV),
+          *t_de = t_hi + round16f(nsc * kPostHist), *t_pf[2] = {t_de + round16f(nsc), t_de + round16f(nsc) + round16f(nstreams * 6)};
+    float *ov = d_overlap ? d_overlap : t_ov, *hi = d_hist ? d_hist : t_hi, *de = d_deemph ? d_deemph : t_de;
+    if (!d_overlap) NYQ_HIP(ctx, hipMemsetAsync(t_ov, 0, nsc * NYQ_HALF_OV * sizeof(float), ctx->stream));
+    if (!d_hist) NYQ_HIP(ctx, hipMemsetAsync(t_hi, 0, nsc * kPostHist * sizeof(float), ctx->stream));
+    if (!d_deemph) NYQ_HIP(ctx, hipMemsetAsync(t_de, 0, nsc * sizeof(float), ctx->stream));
+    const float *pf_in = d_pf_state_in;
+    size_t k = 0;
+    for (size_t f0 = 0; f0 < nframes; f0 += W, k++) {
+        const size_t len = nframes - f0 < W ? nframes - f0 : W;
+        const bool lastw = f0 + len == nframes;
+        float *pf_out = lastw ? d_pf_state_out : t_pf[k & 1];
+        int rc = synth_core(ctx, LM, d_freq + f0 * channels * N, d_transient ? d_transient + f0 : nullptr, d_pcm, ov, ov, d_work,
+                            nstreams, len, channels, nframes);
+        if (rc != NYQ_OK) return rc;
+        rc = post_core(ctx, LM, d_pcm, d_pf_pitch + f0, d_pf_gain + f0, d_pf_tapset + f0, pf_in, pf_out, hi, de, d_out + f0 * N * channels,
+                       nstreams, len, channels, nframes);
+        if (rc != NYQ_OK) return rc;
+        pf_in = pf_out;
     }
-    const size_t ngroups = (nstreams + 1) / 2;
-    const unsigned grid = (unsigned)(ngroups < (size_t)ctx->res_chain_fused ? ngroups : (size_t)ctx->res_chain_fused);
-    hipLaunchKernelGGL(celt_chain_fused_kernel, dim3(grid), dim3(kWave * kFuseWaves), 0, ctx->stream, A, ctx->d_trig, ctx->d_window);
-    NYQ_HIP(ctx, hipGetLastError());
     return NYQ_OK;
 }
 

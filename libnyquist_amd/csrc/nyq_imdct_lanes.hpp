@@ -220,6 +220,10 @@ struct SynthArgs {
     int channels;
     const float *state_in;
     float *state_out;
+    // freq and transient may be WINDOWS into longer per-stream arrays: consecutive streams are `fstride` frames apart
+    // (0 = dense: nframes).  pcm, tails and the states are always dense.
+    long fstride;
+    NYQ_HD long fs() const { return fstride ? fstride : nframes; }
 };
 
 // Long frames.  A wave visits CHUNKS of kChainGroups groups = 4 G consecutive frames of one
@@ -253,7 +257,7 @@ struct FrameLongRows {
         const long s = sc / A.channels;
         unsigned long long m = 0;
         if (A.transient) {
-            const unsigned char *t = A.transient + s * A.nframes;
+            const unsigned char *t = A.transient + s * A.fs();
             for (int i = -1; i <= kChainFrames; i++) {
                 const long f = k * kChainFrames + i;
                 if (i + 1 < 64 && f >= 0 && f < A.nframes && t[f]) m |= 1ull << (i + 1);   // (4 G + 2 <= 64 whenever flags exist: LM >= 1)
@@ -269,7 +273,7 @@ struct FrameLongRows {
         const long f0 = k * kChainFrames + (long)qq_ * G;
         qq = qq_;
         in_step = (long)A.channels * N;
-        in0 = A.freq + ((s * A.nframes + f0) * A.channels + c) * (long)N;
+        in0 = A.freq + ((s * A.fs() + f0) * A.channels + c) * (long)N;
         fin0 = A.pcm + (sc * A.nframes + f0) * (long)N;
         tail0 = A.tails + (sc * (A.nframes + 1) + f0 + 1) * (long)kHalfOv;
         longmask = 0;
@@ -312,7 +316,7 @@ struct FrameShortRows {
         const long N = 120L * B_;
         B = B_;
         b0 = h * Geo<4>::G;
-        in0 = A.freq + ((s * A.nframes + f) * A.channels + c) * N;
+        in0 = A.freq + ((s * A.fs() + f) * A.channels + c) * N;
         fin0 = A.pcm + (sc * A.nframes + f) * N;
         tail_slot = A.tails + (sc * (A.nframes + 1) + f + 1) * (long)kHalfOv;
     }

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kWave *Cfg::WPB) void synth_long_kernel(SynthArgs A
             const long cpc = FrameLongRows<N2R>::chunks_per_channel(A.nframes);
             const long sc = ci / cpc, k = ci - sc * cpc;
             const long f = k * FrameLongRows<N2R>::kChainFrames - 1 + lane;
-            if (lane <= FrameLongRows<N2R>::kChainFrames + 1 && f >= 0 && f < A.nframes) tr = A.transient[(sc / A.channels) * A.nframes + f] != 0;
+            if (lane <= FrameLongRows<N2R>::kChainFrames + 1 && f >= 0 && f < A.nframes) tr = A.transient[(sc / A.channels) * A.fs() + f] != 0;
         }
         return tr;
     };
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(kWave *Cfg::WPB) void synth_short_kernel(SynthArgs 
         bool hit = false;
         if (mine < units) {
             const long sc = mine / A.nframes, f = mine - sc * A.nframes;
-            hit = A.transient[(sc / A.channels) * A.nframes + f] != 0;
+            hit = A.transient[(sc / A.channels) * A.fs() + f] != 0;
         }
         unsigned long long todo = __ballot(hit);
         while (todo) {
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(kWave *kFixupWaves) void synth_fixup_kernel(SynthAr
     bool need = false;
     if (mine < units) {
         const long sc = mine / A.nframes, f = mine - sc * A.nframes;
-        need = !head_done_in_wave(A.transient ? A.transient + (sc / A.channels) * A.nframes : nullptr, f, chain_frames);
+        need = !head_done_in_wave(A.transient ? A.transient + (sc / A.channels) * A.fs() : nullptr, f, chain_frames);
     }
     unsigned long long todo = __ballot(need);
     const float wa = lane < kHalfOv ? window[kOverlap - 1 - lane] : 0.f;

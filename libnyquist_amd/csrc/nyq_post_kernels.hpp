@@ -23,107 +23,9 @@
 // operation: filter frame f (LDS only) -> move frame f+1 from registers to the ring -> issue the loads
 // of frame f+2 -> store frame f.
 #pragma once
-#include <hip/hip_runtime.h>
-
-#include "nyq_imdct_lanes.hpp"
+#include "nyq_post_common.hpp"
 
 namespace nyq {
-
-constexpr int kPostRing = 2048;         // per-channel LDS buffer: DECODE_BUFFER_SIZE, celt_decoder_clean.c:59
-constexpr int kPostHist = 1088;         // history in front of the frame (>= COMBFILTER_MAXPERIOD + 2); also handed from call to call
-constexpr int kCombMinPeriod = 15;      // celt.h:188
-constexpr int kCombMaxPeriod = 1024;    // celt.h:187 (keeps every tap inside the buffer whatever the caller passes)
-constexpr float kPreemph = 0.85000610f; // mode->preemph[0], static_modes_float.h:581
-
-struct PostArgs {
-    const float *pcm;        // [nstreams*channels][nframes*N]  IMDCT output (read only)
-    const int *pf_pitch;     // [nstreams][nframes]
-    const float *pf_gain;    // [nstreams][nframes]
-    const int *pf_tapset;    // [nstreams][nframes]
-    const float *pf_state;   // [nstreams][6] {period_old, period, gain_old, gain, tapset_old, tapset} or null
-    float *pf_state_out;     // same layout, must not alias pf_state (channels of a stream run in different waves)
-    float *hist;             // [nstreams*channels][1088] filtered history in/out, or null (zeros, discarded)
-    float *deemph;           // [nstreams*channels] preemph_memD in/out, or null
-    float *out;              // [nstreams][nframes*N][channels]
-    long nstreams, nframes;
-    int channels;
-};
-
-__device__ __forceinline__ void comb_gains(float g, int tapset, float &a, float &b, float &c) {
-    // celt.c:121-124 gains[tapset][0..2]
-    const float t0 = tapset == 0 ? 0.3066406250f : tapset == 1 ? 0.4638671875f : 0.7998046875f;
-    const float t1 = tapset == 0 ? 0.2170410156f : tapset == 1 ? 0.2680664062f : 0.1000976562f;
-    const float t2 = tapset == 0 ? 0.1296386719f : 0.f;
-    a = g * t0;
-    b = g * t1;
-    c = g * t2;
-}
-
-// the value, but not a loop invariant to the optimiser: per-lane offsets derived from an opaque copy of the lane id are
-// recomputed where they are used (a few VALU operations) instead of being hoisted out of the frame loop and kept alive
-__device__ __forceinline__ int opaque(int v) {
-    asm volatile("" : "+v"(v));
-    return v;
-}
-
-#define NYQ_POST_SYNC()                                          \
-    do {                                                         \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
-        __builtin_amdgcn_wave_barrier();                         \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
-    } while (0)
-
-// 16-byte moves go through a native vector value (a struct copy stays a memcpy and lands in scratch memory)
-typedef float vf4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f4 lds4(const float *base, int idx) {
-    const vf4 v = *reinterpret_cast<const vf4 *>(base + idx);
-    return f4{v.x, v.y, v.z, v.w};
-}
-__device__ __forceinline__ void sts4(float *base, int idx, const f4 &v) {
-    *reinterpret_cast<vf4 *>(base + idx) = vf4{v.x, v.y, v.z, v.w};
-}
-__device__ __forceinline__ void sts4(float *base, int idx, const vf4 &v) { *reinterpret_cast<vf4 *>(base + idx) = v; }
-
-template <int A>
-__device__ __forceinline__ void pick8(const f4 &q0, const f4 &q1, const f4 &q2, float (&x)[8]) {
-    const float e[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
-#pragma unroll
-    for (int i = 0; i < 8; i++) x[i] = e[A + i];
-}
-
-// x[c][0..8) = buf_c[r .. r+8) for an arbitrary r >= 0 whose alignment r & 3 is the same in every lane
-// (and in every channel: the channels of a stream share the pitch period)
-template <int NC>
-__device__ __forceinline__ void taps8(const float *ring, int r, float (&x)[NC][8]) {
-    const int a = __builtin_amdgcn_readfirstlane(r) & 3;
-    const int rb = r - a;
-    f4 q0[NC], q1[NC], q2[NC];
-#pragma unroll
-    for (int c = 0; c < NC; c++) {
-        const float *rc = ring + c * kPostRing;
-        q0[c] = lds4(rc, rb);
-        q1[c] = lds4(rc, rb + 4);
-        q2[c] = lds4(rc, rb + 8);
-    }
-    switch (a) {
-        case 0:
-#pragma unroll
-            for (int c = 0; c < NC; c++) pick8<0>(q0[c], q1[c], q2[c], x[c]);
-            break;
-        case 1:
-#pragma unroll
-            for (int c = 0; c < NC; c++) pick8<1>(q0[c], q1[c], q2[c], x[c]);
-            break;
-        case 2:
-#pragma unroll
-            for (int c = 0; c < NC; c++) pick8<2>(q0[c], q1[c], q2[c], x[c]);
-            break;
-        default:
-#pragma unroll
-            for (int c = 0; c < NC; c++) pick8<3>(q0[c], q1[c], q2[c], x[c]);
-            break;
-    }
-}
 
 // The constant part of a comb_filter() call for one tap alignment AL: outputs [kOverlap, n) of the rings, w1 per
 // step (four adjacent ones per lane, lanes 0 .. w1/4-1), taps from three aligned 16-byte reads per channel.
@@ -380,9 +282,9 @@ __global__ __launch_bounds__(kWave *WPB) void celt_post_kernel(PostArgs A, const
         NYQ_POST_SYNC();
         const vf4 *src = reinterpret_cast<const vf4 *>(A.pcm + sc0 * A.nframes * N);   // channel c: + c * nframes * NV
         const long cstride = A.nframes * NV;
-        const int *ppitch = A.pf_pitch + s * A.nframes;
-        const float *pgain = A.pf_gain + s * A.nframes;
-        const int *ptap = A.pf_tapset + s * A.nframes;
+        const int *ppitch = A.pf_pitch + s * A.ps();
+        const float *pgain = A.pf_gain + s * A.ps();
+        const int *ptap = A.pf_tapset + s * A.ps();
         // the prefetched frame lives in registers (native vector values: an array of 16-byte structs here ends
         // up in scratch memory)
         vf4 nx[NC][4];
@@ -423,7 +325,7 @@ __global__ __launch_bounds__(kWave *WPB) void celt_post_kernel(PostArgs A, const
         }
         NYQ_POST_SYNC();
         constexpr int r0 = kPostHist;                          // buffer index of the frame start
-        float *dst = A.out + (s * A.nframes * N) * A.channels + c0;
+        float *dst = A.out + (s * A.ps() * N) * A.channels + c0;
         for (long f = 0; f < A.nframes; f++) {
             if (T_cur < kCombMinPeriod) T_cur = kCombMinPeriod;   // celt_decoder_clean.c:661-662
             if (T_old < kCombMinPeriod) T_old = kCombMinPeriod;

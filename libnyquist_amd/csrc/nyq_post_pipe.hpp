@@ -26,7 +26,7 @@
 // workgroup's LDS and a fourth wave's registers per SIMD to spare -- the workgroups live for the whole launch and must
 // all be placed at once (kPipeHist, and the kernel's launch bounds, say why).
 #pragma once
-#include "nyq_post_kernels.hpp"
+#include "nyq_post_common.hpp"
 
 namespace nyq {
 
@@ -561,6 +561,7 @@ __global__ __launch_bounds__(kWave *kPipeWaves, NYQ_PIPE_MINWAVES) void celt_pos
     const long nunits = A.nstreams * A.channels;
     const long npairs = (nunits + kPipeUnits - 1) / kPipeUnits;
     const long nfr = A.nframes;
+    const long pst = A.ps();                       // frames per stream in pf_* and out (a window of longer arrays, or nfr)
     NYQ_WG_TRACE(2);
     __syncthreads();
 
@@ -678,7 +679,7 @@ __global__ __launch_bounds__(kWave *kPipeWaves, NYQ_PIPE_MINWAVES) void celt_pos
                         const int v = ln + q * kWave;
                         nx[k][q] = fr[v < NV ? v : NV - 1]; // lanes past the frame re-read its last vector
                     }
-                    const long pi = sU[k] * nfr + fidx;
+                    const long pi = sU[k] * pst + fidx;
                     pT[k] = A.pf_pitch[pi];
                     pG[k] = A.pf_gain[pi];
                     pS[k] = A.pf_tapset[pi];
@@ -760,7 +761,7 @@ __global__ __launch_bounds__(kWave *kPipeWaves, NYQ_PIPE_MINWAVES) void celt_pos
 #pragma unroll
                         for (int k = 0; k < kPipeUnits; k++) {
                             if (!live[k]) continue;
-                            float *o = A.out + (sU[k] * nfr * N + (f - 1) * N) * A.channels + cU[k];
+                            float *o = A.out + (sU[k] * pst * N + (f - 1) * N) * A.channels + cU[k];
                             const int lg = opaque(lane);       // (no per-lane 64-bit induction variables kept over the frame loop)
 #pragma unroll 2
                             for (int j = lg; j < N; j += kWave) o[(long)j * A.channels] = dstg[k][j];
@@ -801,7 +802,7 @@ __global__ __launch_bounds__(kWave *kPipeWaves, NYQ_PIPE_MINWAVES) void celt_pos
                     if (f >= 1) {
                         const long t0 = (f - 1) * N;           // first sample of the frame
                         if (pairOut) {
-                            vf4 *d4 = reinterpret_cast<vf4 *>(A.out + (sU[0] * nfr * N + t0) * 2);
+                            vf4 *d4 = reinterpret_cast<vf4 *>(A.out + (sU[0] * pst * N + t0) * 2);
 #pragma unroll
                             for (int q = 0; q < 2 * QH; q++) {
                                 const int v = lh + (2 * QH * h + q) * kWave;
@@ -811,7 +812,7 @@ __global__ __launch_bounds__(kWave *kPipeWaves, NYQ_PIPE_MINWAVES) void celt_pos
 #pragma unroll
                             for (int k = 0; k < kPipeUnits; k++) {
                                 if (!live[k]) continue;
-                                vf4 *d4 = reinterpret_cast<vf4 *>(A.out + sU[k] * nfr * N + t0);
+                                vf4 *d4 = reinterpret_cast<vf4 *>(A.out + sU[k] * pst * N + t0);
 #pragma unroll
                                 for (int q = 0; q < QH; q++) {
                                     const int v = lh + (QH * h + q) * kWave;

@@ -13,7 +13,9 @@
 #include <functional>
 #include <map>
 #include <mutex>
+#include <exception>
 #include <stdexcept>
+#include <system_error>
 #include <thread>
 #include <tuple>
 
@@ -24,6 +26,12 @@
 #include "opus_stream.hpp"
 
 namespace nyq_host {
+
+// Test-only fault injection (tests/sched/lease_check.cpp, built with -DNYQ_HOST_TEST_HOOKS): the n-th thread start
+// from now on fails the way pthread_create does when the process is out of threads.  Never compiled into the product.
+#ifdef NYQ_HOST_TEST_HOOKS
+std::atomic<long> g_failThreadStartIn{0};
+#endif
 
 namespace {
 
@@ -209,17 +217,63 @@ int usableHostThreads() {
     return n;
 }
 
+// Threads that are ALWAYS joined: a std::thread that is still joinable when it is destroyed ends the process
+// (std::terminate -> abort), so nothing here may leave a scope -- by return or by exception -- with one running.
+class JoinedThreads {
+public:
+    JoinedThreads() = default;
+    JoinedThreads(const JoinedThreads &) = delete;
+    JoinedThreads &operator=(const JoinedThreads &) = delete;
+    ~JoinedThreads() { join(); }
+    template <class Fn>
+    void start(Fn &&fn) {                   // throws std::system_error like std::thread; what has been started stays owned
+#ifdef NYQ_HOST_TEST_HOOKS
+        if (g_failThreadStartIn.load() > 0 && g_failThreadStartIn.fetch_sub(1) == 1)
+            throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again), "thread start (injected)");
+#endif
+        threads_.emplace_back(std::forward<Fn>(fn));
+    }
+    void join() {
+        for (auto &t : threads_)
+            if (t.joinable()) t.join();
+        threads_.clear();
+    }
+    size_t size() const { return threads_.size(); }
+
+private:
+    std::vector<std::thread> threads_;
+};
+
+// body(i) for i in [0, n) on up to `threads` threads (the caller's included).  Nothing escapes a worker thread: the first
+// exception of any body is kept, the remaining indices are dropped, every thread is joined, and it is rethrown here.  If
+// the process cannot start another thread the loop runs on the threads it got (the calling thread at least).
 template <class F>
 void parallelFor(size_t n, int threads, F &&body) {
     std::atomic<size_t> next{0};
+    std::mutex emu;
+    std::exception_ptr first;
     auto work = [&]() {
-        for (size_t i = next++; i < n; i = next++) body(i);
+        for (size_t i = next++; i < n; i = next++) {
+            try {
+                body(i);
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(emu);
+                if (!first) first = std::current_exception();
+                next.store(n);
+            }
+        }
     };
-    std::vector<std::thread> pool;
-    const int extra = (int)std::min<size_t>(threads > 0 ? threads - 1 : 0, n > 0 ? n - 1 : 0);
-    for (int t = 0; t < extra; t++) pool.emplace_back(work);
-    work();
-    for (auto &t : pool) t.join();
+    {
+        JoinedThreads pool;
+        const int extra = (int)std::min<size_t>(threads > 0 ? threads - 1 : 0, n > 0 ? n - 1 : 0);
+        try {
+            for (int t = 0; t < extra; t++) pool.start(work);
+        } catch (const std::system_error &) {
+            // fewer threads than asked for: slower, not wrong
+        }
+        work();
+    }
+    if (first) std::rethrow_exception(first);
 }
 
 
@@ -259,12 +313,40 @@ public:
         flatten();
         layout();
         planOutput();
-        std::vector<std::thread> feeders;
-        for (int k = 0; k < nfeeders_; k++) feeders.emplace_back([this, k] { feederLoop(k); });
-        parallelFor(members_.size(), threads_, [&](size_t mi) { decodeFile(members_[mi]); });
-        const auto t1 = std::chrono::steady_clock::now();
-        cv_.notify_all();
-        for (auto &t : feeders) t.join();
+        std::chrono::steady_clock::time_point t1;
+        {
+            // The feeders are joined whichever way this block is left.  If anything throws in here (a feeder that cannot
+            // be started, an exception out of a decoding thread) the guard below raises `abort_` first, so that feeders
+            // waiting for work return instead of waiting for pieces that will never come.
+            JoinedThreads feeders;
+            struct AbortOnUnwind {
+                SubBatch &sb;
+                bool armed = true;
+                ~AbortOnUnwind() {
+                    if (!armed) return;
+                    {
+                        std::lock_guard<std::mutex> lk(sb.mu_);
+                        sb.abort_ = true;
+                    }
+                    sb.cv_.notify_all();
+                }
+            } guard{*this};
+            // one feeder per device first, then the second of each, ...: if the process runs out of threads on the way
+            // the batch goes on with the feeders it has, as long as every device has one
+            try {
+                for (int f = 0; f < feedersPerDev_; f++)
+                    for (int d = 0; d < ndev_; d++) {
+                        const int which = d * feedersPerDev_ + f;
+                        feeders.start([this, which] { feederLoop(which); });
+                    }
+            } catch (const std::system_error &e) {
+                if (feeders.size() < (size_t)ndev_) throw std::runtime_error(std::string("cannot start a feeder thread per device: ") + e.what());
+            }
+            parallelFor(members_.size(), threads_, [&](size_t mi) { decodeFile(members_[mi]); });
+            t1 = std::chrono::steady_clock::now();
+            guard.armed = false;
+            cv_.notify_all();
+        }
         if (!gpuError_.empty()) throw std::runtime_error(gpuError_);
         laterSegments();
         // pass 3 for the files that could not be finished as their pieces completed (later segments, or a stream of
@@ -459,8 +541,8 @@ private:
             size_t pi;
             {
                 std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return !mine.empty() || finishedPieces_ == pieces_.size(); });
-                if (mine.empty()) return;
+                cv_.wait(lk, [&] { return !mine.empty() || finishedPieces_ == pieces_.size() || abort_; });
+                if (mine.empty() || abort_) return;
                 pi = mine.front();
                 mine.pop_front();
             }
@@ -470,7 +552,7 @@ private:
             const size_t f0 = myslice * p.sliceLen, len = std::min(p.sliceLen, g.maxF - f0);
             const size_t so = p.k0 * g.maxF + f0;         // first stream of the piece, first frame of the slice
             const bool last = myslice + 1 == p.nslices;
-            bool released = false;
+            bool released = false, ok = false;
             const auto c0 = std::chrono::steady_clock::now();
             try {
                 if (nyq_celt_frames_to_pcm_window(ctx, g.LM, g.freq + so * g.ch * g.N, g.tr + so, g.pp + so, g.pg + so, g.pt + so,
@@ -497,18 +579,30 @@ private:
                 }
                 cvAppend_.notify_all();
                 if (last && p.anyMore) keepStates(ctx, p);
+                ok = true;
             } catch (const std::exception &e) {
                 std::lock_guard<std::mutex> lk(mu_);
                 if (gpuError_.empty()) gpuError_ = e.what();
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (gpuError_.empty()) gpuError_ = "unknown exception in a feeder thread";
             }
             gpuBusy_[(size_t)which] += std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
-            if (last) finishFilesOf(p);
-            std::unique_lock<std::mutex> lk(mu_);
-            cvAppend_.wait(lk, [&] { return p.appendTurn >= myslice; });   // (earlier slices always get there)
-            if (p.appendTurn == myslice) {                  // an error above skipped the hand-over: do not block later slices
-                p.appendTurn = myslice + 1;
-                cvAppend_.notify_all();
+            bool finishFiles = false;
+            {
+                // Every earlier slice of the piece has handed its samples over before this one is closed -- also on the
+                // error path, where the hand-over above was skipped: nothing may touch the files' sample vectors (pass 3
+                // below) while an earlier slice's feeder is still appending to them.
+                std::unique_lock<std::mutex> lk(mu_);
+                cvAppend_.wait(lk, [&] { return p.appendTurn >= myslice; });   // (earlier slices always get there)
+                if (p.appendTurn == myslice) {              // an error above skipped the hand-over: do not block later slices
+                    p.appendTurn = myslice + 1;
+                    cvAppend_.notify_all();
+                }
+                finishFiles = last && ok && gpuError_.empty();   // (after a GPU failure run() throws: no file is finished)
             }
+            if (finishFiles) finishFilesOf(p);
+            std::lock_guard<std::mutex> lk(mu_);
             if (!released) {
                 p.nextSlice++;
                 p.inFlight = false;
@@ -584,17 +678,20 @@ private:
     // frame count -- no padding, so the decoder state that comes back is exact) with their states gathered
     // into the batch layout and scattered back.
     void laterSegments() {
-        nyq_ctx *ctx = (nyq_ctx *)ctxs_[0];
         const size_t n = sfp_.size();
         for (size_t r = 1;; r++) {
-            std::map<std::tuple<int, int, long>, std::vector<size_t>> shapes;
+            // (device, channels, frame size, frame count): a stream's later segments run on the device that holds its
+            // group -- no stream's data ever visits another device
+            std::map<std::tuple<int, int, int, long>, std::vector<size_t>> shapes;
             for (size_t i = 0; i < n; i++)
                 if (sf(i).later.size() >= r && !stateOf_[i].empty())   // (no state: the file failed in pass 1)
-                    shapes[std::make_tuple(sf(i).channels, sf(i).later[r - 1].LM, sf(i).later[r - 1].nframes)].push_back(i);
+                    shapes[std::make_tuple(groups_[sf(i).group].dev, sf(i).channels, sf(i).later[r - 1].LM, sf(i).later[r - 1].nframes)]
+                        .push_back(i);
             if (shapes.empty()) break;
             for (const auto &kv : shapes) {
-                const int ch = std::get<0>(kv.first), LM = std::get<1>(kv.first);
-                const size_t nf = (size_t)std::get<2>(kv.first), N = (size_t)120 << LM;
+                nyq_ctx *ctx = (nyq_ctx *)ctxs_[(size_t)std::get<0>(kv.first) * (size_t)feedersPerDev_];
+                const int ch = std::get<1>(kv.first), LM = std::get<2>(kv.first);
+                const size_t nf = (size_t)std::get<3>(kv.first), N = (size_t)120 << LM;
                 const std::vector<size_t> &ids = kv.second;
                 const size_t ns = ids.size(), per = nf * ch * N;
                 std::vector<float> freq(ns * per), pcm(ns * per), pg(ns * nf), state(nyq_celt_state_floats(ns, ch));
@@ -697,6 +794,7 @@ private:
     std::condition_variable cv_, cvAppend_;
     std::vector<std::deque<size_t>> ready_;   // per device
     size_t finishedPieces_ = 0;
+    bool abort_ = false;                               // run() is unwinding: feeders stop taking pieces
     std::string gpuError_;
     std::vector<double> gpuBusy_;
 };
@@ -707,6 +805,14 @@ BatchOpusDecoder::BatchOpusDecoder(int device) : BatchOpusDecoder(std::vector<in
 
 BatchOpusDecoder::BatchOpusDecoder(const std::vector<int> &devices) : devices_(devices) {
     if (devices_.empty()) throw std::runtime_error("BatchOpusDecoder: empty device list");
+    if (const char *e = std::getenv("NYQ_BATCH_BYTES")) {      // read once, here: no decoding path looks at the environment
+        const long long v = std::atoll(e);
+        if (v > 0) stagingBudget_ = (size_t)v;
+    }
+    const int ndev = nyq_device_count();
+    for (int d : devices_)
+        if (d < 0 || d >= ndev)
+            throw std::runtime_error("BatchOpusDecoder: device " + std::to_string(d) + " does not exist (" + std::to_string(ndev) + " visible)");
     arenas_.resize(devices_.size());
     for (size_t d = 0; d < devices_.size(); d++)
         for (int k = 0; k < kFeeders; k++) {
@@ -732,11 +838,12 @@ void BatchOpusDecoder::trim(size_t keepBytes) {
             a.pinned ? nyq_host_free(a.p) : std::free(a.p);
             a = Arena();
         }
-    size_t kept = 0;                                           // pooled sample buffers: keep what fits the same bound
-    for (auto it = pool_.begin(); it != pool_.end();) {
-        if (kept + it->capacity() * sizeof(float) > keepBytes) it = pool_.erase(it);
-        else { kept += it->capacity() * sizeof(float); ++it; }
-    }
+    // pooled sample buffers, ascending by capacity (decodeImpl hands them out from the back: the largest first); keep
+    // the largest ones that fit the same bound
+    std::sort(pool_.begin(), pool_.end(), [](const std::vector<float> &a, const std::vector<float> &b) { return a.capacity() < b.capacity(); });
+    size_t kept = 0, firstKept = pool_.size();
+    while (firstKept > 0 && kept + pool_[firstKept - 1].capacity() * sizeof(float) <= keepBytes) kept += pool_[--firstKept].capacity() * sizeof(float);
+    pool_.erase(pool_.begin(), pool_.begin() + (long)firstKept);
 }
 
 // page-locked staging memory of one device, kept from call to call (grow only); pageable memory if pinning fails
@@ -783,11 +890,7 @@ void BatchOpusDecoder::decodeImpl(const std::vector<const std::vector<uint8_t> *
     // Memory bound: the page-locked group buffers hold freq[] and PCM of every stream of a batch, so a big job
     // (BASELINE config 4: 1000 streams of a 224 s file = 86 GB of coefficients) runs as consecutive sub-batches
     // of at most NYQ_BATCH_BYTES (default 6 GiB) of staging memory; files keep their order.
-    size_t budget = (size_t)6 << 30;
-    if (const char *e = std::getenv("NYQ_BATCH_BYTES")) {
-        const long long v = std::atoll(e);
-        if (v > 0) budget = (size_t)v;
-    }
+    const size_t budget = stagingBudget_;
     std::vector<std::vector<size_t>> batches(1);
     {
         std::map<std::pair<int, int>, std::pair<size_t, size_t>> shape;   // (channels, LM) -> (streams, longest)
@@ -833,7 +936,7 @@ void BatchOpusDecoder::decodeImpl(const std::vector<const std::vector<uint8_t> *
         }
     };
     for (const std::vector<size_t> &members : batches) {
-        if (sink)                                          // sample buffers out of the pool (largest first: long files get them)
+        if (sink)                                          // sample buffers out of the pool (capacity kept from earlier calls)
             for (size_t i : members)
                 if (!pool_.empty()) {
                     out[i].pcm = std::move(pool_.back());

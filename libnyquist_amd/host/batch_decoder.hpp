@@ -60,6 +60,8 @@ public:
     void decode(const std::vector<const std::vector<uint8_t> *> &files, const StreamSink &sink, BatchStats *stats = nullptr,
                 int threads = 0);
     int deviceCount() const { return (int)devices_.size(); }
+    // page-locked staging memory a sub-batch may use (default 6 GiB, or NYQ_BATCH_BYTES as it stood at construction)
+    void setStagingBudget(size_t bytes) { if (bytes) stagingBudget_ = bytes; }
 
     // give the page-locked staging memory back if it has grown beyond `keepBytes` (a pooled decoder should not sit
     // on gigabytes of pinned memory after one big job)
@@ -76,6 +78,7 @@ private:
         bool pinned = false;
     };
     std::vector<int> devices_;
+    size_t stagingBudget_ = (size_t)6 << 30;
     std::vector<void *> ctx_;                 // nyq_ctx*, device d's feeders at [d * kFeeders, (d + 1) * kFeeders)
     std::vector<Arena> arenas_;
     std::vector<std::vector<float>> pool_;    // sample buffers of the sink form, capacity kept

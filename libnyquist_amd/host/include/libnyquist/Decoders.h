@@ -76,4 +76,11 @@ void BatchLoad(std::vector<AudioData> &out, const std::vector<std::vector<uint8_
 // (independent streams, no exchange between devices); the results are identical to the one-device call.
 void BatchLoad(std::vector<AudioData> &out, const std::vector<std::vector<uint8_t>> &buffers, const std::vector<int> &devices);
 
+// GPU that NyquistIO::Load / OpusDecoder use (default: NYQ_DEVICE as it stood at the first Load, else 0); < 0 = back to that
+void SetDefaultDevice(int device);
+
+// Diagnostics: decoders (GPU contexts + staging memory) the Load / BatchLoad paths have made and torn down so far.  They
+// are pooled per device list, so a steady state of concurrent Loads makes and destroys none.
+void DecoderPoolCounts(long *created, long *destroyed);
+
 }  // namespace nqr

@@ -1,5 +1,6 @@
 // nqr_surface.cpp -- NyquistIO / OpusDecoder of the plugin surface (reference: src/Common.cpp:33-219,
 // src/OpusDecoder.cpp:39-183), backed by the batched MI355X decode path.
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -25,11 +26,24 @@ void fill(AudioData *d, nyq_host::DecodedStream &s) {
     if (d->samples.empty()) throw std::runtime_error("could not read any data");
 }
 
-int deviceFromEnv() {
-    const char *e = std::getenv("NYQ_DEVICE");
-    return e ? std::atoi(e) : 0;
+// The device of the single-file Load path (the reference has no device argument: its offload uses device 0): set with
+// nqr::SetDefaultDevice, otherwise NYQ_DEVICE as it stood when the FIRST Load ran -- the environment is read once, never
+// again on a decoding path (a host program may change its environment from other threads).
+std::atomic<int> g_defaultDevice{-1};
+int defaultDevice() {
+    int d = g_defaultDevice.load(std::memory_order_acquire);
+    if (d >= 0) return d;
+    static const int fromEnv = [] {
+        const char *e = std::getenv("NYQ_DEVICE");
+        char *end = nullptr;
+        const long v = e ? std::strtol(e, &end, 10) : 0;
+        return (e && end != e && *end == 0 && v >= 0 && v < 1024) ? (int)v : 0;
+    }();
+    return fromEnv;
 }
 }  // namespace
+
+void nqr::SetDefaultDevice(int device) { g_defaultDevice.store(device < 0 ? -1 : device, std::memory_order_release); }
 
 int nqr::GetFormatBitsPerSample(PCMFormat f) {
     switch (f) {
@@ -73,14 +87,25 @@ void nqr::OpusDecoder::LoadFromPath(AudioData *data, const std::string &path) {
     LoadFromBuffer(data, fileBuffer.buffer);
 }
 
-// Decoders (two GPU contexts and the page-locked staging memory each) are kept between calls: a lease takes
-// an idle one of the device or makes one, and hands it back afterwards.  Concurrent Loads from several
-// threads therefore each work on their own decoder; at most two idle ones are kept per device.  The pool is
-// never destroyed (no HIP call from a static destructor after the runtime has shut down).
+// Decoders (GPU contexts and page-locked staging memory) are kept between calls: a lease takes an idle one of the device
+// list or makes one, and hands it back afterwards, so concurrent Loads from several threads each work on their own decoder
+// and repeated Loads do not re-create contexts.  (The reference makes a fresh decoder per Load and shares nothing,
+// src/OpusDecoder.cpp:169-178.)
+//
+// A decoder that is handed back is KEPT, up to kMaxIdle per device list -- as many as any sensible number of loading
+// threads -- and only its staging memory is trimmed: the first two keep up to 512 MB of page-locked memory, the others 32 MB.
+// Round 2 kept two and destroyed every further one on return, i.e. with six loading threads four decoders (24 contexts,
+// 48+ HIP streams, pinned arenas) were torn down and rebuilt per Load while the other threads were inside their GPU calls;
+// the one process abort this project has seen happened in exactly that test.  Teardown beyond kMaxIdle
+// still exists, but is serialised with construction (one at a time, g_lifecycle) and no longer part of the steady state.
+// The pool itself is never destroyed (no HIP call from a static destructor after the runtime has shut down).
 namespace {
+constexpr size_t kMaxIdle = 16;
 struct DecoderPool {
     std::mutex mu;
     std::map<std::vector<int>, std::vector<nyq_host::BatchOpusDecoder *>> idle;   // by device list
+    std::mutex lifecycle;                    // context construction / destruction, one at a time
+    std::atomic<long> created{0}, destroyed{0};
 };
 DecoderPool &decoderPool() {
     static DecoderPool *p = new DecoderPool;
@@ -91,27 +116,42 @@ struct DecoderLease {
     nyq_host::BatchOpusDecoder *dec = nullptr;
     explicit DecoderLease(int d) : DecoderLease(std::vector<int>{d}) {}
     explicit DecoderLease(const std::vector<int> &d) : device(d) {
+        DecoderPool &P = decoderPool();
         {
-            std::lock_guard<std::mutex> lk(decoderPool().mu);
-            auto &v = decoderPool().idle[d];
+            std::lock_guard<std::mutex> lk(P.mu);
+            auto &v = P.idle[d];
             if (!v.empty()) {
                 dec = v.back();
                 v.pop_back();
             }
         }
-        if (!dec) dec = new nyq_host::BatchOpusDecoder(d);
+        if (!dec) {
+            std::lock_guard<std::mutex> lk(P.lifecycle);
+            dec = new nyq_host::BatchOpusDecoder(d);       // (throws: nothing leased, nothing to hand back)
+            P.created++;
+        }
     }
-    ~DecoderLease() {
-        dec->trim((size_t)512 << 20);
+    ~DecoderLease() {                                      // never throws: trim() and the destructor only free
+        DecoderPool &P = decoderPool();
+        size_t ahead;
         {
-            std::lock_guard<std::mutex> lk(decoderPool().mu);
-            auto &v = decoderPool().idle[device];
-            if (v.size() < 2) {
+            std::lock_guard<std::mutex> lk(P.mu);
+            ahead = P.idle[device].size();
+        }
+        if (ahead < kMaxIdle) {
+            dec->trim(ahead < 2 ? (size_t)512 << 20 : (size_t)32 << 20);
+            std::lock_guard<std::mutex> lk(P.mu);
+            auto &v = P.idle[device];
+            if (v.size() < kMaxIdle) {
                 v.push_back(dec);
                 dec = nullptr;
             }
         }
-        delete dec;
+        if (dec) {
+            std::lock_guard<std::mutex> lk(P.lifecycle);
+            delete dec;
+            P.destroyed++;
+        }
     }
     DecoderLease(const DecoderLease &) = delete;
     DecoderLease &operator=(const DecoderLease &) = delete;
@@ -119,10 +159,16 @@ struct DecoderLease {
 }  // namespace
 
 void nqr::OpusDecoder::LoadFromBuffer(AudioData *data, const std::vector<uint8_t> &memory) {
-    DecoderLease lease(deviceFromEnv());
+    DecoderLease lease(defaultDevice());
     std::vector<nyq_host::DecodedStream> out;
     lease.dec->decode({&memory}, out, nullptr, 1);
     fill(data, out[0]);
+}
+
+// decoders made / torn down by the Load paths so far (tests: a steady state of concurrent Loads makes none)
+void nqr::DecoderPoolCounts(long *created, long *destroyed) {
+    if (created) *created = decoderPool().created.load();
+    if (destroyed) *destroyed = decoderPool().destroyed.load();
 }
 
 std::vector<std::string> nqr::OpusDecoder::GetSupportedFileExtensions() { return {"opus"}; }

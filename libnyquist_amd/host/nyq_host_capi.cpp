@@ -4,6 +4,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "batch_decoder.hpp"
@@ -12,6 +14,8 @@
 #include "opus_stream.hpp"
 
 using namespace nyq_host;
+
+static thread_local std::string g_capi_err;
 
 extern "C" {
 
@@ -98,7 +102,8 @@ long nyqh_nyquistio_load(const char *path, float *samples, long capacity, long *
         return (long)data.samples.size();
     } catch (const nqr::UnsupportedExtensionEx &) {
         return -2;
-    } catch (const std::exception &) {
+    } catch (const std::exception &e) {
+        g_capi_err = e.what();
         return -1;
     }
 }
@@ -119,7 +124,8 @@ long nyqh_nyquistio_load_buffer(const unsigned char *file, long size, float *sam
         return (long)data.samples.size();
     } catch (const nqr::UnsupportedExtensionEx &) {
         return -2;
-    } catch (const std::exception &) {
+    } catch (const std::exception &e) {
+        g_capi_err = e.what();
         return -1;
     }
 }
@@ -131,20 +137,29 @@ static std::mutex g_capi_mu;
 static nyq_host::BatchOpusDecoder *g_capi_dec = nullptr;
 static std::vector<int> g_capi_devs;
 
-// devices from NYQ_DEVICES ("0,1,2": one decoder over several GPUs) or NYQ_DEVICE (one), default device 0
-static std::vector<int> capiDevices() {
+// devices from NYQ_DEVICES ("0,1,2": one decoder over several GPUs) or NYQ_DEVICE (one), default device 0.  These entry
+// points exist for the tests and tools, which set the variables before a call; anything that is not a list of
+// non-negative integers is an error, not device 0.
+static std::vector<int> parseDeviceList(const char *e) {
     std::vector<int> v;
-    if (const char *e = std::getenv("NYQ_DEVICES")) {
-        for (const char *p = e; *p;) {
-            v.push_back(std::atoi(p));
-            while (*p && *p != ',') p++;
-            if (*p == ',') p++;
-        }
-    } else if (const char *e1 = std::getenv("NYQ_DEVICE")) {
-        v.push_back(std::atoi(e1));
+    for (const char *p = e; *p;) {
+        char *end = nullptr;
+        const long d = std::strtol(p, &end, 10);
+        if (end == p || d < 0 || d > 1023) throw std::runtime_error(std::string("bad device list: ") + e);
+        v.push_back((int)d);
+        p = end;
+        if (*p == ',') { p++; if (!*p) throw std::runtime_error(std::string("bad device list: ") + e); }
+        else if (*p) throw std::runtime_error(std::string("bad device list: ") + e);
     }
-    if (v.empty()) v.push_back(0);
+    if (v.empty()) throw std::runtime_error("empty device list");
     return v;
+}
+static std::vector<int> g_capi_devs_set;                       // nyqh_set_devices: overrides the environment (guarded by g_capi_mu)
+static std::vector<int> capiDevices() {
+    if (!g_capi_devs_set.empty()) return g_capi_devs_set;
+    if (const char *e = std::getenv("NYQ_DEVICES")) return parseDeviceList(e);
+    if (const char *e1 = std::getenv("NYQ_DEVICE")) return parseDeviceList(e1);
+    return {0};
 }
 
 static nyq_host::BatchOpusDecoder &capiDecoder() {               // call with g_capi_mu held
@@ -187,7 +202,8 @@ long nyqh_batch_decode_timed(const unsigned char *file, long size, long count, i
         stats[4] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         stats[5] = (double)dec.deviceCount();
         return nsamp;
-    } catch (const std::exception &) {
+    } catch (const std::exception &e) {
+        g_capi_err = e.what();
         return -1;
     }
 }
@@ -231,9 +247,60 @@ long nyqh_batch_decode_files(const unsigned char *const *files, const long *size
                 }
         }
         return total;
-    } catch (const std::exception &) {
+    } catch (const std::exception &e) {
+        g_capi_err = e.what();
         return -1;
     }
 }
+
+// nqr::BatchLoad(out, buffers, devices) through the plugin surface: a batch of different files over a device LIST
+// (a device may appear more than once: {0, 0} runs two device shards -- two sets of feeders, contexts and staging
+// arenas -- on one GPU).  Outputs as nyqh_batch_decode_files; returns the total sample count, -1 if the call threw
+// (one failing file makes BatchLoad throw after the others have been decoded, as documented in Decoders.h).
+long nyqh_batch_load_devices(const unsigned char *const *files, const long *sizes, long count, const int *devices, int ndevices,
+                             long *nsamples, float *out, long capacity) {
+    try {
+        std::vector<std::vector<uint8_t>> bufs((size_t)count);
+        for (long i = 0; i < count; i++) bufs[i].assign(files[i], files[i] + sizes[i]);
+        std::vector<nqr::AudioData> res;
+        nqr::BatchLoad(res, bufs, std::vector<int>(devices, devices + ndevices));
+        long total = 0;
+        for (long i = 0; i < count; i++) {
+            nsamples[i] = (long)res[i].samples.size();
+            total += nsamples[i];
+        }
+        if (out && capacity >= total) {
+            long pos = 0;
+            for (long i = 0; i < count; i++) {
+                std::memcpy(out + pos, res[i].samples.data(), (size_t)nsamples[i] * sizeof(float));
+                pos += nsamples[i];
+            }
+        }
+        return total;
+    } catch (const std::exception &e) {
+        g_capi_err = e.what();
+        return -1;
+    }
+}
+
+// device count of the decoder the batch entry points above are using right now (0: none made yet)
+int nyqh_capi_device_count(void) {
+    std::lock_guard<std::mutex> lk(g_capi_mu);
+    return g_capi_dec ? g_capi_dec->deviceCount() : 0;
+}
+
+void nyqh_set_default_device(int device) { nqr::SetDefaultDevice(device); }
+
+// device list of the batch entry points above from now on (instead of NYQ_DEVICES / NYQ_DEVICE); n = 0: back to the environment
+void nyqh_set_devices(const int *devices, int n) {
+    std::lock_guard<std::mutex> lk(g_capi_mu);
+    g_capi_devs_set.assign(devices, devices + (n > 0 ? n : 0));
+}
+
+// counts[0] = decoders made, counts[1] = decoders torn down by the NyquistIO::Load / BatchLoad paths so far
+void nyqh_decoder_pool_counts(long *counts) { nqr::DecoderPoolCounts(&counts[0], &counts[1]); }
+
+// text of the last exception one of these entry points swallowed on the calling thread
+const char *nyqh_last_error(void) { return g_capi_err.c_str(); }
 
 }  // extern "C"

@@ -18,6 +18,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "perf: wall-clock guards, outside the parity tier (run with -m perf on the GPU box)")
 
 
 # The 2-rank rehearsal of bench.py (tests/test_sharding.py::test_bench_two_ranks_on_one_gpu) has to be STARTED before this
@@ -39,8 +40,7 @@ def pytest_sessionstart(session):
     except Exception:
         return
     port = 29600 + (os.getpid() % 300)
-    REHEARSAL["out"] = open(os.path.join(ROOT, "gpurun_out", "rehearsal_stdout.txt") if os.path.isdir(os.path.join(ROOT, "gpurun_out"))
-                            else os.path.join("/tmp", "nyq_rehearsal_stdout.txt"), "w+")
+    REHEARSAL["out"] = open(os.path.join("/tmp", "nyq_rehearsal_stdout.txt"), "w+")
     REHEARSAL["err"] = open(os.path.join("/tmp", "nyq_rehearsal_stderr.txt"), "w+")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     REHEARSAL["proc"] = subprocess.Popen(

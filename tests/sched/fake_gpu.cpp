@@ -20,17 +20,34 @@ struct nyq_ctx {
 // every call is counted against its context's device (fake_gpu_calls) so that a test can see the sharding.
 static constexpr int kFakeDevices = 4;
 static std::atomic<long> g_calls[kFakeDevices];
+static std::atomic<long> g_created{0}, g_destroyed{0}, g_live{0}, g_allCalls{0};
+// fault injection: every g_failCallEvery-th GPU call / every g_failCreateEvery-th context creation fails (0 = never)
+static std::atomic<long> g_failCallEvery{0}, g_failCreateEvery{0};
 
 extern "C" {
 
 long fake_gpu_calls(int device) { return device >= 0 && device < kFakeDevices ? g_calls[device].load() : -1; }
+void fake_gpu_counts(long *created, long *destroyed, long *live) { *created = g_created; *destroyed = g_destroyed; *live = g_live; }
+void fake_gpu_fail_every(long calls, long creates) { g_failCallEvery = calls; g_failCreateEvery = creates; }
+
+int nyq_device_count(void) { return kFakeDevices; }
 
 int nyq_ctx_create(nyq_ctx **out, int device) {
     if (device < 0 || device >= kFakeDevices) return NYQ_ERR_NO_DEVICE;
+    static std::atomic<long> attempts{0};
+    const long n = ++attempts, every = g_failCreateEvery.load();
+    if (every > 0 && n % every == 0) return NYQ_ERR_HIP;           // an injected failure of context creation
+    g_created++;
+    g_live++;
     *out = new nyq_ctx{device};
     return NYQ_OK;
 }
-void nyq_ctx_destroy(nyq_ctx *c) { delete c; }
+void nyq_ctx_destroy(nyq_ctx *c) {
+    if (!c) return;
+    g_destroyed++;
+    g_live--;
+    delete c;
+}
 const char *nyq_last_error(const nyq_ctx *) { return "fake"; }
 void *nyq_host_alloc(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
 void nyq_host_free(void *p) { std::free(p); }
@@ -45,6 +62,8 @@ int nyq_celt_frames_to_pcm_window(nyq_ctx *ctx, int LM, const float *freq, const
                                   size_t nframes, int channels, size_t frames_per_stream) {
     const size_t N = (size_t)120 << LM, nsc = nstreams * channels;
     g_calls[ctx->device]++;
+    const long ncall = ++g_allCalls, every = g_failCallEvery.load();
+    if (every > 0 && ncall % every == 0) return NYQ_ERR_HIP;      // an injected device failure
     for (size_t s = 0; s < nstreams; s++)
         for (int c = 0; c < channels; c++) {
             // the running state lives where the real overlap state lives: first float of the stream-channel's 60

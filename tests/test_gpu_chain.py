@@ -19,7 +19,18 @@ def ctx():
     c.close()
 
 
-def _run_chain(ctx, lm, freq, tr, pitch, gain, taps, pst, ov, hist, dm, ch, fused):
+@pytest.fixture(scope="module")
+def ctx_ab():
+    """a context of the tools' A/B build (tools/libnyq_imdct_ab.so, -DNYQ_AB_FORMS): the only build that has the fused
+    chain kernel; the product library answers NYQ_ERR_INVALID to NYQ_OPT_CHAIN_FUSED = 1"""
+    import libnyquist_amd as nyq
+    c = nyq.Context(0, ab=True)
+    yield c
+    c.close()
+
+
+def _run_chain(ctx, lm, freq, tr, pitch, gain, taps, pst, ov, hist, dm, ch, fused, window=0):
+    import libnyquist_amd as nyq
     import torch
     dev = torch.device("cuda", 0)
     T = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dt)).to(dev)
@@ -34,14 +45,18 @@ def _run_chain(ctx, lm, freq, tr, pitch, gain, taps, pst, ov, hist, dm, ch, fuse
     d_pcm = torch.empty((ns * ch, nf * n), device=dev)
     d_work = torch.empty(ctx.celt_synth_work_floats(ns, nf, ch), device=dev)
     torch.cuda.synchronize(dev)
-    os.environ["NYQ_CHAIN_FUSED"] = "1" if fused else "0"
+    if fused:
+        ctx.set_option(nyq.binding.OPT_CHAIN_FUSED, 1)
+    ctx.set_option(nyq.binding.OPT_CHAIN_WINDOW, window)
     try:
         ctx.celt_chain_dev(lm, d_freq.data_ptr(), d_tr.data_ptr(), d_pp.data_ptr(), d_pg.data_ptr(), d_pt.data_ptr(), d_si.data_ptr(),
                            d_so.data_ptr(), d_ov.data_ptr(), d_h.data_ptr(), d_m.data_ptr(), d_out.data_ptr(), d_pcm.data_ptr(),
                            d_work.data_ptr(), ns, nf, ch)
         ctx.synchronize()
     finally:
-        del os.environ["NYQ_CHAIN_FUSED"]
+        if fused:
+            ctx.set_option(nyq.binding.OPT_CHAIN_FUSED, 0)
+        ctx.set_option(nyq.binding.OPT_CHAIN_WINDOW, 0)
     return d_out.cpu().numpy(), d_so.cpu().numpy(), d_ov.cpu().numpy(), d_h.cpu().numpy(), d_m.cpu().numpy()
 
 
@@ -63,17 +78,18 @@ def _case(rng, ns, nf, ptr, ch=2, lm=3):
 
 
 @pytest.mark.parametrize("ns,nf,ptr", [(1, 1, 0.0), (1, 2, 1.0), (2, 3, 0.5), (3, 17, 0.1), (5, 40, 0.03), (8, 33, 1.0), (33, 20, 0.3)])
-def test_fused_chain_vs_oracle_and_two_kernel_chain(ctx, oracle, ns, nf, ptr):
+def test_fused_chain_vs_oracle_and_two_kernel_chain(ctx, ctx_ab, oracle, ns, nf, ptr):
     """The fused launch against the oracle (synthesis, then post-filter + de-emphasis) and, bit for bit, against the
     two-kernel chain: same lane program, same recursion, same order of operations."""
     ctx.set_tables(*oracle.tables()[:2])
+    ctx_ab.set_tables(*oracle.tables()[:2])
     rng = np.random.default_rng(4200 + ns * 100 + nf)
     freq, tr, pitch, gain, taps, pst, ov, hist, dm = _case(rng, ns, nf, ptr)
     ch, n = 2, 960
     wp, ws = oracle.celt_synth(3, freq, tr, ov, nthreads=4)
     want, filt, wst, wdm = oracle.celt_post(3, np.concatenate([hist.reshape(ns, ch, 1088), wp.reshape(ns, ch, nf * n)], axis=2), 1088,
                                             pitch, gain, taps, pst, dm)
-    out, gst, gov, gh, gdm = _run_chain(ctx, 3, freq, tr, pitch, gain, taps, pst, ov, hist, dm, ch, fused=True)
+    out, gst, gov, gh, gdm = _run_chain(ctx_ab, 3, freq, tr, pitch, gain, taps, pst, ov, hist, dm, ch, fused=True)
     assert rel_rms(out, want) <= 1e-5, (ns, nf, ptr)
     assert np.array_equal(gst, wst)
     assert rel_rms(gov, ws) <= 1e-6
@@ -86,10 +102,11 @@ def test_fused_chain_vs_oracle_and_two_kernel_chain(ctx, oracle, ns, nf, ptr):
 
 
 @pytest.mark.parametrize("fused,lm,h", [(True, 3, 11), (False, 3, 11), (False, 3, 1), (False, 2, 7), (False, 1, 5), (False, 0, 3)])
-def test_chain_continues_from_its_own_state(ctx, oracle, fused, lm, h):
+def test_chain_continues_from_its_own_state(ctx, ctx_ab, oracle, fused, lm, h):
     """Two calls with the state of the first handed to the second == one call over both halves -- the fused kernel and the
     shipped two-kernel chain (whose post-filter keeps 1040 samples of history in LDS and assembles the 1088 of the
     hand-over from both of its buffers), every frame size, a first call as short as one frame."""
+    ctx = ctx_ab if fused else ctx
     ctx.set_tables(*oracle.tables()[:2])
     rng = np.random.default_rng(77 + lm)
     ns, nf = 6, 24
@@ -111,8 +128,9 @@ def test_chain_continues_from_its_own_state(ctx, oracle, fused, lm, h):
             assert rel_rms(x, y) <= 1e-6
 
 
-def test_other_shapes_run_the_two_kernel_chain(ctx, oracle):
+def test_other_shapes_run_the_two_kernel_chain(ctx_ab, oracle):
     """Frame sizes / channel counts the fused kernel does not cover go through synth + post inside the same entry."""
+    ctx = ctx_ab
     ctx.set_tables(*oracle.tables()[:2])
     rng = np.random.default_rng(5)
     for lm, ch in ((2, 2), (3, 1), (0, 3)):
@@ -126,47 +144,58 @@ def test_other_shapes_run_the_two_kernel_chain(ctx, oracle):
         assert np.array_equal(gst, wst)
 
 
-def test_post_filter_kernel_is_placed_at_once_behind_other_kernels(ctx):
-    """The post-filter pipeline's workgroups live for the whole launch; with a register / LDS footprint that fits a CU
-    exactly, some of them were placed 0.8 ms late whenever another kernel had run before (1.6 instead of 1.0 ms,
-    DESIGN 4.4a).  Guard: the kernel behind a synthesis call must not take much longer than behind itself."""
-    import torch
-    from conftest import REHEARSAL
-    if REHEARSAL["proc"] is not None:                          # (a timing comparison: not beside the two-rank rehearsal)
-        REHEARSAL["proc"].wait(timeout=600)
-    dev = torch.device("cuda", 0)
-    ns, nf, ch, n = 1024, 64, 2, 960
-    g = torch.Generator(device=dev)
-    g.manual_seed(11)
-    freq = torch.randn((ns, nf, ch, n), generator=g, device=dev) * 30.0
-    trans = (torch.rand((ns, nf), generator=g, device=dev) < 0.028).to(torch.uint8)
-    pitch = torch.randint(15, 80, (ns, nf), generator=g, device=dev, dtype=torch.int32)
-    gain = (torch.rand((ns, nf), generator=g, device=dev) < 0.7).float() * (torch.randint(1, 9, (ns, nf), generator=g, device=dev) * 0.09375).float()
-    tap = torch.randint(0, 3, (ns, nf), generator=g, device=dev, dtype=torch.int32)
-    out = torch.empty((ns, nf * n, ch), device=dev)
-    pcm = torch.empty((ns * ch, nf * n), device=dev)
-    work = torch.empty(ctx.celt_synth_work_floats(ns, nf, ch), device=dev)
-    stream = torch.cuda.current_stream(dev)
-    ctx.set_stream(stream.cuda_stream)
-    try:
-        def synth():
-            ctx.celt_synth_dev(3, freq.data_ptr(), trans.data_ptr(), pcm.data_ptr(), 0, work.data_ptr(), ns, nf, ch)
+def test_product_build_refuses_the_ab_forms(ctx):
+    """The measured-and-rejected kernel forms are not in the product library: asking for them is an error, not a silent
+    fallback, and nothing is chosen through the process environment any more."""
+    import libnyquist_amd as nyq
+    assert ctx.lib.nyq_ab_forms_built() == 0
+    with pytest.raises(nyq.NyqError):
+        ctx.set_option(nyq.binding.OPT_CHAIN_FUSED, 1)
+    with pytest.raises(nyq.NyqError):
+        ctx.set_option(nyq.binding.OPT_POST_FORM, nyq.binding.POST_FORM_WAVE_PER_CHANNEL)
+    ctx.set_option(nyq.binding.OPT_POST_FORM, nyq.binding.POST_FORM_PIPELINE)
+    assert ctx.get_option(nyq.binding.OPT_CHAIN_FUSED) == 0
 
-        def post_ms(before):
-            ts = []
-            for _ in range(7):
-                before()
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(stream)
-                ctx.celt_post_dev(3, pcm.data_ptr(), pitch.data_ptr(), gain.data_ptr(), tap.data_ptr(), 0, 0, 0, 0, out.data_ptr(), ns, nf, ch)
-                b.record(stream)
-                torch.cuda.synchronize(dev)
-                ts.append(a.elapsed_time(b))
-            return float(np.median(ts))
-        synth()
-        post_ms(lambda: None)
-        alone = post_ms(lambda: None)
-        behind = post_ms(synth)
-        assert behind <= 1.3 * alone, (alone, behind)
-    finally:
-        ctx.reset_stream()
+
+@pytest.mark.parametrize("lm,ch,ns,nf,window,with_state", [(3, 2, 5, 200, 64, True), (3, 2, 3, 131, 64, False), (2, 1, 4, 300, 128, True),
+                                                          (1, 2, 3, 257, 64, False), (0, 3, 2, 330, 64, True), (3, 2, 2, 128, 64, True)])
+def test_windowed_chain_is_bit_identical_to_one_window(ctx, oracle, lm, ch, ns, nf, window, with_state):
+    """nyq_celt_chain_dev over time windows (NYQ_OPT_CHAIN_WINDOW: synthesis and post-filter alternate over windows of 64 k
+    frames, the time-domain frames of a window living in the first part of d_pcm only): the samples and every piece of
+    decoder state equal the one-window call bit for bit -- with the caller's state buffers and, where the caller passes
+    none (fresh decoder), through the temporaries carved from d_work -- and the oracle within 1e-5."""
+    import libnyquist_amd as nyq
+    import torch
+    ctx.set_tables(*oracle.tables()[:2])
+    rng = np.random.default_rng(31 * lm + nf)
+    n = 120 << lm
+    freq, tr, pitch, gain, taps, pst, ov, hist, dm = _case(rng, ns, nf, 0.05, ch=ch, lm=lm)
+    if with_state:
+        one = _run_chain(ctx, lm, freq, tr, pitch, gain, taps, pst, ov, hist, dm, ch, fused=False, window=0)
+        win = _run_chain(ctx, lm, freq, tr, pitch, gain, taps, pst, ov, hist, dm, ch, fused=False, window=window)
+        for a, b in zip(one, win):
+            assert np.array_equal(a, b)
+        wp, ws = oracle.celt_synth(lm, freq, tr, ov, nthreads=4)
+        want, filt, wst, wdm = oracle.celt_post(lm, np.concatenate([hist.reshape(ns, ch, 1088), wp.reshape(ns, ch, nf * n)], axis=2), 1088,
+                                                pitch, gain, taps, pst, dm)
+        assert rel_rms(win[0], want) <= 1e-5 and np.array_equal(win[1], wst)
+        return
+    dev = torch.device("cuda", 0)
+    T = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dt)).to(dev)
+    d_freq, d_tr = T(freq, np.float32), T(tr, np.uint8)
+    d_pp, d_pg, d_pt = T(pitch, np.int32), T(gain, np.float32), T(taps, np.int32)
+    outs = []
+    for w in (0, window):
+        d_out = torch.zeros((ns, nf * n, ch), device=dev)
+        d_pcm = torch.empty((ns * ch, nf * n), device=dev)
+        d_work = torch.empty(ctx.celt_synth_work_floats(ns, nf, ch), device=dev)
+        torch.cuda.synchronize(dev)
+        ctx.set_option(nyq.binding.OPT_CHAIN_WINDOW, w)
+        try:
+            ctx.celt_chain_dev(lm, d_freq.data_ptr(), d_tr.data_ptr(), d_pp.data_ptr(), d_pg.data_ptr(), d_pt.data_ptr(), 0, 0, 0, 0, 0,
+                               d_out.data_ptr(), d_pcm.data_ptr(), d_work.data_ptr(), ns, nf, ch)
+            ctx.synchronize()
+        finally:
+            ctx.set_option(nyq.binding.OPT_CHAIN_WINDOW, 0)
+        outs.append(d_out.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])

@@ -294,6 +294,60 @@ def test_mixed_batch_every_file_as_if_decoded_alone(host):
 
 
 @pytest.mark.gpu
+def test_two_device_shards_on_one_gpu_equal_the_one_device_batch(host):
+    """The real multi-device path on hardware: a device LIST {0, 0} makes two device shards -- two sets of six feeder
+    threads and contexts, two page-locked staging arenas, streams dealt s mod 2 -- on the box's one GPU, through both
+    entry points (nyqh_batch_decode_files with the list set, and nqr::BatchLoad(out, buffers, {0, 0})).  Every file must
+    equal NyquistIO::Load of that file alone bit for bit, the decoder must report two devices, and a list with a device
+    that does not exist must be refused up front."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(GOLDEN, "corpus", "*.opus"))) + [os.path.join(GOLDEN, "short.opus")]
+    paths = [p for p in paths if "unsupported_" not in p]
+    paths = paths + paths[::3] + [os.path.join(GOLDEN, "short.opus")] * 3
+    raws = [open(p, "rb").read() for p in paths]
+    info = np.zeros(8, np.int64)
+    alone = []
+    for r in raws:
+        n = host.nyqh_nyquistio_load_buffer(r, len(r), None, 0, info)
+        a = np.zeros(n, np.float32)
+        assert host.nyqh_nyquistio_load_buffer(r, len(r), a.ctypes.data_as(C.c_void_p), n, info) == n
+        alone.append(a)
+    cnt = len(raws)
+    files = (C.c_char_p * cnt)(*raws)
+    sizes = (C.c_long * cnt)(*[len(r) for r in raws])
+    ns = (C.c_long * cnt)()
+    cap = sum(a.size for a in alone)
+
+    def check(out):
+        pos = 0
+        for i, a in enumerate(alone):
+            assert ns[i] == a.size, paths[i]
+            assert np.array_equal(out[pos:pos + a.size], a), paths[i]
+            pos += a.size
+
+    two = (C.c_int * 2)(0, 0)
+    host.nyqh_set_devices(two, 2)
+    try:
+        out = np.zeros(cap, np.float32)
+        assert host.nyqh_batch_decode_files(files, sizes, cnt, 8, ns, out.ctypes.data_as(C.c_void_p), cap) == cap, host.nyqh_last_error()
+        assert host.nyqh_capi_device_count() == 2
+        check(out)
+        raw = open(os.path.join(GOLDEN, "short.opus"), "rb").read()
+        first, last = np.zeros(421930, np.float32), np.zeros(421930, np.float32)
+        stats = np.zeros(6, np.float64)
+        assert host.nyqh_batch_decode_timed(raw, len(raw), 64, 8, first.ctypes.data_as(C.c_void_p), last.ctypes.data_as(C.c_void_p), 421930, stats) == 421930
+        assert stats[5] == 2 and np.array_equal(first, last)
+    finally:
+        host.nyqh_set_devices(two, 0)
+    out = np.zeros(cap, np.float32)
+    assert host.nyqh_batch_load_devices(files, sizes, cnt, two, 2, ns, out.ctypes.data_as(C.c_void_p), cap) == cap, host.nyqh_last_error()
+    check(out)
+    bad = (C.c_int * 2)(0, 97)
+    assert host.nyqh_batch_load_devices(files, sizes, cnt, bad, 2, ns, None, 0) == -1
+    assert b"does not exist" in host.nyqh_last_error()
+
+
+@pytest.mark.gpu
 def test_concurrent_loads_from_several_threads(host):
     """NyquistIO::Load from six host threads at once (each call leases its own decoder = its own GPU contexts and
     staging memory from the per-device pool): same samples as the sequential loads."""
@@ -319,9 +373,16 @@ def test_concurrent_loads_from_several_threads(host):
                 if n != want[k].size or not np.array_equal(out, want[k]):
                     errors.append((tid, rep, paths[k]))
 
+    counts = (C.c_long * 2)()
+    host.nyqh_decoder_pool_counts(counts)
+    made0, gone0 = counts[0], counts[1]
     threads = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
     for t in threads:
         t.start()
     for t in threads:
         t.join()
     assert not errors, errors[:5]
+    # decoders are pooled: six loading threads make at most six decoders between them and tear none down (round 2 tore
+    # down and rebuilt four of them -- 24 contexts -- per Load while the other threads were inside their GPU calls)
+    host.nyqh_decoder_pool_counts(counts)
+    assert counts[0] - made0 <= 6 and counts[1] - gone0 == 0, (counts[0] - made0, counts[1] - gone0)

@@ -623,8 +623,17 @@ def test_frames_to_pcm_window_slices_equal_one_call(ctx, oracle):
                                                       ns, 64, ch, 32))
 
 
+@pytest.fixture(scope="module")
+def ctx_ab():
+    """context of the tools' A/B build (tools/libnyq_imdct_ab.so): the product's kernels plus the round-1 post-filter forms"""
+    import libnyquist_amd as nyq
+    c = nyq.Context(0, ab=True)
+    yield c
+    c.close()
+
+
 @pytest.mark.parametrize("seed", range(16))
-def test_random_shapes_synth_then_post_vs_oracle(ctx, oracle, seed):
+def test_random_shapes_synth_then_post_vs_oracle(ctx, ctx_ab, oracle, seed):
     """Randomised shapes through both GPU stages against the oracle: frame size, channel count, stream and frame
     counts (around the kernels' group / chain / slice boundaries), transient density, incoming state, post-filter
     parameters with short periods and switched-off frames, both stereo post-filter modes."""
@@ -654,12 +663,19 @@ def test_random_shapes_synth_then_post_vs_oracle(ctx, oracle, seed):
     pst = np.stack([[rng.integers(15, 1023), rng.integers(15, 1023), 0.28125, 0.375, 1, 2] for _ in range(ns)]).astype(np.float32)
     dm = (rng.standard_normal(ns * ch) * 10).astype(np.float32)
     want, filt, wst, wdm = oracle.celt_post(lm, np.concatenate([hist, wp.reshape(ns, ch, nf * n)], axis=2), 1088, pitch, gain, taps, pst, dm)
-    for mode in (("0", "1", "2") if ch == 2 else ("0", "2")):     # wave per channel, per stereo pair, workgroup pipeline
-        os.environ["NYQ_POST_STEREO_PAIRS"] = mode
+    import libnyquist_amd as nyq
+    B = nyq.binding
+    ctx_ab.set_tables(*oracle.tables()[:2])
+    # the product's one form (workgroup pipeline) on the product library, then the A/B build's three forms
+    forms = [(ctx, B.POST_FORM_PIPELINE), (ctx_ab, B.POST_FORM_PIPELINE), (ctx_ab, B.POST_FORM_WAVE_PER_CHANNEL)]
+    if ch == 2:
+        forms.append((ctx_ab, B.POST_FORM_WAVE_PER_PAIR))
+    for cx, mode in forms:
+        cx.set_option(B.OPT_POST_FORM, mode)
         try:
-            out, gst, gh, gdm = _post_on_gpu(ctx, lm, wp.reshape(ns, ch, nf * n), pitch, gain, taps, pst, hist.reshape(ns * ch, 1088), dm, ch)
+            out, gst, gh, gdm = _post_on_gpu(cx, lm, wp.reshape(ns, ch, nf * n), pitch, gain, taps, pst, hist.reshape(ns * ch, 1088), dm, ch)
         finally:
-            del os.environ["NYQ_POST_STEREO_PAIRS"]
+            cx.set_option(B.OPT_POST_FORM, B.POST_FORM_PIPELINE)
         assert rel_rms(out, want) <= 1e-5, (lm, ch, ns, nf, mode)
         assert np.array_equal(gst, wst)
         assert rel_rms(gh, filt[:, :, -1088:].reshape(ns * ch, 1088)) <= 1e-5

@@ -38,6 +38,17 @@ def load_host():
     H.nyqh_batch_decode_timed.restype = C.c_long
     H.nyqh_batch_decode_files.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_long), C.c_long, C.c_int, C.POINTER(C.c_long), C.c_void_p, C.c_long]
     H.nyqh_batch_decode_files.restype = C.c_long
+    H.nyqh_batch_load_devices.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_long), C.c_long, C.POINTER(C.c_int), C.c_int,
+                                          C.POINTER(C.c_long), C.c_void_p, C.c_long]
+    H.nyqh_batch_load_devices.restype = C.c_long
+    H.nyqh_capi_device_count.restype = C.c_int
+    H.nyqh_set_default_device.argtypes = [C.c_int]
+    H.nyqh_set_default_device.restype = None
+    H.nyqh_set_devices.argtypes = [C.POINTER(C.c_int), C.c_int]
+    H.nyqh_set_devices.restype = None
+    H.nyqh_decoder_pool_counts.argtypes = [C.POINTER(C.c_long)]
+    H.nyqh_decoder_pool_counts.restype = None
+    H.nyqh_last_error.restype = C.c_char_p
     return H
 
 

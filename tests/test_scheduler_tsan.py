@@ -66,3 +66,27 @@ def test_damaged_files_under_address_sanitizer():
     assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
     assert r.returncode == 0, (r.returncode, r.stderr[-1500:])
     assert "120 iterations" in r.stdout
+
+
+LEASE_FILES = ["corpus/st_20ms_32k.opus", "corpus/mono_5ms_64k.opus", "corpus/surround51_10ms_192k.opus",
+               "corpus/twosize_st_20ms_then_10ms_10s.opus", "short.opus", "corpus/st_2p5ms_128k.opus"]
+
+
+@pytest.mark.parametrize("san", ["tsan", "asan"])
+@pytest.mark.parametrize("mode,threads,reps,files", [("plain", 6, 3, LEASE_FILES), ("gpu-faults", 6, 3, LEASE_FILES),
+                                                     ("thread-faults", 6, 3, LEASE_FILES), ("churn", 22, 2, LEASE_FILES[:2])])
+def test_concurrent_loads_lease_pool(san, mode, threads, reps, files):
+    """Six threads inside nqr::NyquistIO::Load at once -- the situation of the one process abort seen on a GPU box
+     -- against the fake GPU: the real plugin surface, lease pool, scheduler and entropy decoder under
+    ThreadSanitizer and AddressSanitizer.  plain: bit-exact, no decoder torn down; gpu-faults: every 29th GPU call and every
+    17th context creation fail -> std::runtime_error out of Load, nothing else, survivors bit-exact, no context leaked;
+    thread-faults: thread starts fail on and off -> the batch runs on the threads it gets or throws, no joinable thread is
+    ever destroyed (that is std::terminate -> abort); churn: 22 threads against a pool of 16 -> decoders are torn down
+    beside running ones, still bit-exact."""
+    subprocess.run(["make", "-C", SCHED, "lease"], check=True, stdout=subprocess.DEVNULL)
+    e = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66")
+    r = subprocess.run([os.path.join(SCHED, f"lease_check_{san}"), mode, str(threads), str(reps)] + [os.path.join(GOLDEN, f) for f in files],
+                       env=e, capture_output=True, text=True, timeout=900)
+    assert "ThreadSanitizer" not in r.stderr and "AddressSanitizer" not in r.stderr and "runtime error:" not in r.stderr, r.stderr[-3000:]
+    assert r.returncode == 0, (r.returncode, r.stdout[-800:], r.stderr[-1500:])
+    assert r.stdout.strip().endswith("OK"), r.stdout[-800:]

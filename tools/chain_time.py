@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Time the frames -> PCM chain (nyq_celt_chain_dev) fused vs as two kernels, same process, interleaved; HIP events on
-the operator's stream.  usage: chain_time.py [nstreams] [nframes] [mix|short|long|off|real]"""
+the operator's stream.  usage: chain_time.py [nstreams] [nframes] [mix|short|long|off|real]
+CHAIN_SPLIT=1: the two stages alone next to the chain; CHAIN_WINDOWS="0,64,128": the two-kernel chain of the PRODUCT library
+over time windows of that many frames (NYQ_OPT_CHAIN_WINDOW; 0 = one window), interleaved, medians.
+The fused kernel and the round-1 post-filter form exist only in the tools' A/B build, which this tool loads."""
 import json
 import os
 import sys
@@ -14,7 +17,8 @@ ns = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 nf = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 case = sys.argv[3] if len(sys.argv) > 3 else "mix"
 dev = torch.device("cuda", 0)
-ctx = nyq.Context(0)
+ctx = nyq.Context(0, ab=os.environ.get('CHAIN_WINDOWS') is None)   # A/B build unless the product's windowed chain is what is timed
+B = nyq.binding
 stream = torch.cuda.Stream(dev)
 torch.cuda.set_stream(stream)
 ctx.set_stream(stream.cuda_stream)
@@ -66,7 +70,6 @@ def timed(fn, reps=10):
 
 if os.environ.get("CHAIN_SPLIT") == "1":
     # the two stages timed alone (loops of 10 of the same launch) next to the chain timed as a unit
-    os.environ["NYQ_CHAIN_FUSED"] = "0"
     t_s = timed(lambda: ctx.celt_synth_dev(3, freq.data_ptr(), trans.data_ptr(), pcm.data_ptr(), state.data_ptr() if WITH_STATE else 0,
                                            work.data_ptr(), ns, nf, ch))
     t_p = timed(lambda: ctx.celt_post_dev(3, pcm.data_ptr(), pitch.data_ptr(), gain.data_ptr(), tap.data_ptr(), 0, 0, 0, 0, out.data_ptr(), ns, nf, ch))
@@ -89,10 +92,10 @@ if os.environ.get("CHAIN_SPLIT") == "1":
             ctx.celt_post_dev(3, pcm.data_ptr(), pitch.data_ptr(), gain.data_ptr(), tap.data_ptr(), 0, 0, 0, 0, out.data_ptr(), ns, nf, ch)
         return f
     extra = {w: timed(with_tiny(w)) for w in ("before_synth", "between")}
-    os.environ["NYQ_POST_STEREO_PAIRS"] = "0"
+    ctx.set_option(B.OPT_POST_FORM, B.POST_FORM_WAVE_PER_CHANNEL)
     extra["two_calls_with_round1_post_kernel"] = timed(two_calls)
     extra["round1_post_kernel_alone"] = timed(lambda: ctx.celt_post_dev(3, pcm.data_ptr(), pitch.data_ptr(), gain.data_ptr(), tap.data_ptr(), 0, 0, 0, 0, out.data_ptr(), ns, nf, ch))
-    del os.environ["NYQ_POST_STEREO_PAIRS"]
+    ctx.set_option(B.OPT_POST_FORM, B.POST_FORM_PIPELINE)
     print(json.dumps(extra))
     state.zero_()
     t_c0 = timed(run)
@@ -101,12 +104,37 @@ if os.environ.get("CHAIN_SPLIT") == "1":
     sys.exit(0)
 
 
+if os.environ.get("CHAIN_WINDOWS") is not None:
+    wins = [int(x) for x in os.environ["CHAIN_WINDOWS"].split(",")]
+    times = {w: [] for w in wins}
+    outs = {}
+    for rnd in range(int(os.environ.get("CHAIN_ROUNDS", "9"))):
+        for w in wins:
+            ctx.set_option(B.OPT_CHAIN_WINDOW, w)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            run()
+            b.record(stream)
+            torch.cuda.synchronize(dev)
+            if rnd >= 2:
+                times[w].append(a.elapsed_time(b))
+            if rnd == 0:
+                outs[w] = out.clone()
+    res = {"case": f"{ns} streams x {nf} frames x 2 ch, LM 3, post-filter case {case}, product library"}
+    for w in wins:
+        ms = sorted(times[w])[len(times[w]) // 2]
+        res[f"window_{w}"] = {"ms": ms, "min_ms": min(times[w]), "stereo_frames_per_sec": ns * nf / ms * 1e3,
+                              "GBps_freq_in_plus_pcm_out": ns * nf * ch * 7680 / ms / 1e6,
+                              "bit_identical_to_first": bool(torch.equal(outs[w], outs[wins[0]]))}
+    print(json.dumps(res))
+    sys.exit(0)
+
 res = {}
 outs = {}
 times = {"0": [], "1": []}
 for rnd in range(8):
     for mode in ("0", "1"):
-        os.environ["NYQ_CHAIN_FUSED"] = mode
+        ctx.set_option(B.OPT_CHAIN_FUSED, int(mode))
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(stream)
         run()

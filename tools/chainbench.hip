@@ -75,7 +75,7 @@ int main(int argc, char **argv) {
         CK(hipMemcpy(d_tap, pt.data(), ns * nf * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(d_gain, pg.data(), ns * nf * 4, hipMemcpyHostToDevice));
     }
-    PostArgs A;
+    PostArgs A{};
     A.pcm = d_pcm; A.pf_pitch = d_pitch; A.pf_gain = d_gain; A.pf_tapset = d_tap; A.pf_state = nullptr; A.pf_state_out = nullptr;
     A.hist = nullptr; A.deemph = nullptr; A.out = d_out; A.nstreams = ns; A.nframes = nf; A.channels = ch;
 

@@ -11,7 +11,8 @@ import torch  # noqa: E402
 import libnyquist_amd as nyq  # noqa: E402
 
 dev = torch.device("cuda", 0)
-ctx = nyq.Context(0)
+ctx = nyq.Context(0, ab=True)     # the tools' A/B build: the product's kernels + the round-1 post-filter forms
+B = nyq.binding
 stream = torch.cuda.Stream(dev)
 torch.cuda.set_stream(stream)
 ctx.set_stream(stream.cuda_stream)
@@ -81,11 +82,11 @@ for label, lo, hi, gmax in () if ONLY and ONLY != 'post' else (("pitch 15..1000,
     else:
         pg = (torch.randint(0, gmax, (ns, nf), generator=g, device=dev) * 0.09375).float()
     for mode in ("0", "1", "2"):      # one wave per channel vs one wave per stereo pair vs workgroup pipeline (default), same process, same box
-        os.environ["NYQ_POST_STEREO_PAIRS"] = mode
+        ctx.set_option(B.OPT_POST_FORM, {"0": B.POST_FORM_WAVE_PER_CHANNEL, "1": B.POST_FORM_WAVE_PER_PAIR, "2": B.POST_FORM_PIPELINE}[mode])
         ms = timeit(lambda: ctx.celt_post_dev(3, pcm.data_ptr(), pp.data_ptr(), pg.data_ptr(), pt.data_ptr(), 0, 0, 0, 0, out.data_ptr(), ns, nf, ch), 5)
         res.append(dict(op=f"celt_post_dev {ns} streams x {nf} frames x 2ch, {label}" + (" [stereo pairs]" if mode == "1" else " [pipeline]" if mode == "2" else ""),
                         rows=ns * nf * ch, ms=ms, alg_GBps=ns * nf * ch * 7680 / ms / 1e6, rows_per_s=ns * nf * ch / ms * 1e3))
-    del os.environ["NYQ_POST_STEREO_PAIRS"]
+    ctx.set_option(B.OPT_POST_FORM, B.POST_FORM_PIPELINE)
 if not ONLY or ONLY == 'post':
     ns1, ch1 = 2048, 1
     out1 = torch.empty((ns1, nf * 960, ch1), device=dev)
