@@ -107,7 +107,7 @@ def cpu_share():
     return n
 
 
-def opus_file_decode_leg(count=256, fname="short.opus", n=421930, threads=None):
+def opus_file_decode_leg(count=256, fname="short.opus", n=421930, threads=None, device=0):
     """File-level decode of `count` copies of tests/golden/<fname> (short.opus: 220 stereo 20 ms CELT frames + one
     closing 2.5 ms frame, 123 kbit/s; sb-reverie.opus: 11184 frames = 224 s, BASELINE config 4's file) as ONE
     batch through libnyquist_host (CPU entropy stage in
@@ -120,6 +120,9 @@ def opus_file_decode_leg(count=256, fname="short.opus", n=421930, threads=None):
     H.nyqh_batch_decode_timed.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                     ctypes.c_long, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")]
     H.nyqh_batch_decode_timed.restype = ctypes.c_long
+    H.nyqh_set_devices.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    H.nyqh_set_devices.restype = None
+    H.nyqh_set_devices((ctypes.c_int * 1)(device), 1)      # this rank's GPU (an explicit call: the environment is not touched)
     first = np.zeros(n, np.float32)
     stats = np.zeros(6, np.float64)
     H.nyqh_batch_decode_timed(raw, len(raw), count, threads, first.ctypes.data_as(ctypes.c_void_p), None, n, stats)   # contexts, pinned staging, pooled buffers
@@ -453,16 +456,15 @@ def main():
             host_boundary = {"error": repr(e)}
 
     # File-level decode on EVERY rank: each decodes its own copies on its own GPU with its share of the host threads
-    # (NYQ_DEVICE selects the device of the C entry point); the whole-job rate uses the slowest rank's wall clock.
+    # (nyqh_set_devices selects the device of the C entry point); the whole-job rate uses the slowest rank's wall clock.
     file_leg = None
     if not args.no_host_leg:
         try:
-            os.environ["NYQ_DEVICE"] = str(local_rank)
             thr = max(1, cpu_share() // world)
-            file_leg = opus_file_decode_leg(256 if world == 1 else 128, threads=thr)
+            file_leg = opus_file_decode_leg(256 if world == 1 else 128, threads=thr, device=local_rank)
             if world == 1:
                 # BASELINE config 4's file (224 s per stream): the GPU walks it in time slices behind the entropy stage
-                file_leg["long_streams"] = opus_file_decode_leg(32, "sb-reverie.opus", 21472602)
+                file_leg["long_streams"] = opus_file_decode_leg(32, "sb-reverie.opus", 21472602, device=local_rank)
         except Exception as e:
             file_leg = {"error": repr(e)} if file_leg is None else dict(file_leg, long_streams_error=repr(e))
         if world > 1:                        # (every rank takes part, whatever happened above)
@@ -472,15 +474,22 @@ def main():
                 file_leg["whole_job"] = {"n_gpus": world, "files": world * file_leg["files"], "slowest_rank_wall_seconds": float(tt.item()),
                                          "files_per_sec": world * file_leg["files"] / float(tt.item())}
 
+    my_kern_avg_ms = sum(kern_ms) / len(kern_ms)
+    per_rank_kern_ms, ranks_seen = [my_kern_avg_ms], 1
     if world > 1:
         t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        k = torch.tensor([sum(kern_ms) / len(kern_ms)], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(k, op=dist.ReduceOp.MAX)
-        kern_avg_ms = float(k.item())
+        k = torch.tensor([my_kern_avg_ms], device=red_dev, dtype=torch.float64)
+        gathered = [torch.zeros_like(k) for _ in range(world)]
+        dist.all_gather(gathered, k)                 # every rank's own mean kernel time (HIP events on its own stream)
+        per_rank_kern_ms = [float(g.item()) for g in gathered]
+        kern_avg_ms = max(per_rank_kern_ms)          # the roofline of the job is that of its slowest GPU
+        ones = torch.ones(1, device=red_dev, dtype=torch.float64)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)  # how many ranks the process group really joined
+        ranks_seen = int(round(float(ones.item())))
     else:
-        kern_avg_ms = sum(kern_ms) / len(kern_ms)
+        kern_avg_ms = my_kern_avg_ms
 
     if rank == 0:
         # parity spot check inside the bench: 4096 rows vs the oracle (relative RMS)
@@ -525,9 +534,17 @@ def main():
                          "kernel": "nyq::imdct_rows_kernel<32, KCfg<1,false,0>>", "kernel_avg_ms": kern_avg_ms,
                          "kernel_median_ms_rank0": float(np.median(kern_ms)),
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_IMDCT * rows,
-                         "measured_device_copy_GBps": copy_gbs},
+                         "measured_device_copy_GBps": copy_gbs,
+                         "per_rank_kernel_avg_ms": per_rank_kern_ms,
+                         "per_rank_frac": [ALG_BYTES_PER_IMDCT * rows / (m * 1e-3) / 1e9 / HBM_PEAK_GBS for m in per_rank_kern_ms]},
+            # which process group carried the barrier / MAX / gather (the data path has no collective), and how many ranks
+            # answered an all-reduce of ones: "did RCCL see N ranks" can be read off the line
+            "dist_backend": (args.dist_backend if world > 1 else None),
+            "ranks_seen": ranks_seen,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world > 1:                               # every rank is past its timed work: release them before the CPU leg
+            dist.barrier()
+        if not args.no_cpu_baseline:                # (any world size: the reference's CPU path timed in the same run)
             try:
                 out["cpu_baseline"] = cpu_baseline(x[: 1 << 16].cpu().numpy(), args.cpu_seconds)
                 out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
@@ -537,7 +554,8 @@ def main():
         print(json.dumps(out), flush=True)
 
     if world > 1:
-        dist.barrier()
+        if rank != 0:
+            dist.barrier()                          # (rank 0 passed this barrier before its CPU leg)
         dist.destroy_process_group()
 
 

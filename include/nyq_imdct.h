@@ -82,6 +82,8 @@ int  nyq_ctx_device_info(nyq_ctx *ctx, int *compute_units, char *name, size_t na
  *   NYQ_OPT_CHAIN_WINDOW    nyq_celt_chain_dev: frames per time window of the two-kernel chain, rounded up to the frame
  *                           size's chain length (16 / 32 / 32 / 64 frames for LM 3 / 2 / 1 / 0) so that the result is
  *                           bit-identical to one window; 0 = the built-in choice
+ *   NYQ_OPT_CHAIN_OVERLAP   with windows: 1 = the post-filter of window k on a second stream beside the synthesis of
+ *                           window k + 1 (an experiment: measured, not faster -- DESIGN.md 4.8)
  * The alternative forms (POST_FORM != pipeline, CHAIN_FUSED = 1) are measured-and-rejected designs kept for A/B
  * runs: they exist only in the tools' build of this library (-DNYQ_AB_FORMS, tools/libnyq_imdct_ab.so);
  * the product build answers NYQ_ERR_INVALID for them.  nyq_ab_forms_built() tells which build this is. */
@@ -89,6 +91,7 @@ int  nyq_ctx_device_info(nyq_ctx *ctx, int *compute_units, char *name, size_t na
 #define NYQ_OPT_POST_FORM     2
 #define NYQ_OPT_CHAIN_FUSED   3
 #define NYQ_OPT_CHAIN_WINDOW  4
+#define NYQ_OPT_CHAIN_OVERLAP 5
 #define NYQ_POST_FORM_PIPELINE         0
 #define NYQ_POST_FORM_WAVE_PER_CHANNEL 1
 #define NYQ_POST_FORM_WAVE_PER_PAIR    2
@@ -157,6 +160,12 @@ int nyq_celt_post_dev(nyq_ctx *ctx, int LM, const float *d_pcm, const int *d_pf_
                       const float *d_pf_gain, const int *d_pf_tapset, const float *d_pf_state_in,
                       float *d_pf_state_out, float *d_hist, float *d_deemph, float *d_out,
                       size_t nstreams, size_t nframes, int channels);
+
+/* Round size of nyq_celt_post_dev in (stream, channel) chains: the kernel keeps 8 chains per compute unit resident for the
+ * whole launch (2048 on an MI355X), so a call runs in ceil(nstreams * channels / this) rounds of roughly equal duration --
+ * 1024 stereo streams take one round, 1280 take two.  Batch callers should size calls in multiples of it (the host-buffer
+ * entry points below cut their pieces that way). */
+size_t nyq_celt_post_round_chains(nyq_ctx *ctx);
 
 /* The two stages above as ONE operator: freq[] -> interleaved PCM, everything celt_decode_with_ec does after
  * denormalise_bands (celt_decoder_clean.c:620-723).  For 20 ms stereo frames (LM 3, channels 2:

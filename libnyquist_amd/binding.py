@@ -12,7 +12,7 @@ import numpy as np
 from . import _build
 
 # nyq_ctx_set_option (include/nyq_imdct.h)
-OPT_BLOCKS_PER_CU, OPT_POST_FORM, OPT_CHAIN_FUSED, OPT_CHAIN_WINDOW = 1, 2, 3, 4
+OPT_BLOCKS_PER_CU, OPT_POST_FORM, OPT_CHAIN_FUSED, OPT_CHAIN_WINDOW, OPT_CHAIN_OVERLAP = 1, 2, 3, 4, 5
 POST_FORM_PIPELINE, POST_FORM_WAVE_PER_CHANNEL, POST_FORM_WAVE_PER_PAIR = 0, 1, 2
 
 HALF_OV = 60
@@ -22,7 +22,7 @@ ERRORS = {-1: "NYQ_ERR_INVALID", -2: "NYQ_ERR_NO_DEVICE", -3: "NYQ_ERR_HIP", -4:
 
 # every symbol include/nyq_imdct.h declares (tests check the .so exports all of them)
 EXPORTS = [
-    "nyq_device_count", "nyq_ctx_set_option", "nyq_ctx_get_option", "nyq_ab_forms_built",
+    "nyq_device_count", "nyq_celt_post_round_chains", "nyq_ctx_set_option", "nyq_ctx_get_option", "nyq_ab_forms_built",
     "nyq_ctx_create", "nyq_ctx_destroy", "nyq_last_error", "nyq_ctx_set_stream", "nyq_ctx_reset_stream", "nyq_ctx_get_stream",
     "nyq_ctx_synchronize", "nyq_ctx_set_tables", "nyq_ctx_get_tables", "nyq_ctx_device_info",
     "nyq_ifft_batch_dev", "nyq_imdct_batch_dev", "nyq_imdct_chain_dev",
@@ -125,6 +125,8 @@ def load(path=None):
     L.nyq_celt_synth_dev.argtypes = [vp, i, fp, fp, fp, fp, fp, sz, sz, i]
     L.nyq_celt_synth.argtypes = [vp, i, fp, fp, fp, fp, sz, sz, i]
     L.nyq_celt_post_dev.argtypes = [vp, i, fp, fp, fp, fp, fp, fp, fp, fp, fp, sz, sz, i]
+    L.nyq_celt_post_round_chains.argtypes = [vp]
+    L.nyq_celt_post_round_chains.restype = sz
     L.nyq_celt_chain_fused_supported.argtypes = [i, i]
     L.nyq_celt_chain_dev.argtypes = [vp, i] + [fp] * 13 + [sz, sz, i]
     L.nyq_celt_frames_to_pcm.argtypes = [vp, i, fp, fp, fp, fp, fp, fp, fp, sz, sz, i]

@@ -57,9 +57,9 @@ struct nyq_ctx {
     int res_imdct[4] = {0, 0, 0, 0};   // resident blocks per kernel instance (occupancy query, cached)
     int res_ifft[4] = {0, 0, 0, 0};
     int res_synth_long[4] = {0, 0, 0, 0};
-    int res_synth_short = 0;
+    int res_synth_short[4] = {0, 0, 0, 0};
     int res_post[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-    int res_post_pipe[4] = {0, 0, 0, 0};
+    int res_post_pipe[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};   // [LM][stereo instance]
     int res_chain_fused = 0;
     int res_vorbis[12] = {0};
     // options (nyq_ctx_set_option): nothing on a launch path reads the process environment
@@ -67,6 +67,8 @@ struct nyq_ctx {
     int opt_post_form = NYQ_POST_FORM_PIPELINE;
     int opt_chain_fused = 0;
     long opt_chain_window = 0;           // frames per window of the two-kernel chain; 0 = built-in choice
+    int opt_chain_overlap = 0;           // windows: post-filter of window k on a second stream beside the synthesis of window k + 1
+    hipStream_t s_post = nullptr;        // (created on first use)
     float *d_vtab = nullptr;             // Vorbis rotation + twiddle tables of every block size, one allocation
     size_t vrot_off[12] = {0}, vtw_off[12] = {0};   // float offsets by log2(n/4)
     std::string err;
@@ -152,7 +154,7 @@ extern "C" int nyq_ctx_set_option(nyq_ctx *ctx, int option, long value) {
         if (value < 0 || value > 64) return fail(ctx, NYQ_ERR_INVALID, "nyq_ctx_set_option: NYQ_OPT_BLOCKS_PER_CU must be 0..64");
         if ((int)value != ctx->opt_blocks_per_cu) {            // the cached grid sizes of the row kernels depend on it
             for (int k = 0; k < 4; k++) ctx->res_imdct[k] = ctx->res_ifft[k] = ctx->res_synth_long[k] = 0;
-            ctx->res_synth_short = 0;
+            for (int k = 0; k < 4; k++) ctx->res_synth_short[k] = 0;
         }
         ctx->opt_blocks_per_cu = (int)value;
         return NYQ_OK;
@@ -168,6 +170,10 @@ extern "C" int nyq_ctx_set_option(nyq_ctx *ctx, int option, long value) {
         if (value == 1 && !nyq_ab_forms_built())
             return fail(ctx, NYQ_ERR_INVALID, "nyq_ctx_set_option: this build has no fused chain kernel (tools/libnyq_imdct_ab.so has)");
         ctx->opt_chain_fused = (int)value;
+        return NYQ_OK;
+    case NYQ_OPT_CHAIN_OVERLAP:
+        if (value != 0 && value != 1) return fail(ctx, NYQ_ERR_INVALID, "nyq_ctx_set_option: NYQ_OPT_CHAIN_OVERLAP must be 0 or 1");
+        ctx->opt_chain_overlap = (int)value;
         return NYQ_OK;
     case NYQ_OPT_CHAIN_WINDOW:
         if (value < 0) return fail(ctx, NYQ_ERR_INVALID, "nyq_ctx_set_option: NYQ_OPT_CHAIN_WINDOW must be >= 0");
@@ -185,6 +191,7 @@ extern "C" int nyq_ctx_get_option(nyq_ctx *ctx, int option, long *value) {
     case NYQ_OPT_POST_FORM: *value = ctx->opt_post_form; return NYQ_OK;
     case NYQ_OPT_CHAIN_FUSED: *value = ctx->opt_chain_fused; return NYQ_OK;
     case NYQ_OPT_CHAIN_WINDOW: *value = ctx->opt_chain_window; return NYQ_OK;
+    case NYQ_OPT_CHAIN_OVERLAP: *value = ctx->opt_chain_overlap; return NYQ_OK;
     default: return fail(ctx, NYQ_ERR_INVALID, "nyq_ctx_get_option: unknown option");
     }
 }
@@ -244,6 +251,7 @@ extern "C" void nyq_ctx_destroy(nyq_ctx *ctx) {
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->ev_block) (void)hipEventDestroy(ctx->ev_block);
     if (ctx->s_side) { (void)hipStreamSynchronize(ctx->s_side); (void)hipStreamDestroy(ctx->s_side); }
+    if (ctx->s_post) { (void)hipStreamSynchronize(ctx->s_post); (void)hipStreamDestroy(ctx->s_post); }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
@@ -303,13 +311,17 @@ static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 // slots all counted by the occupancy query) -- a larger grid would run its surplus blocks as a
 // second, mostly idle round -- capped at the measured sweet spot of NYQ_WAVES_PER_CU, and never
 // more than the work.
+// waves_per_cu: the measured sweet spot of the kernel at hand (tools/bpc_ab.py, one process, interleaved, MI355X):
+//   rows of 3840 / 1920 B (15 KB of loads in flight per wave-group): 6 -- more streams lower HBM efficiency;
+//   rows of 960 / 480 B (7.7 KB per wave-group): 8 / 7 for frame synthesis (LM 1: 1.043 -> 0.989 ms, LM 0: 0.856 -> 0.825),
+//   7-8 for the plain row kernel of 1920 / 960 / 480 B rows (2-4 %).
 template <typename K>
-static int resident_blocks(nyq_ctx *ctx, K kernel, int *cache) {
+static int resident_blocks(nyq_ctx *ctx, K kernel, int *cache, int waves_per_cu = NYQ_WAVES_PER_CU) {
     if (*cache > 0) return *cache;
     int per_cu = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kWave * kWavesPerBlock, 0);
     if (e != hipSuccess || per_cu < 1) per_cu = 1;
-    const int want = (NYQ_WAVES_PER_CU + kWavesPerBlock - 1) / kWavesPerBlock;   // see nyq_kernels.hpp
+    const int want = (waves_per_cu + kWavesPerBlock - 1) / kWavesPerBlock;   // see nyq_kernels.hpp
     if (per_cu > want) per_cu = want;
     if (ctx->opt_blocks_per_cu > 0) per_cu = ctx->opt_blocks_per_cu;   // NYQ_OPT_BLOCKS_PER_CU: tuning knob for profiling runs
     *cache = per_cu * ctx->cus;
@@ -325,7 +337,8 @@ static unsigned grid_for(size_t batch, int rows_per_group, int resident) {
 template <int N2R>
 static int launch_imdct(nyq_ctx *ctx, const float *d_in, const float *d_carry, float *d_fin, float *d_tail,
                         size_t batch) {
-    const int res = resident_blocks(ctx, imdct_rows_kernel<N2R, Cfg>, &ctx->res_imdct[Geo<N2R>::SHIFT]);
+    const int res = resident_blocks(ctx, imdct_rows_kernel<N2R, Cfg>, &ctx->res_imdct[Geo<N2R>::SHIFT],
+                                    N2R == 32 ? 6 : N2R == 8 ? 8 : 7);
     hipLaunchKernelGGL((imdct_rows_kernel<N2R, Cfg>), dim3(grid_for(batch, Geo<N2R>::G, res)), dim3(kWave * kWavesPerBlock), 0,
                        ctx->stream, d_in, d_carry, d_fin, d_tail, (long)batch, ctx->d_trig, ctx->d_window);
     NYQ_HIP(ctx, hipGetLastError());
@@ -382,7 +395,8 @@ extern "C" size_t nyq_celt_synth_work_floats(size_t nstreams, size_t nframes, in
 template <int N2R>
 static int launch_synth_long(nyq_ctx *ctx, const SynthArgs &A) {
     const size_t nchunks = (size_t)A.nstreams * A.channels * FrameLongRows<N2R>::chunks_per_channel(A.nframes);
-    const int res = resident_blocks(ctx, synth_long_kernel<N2R, Cfg>, &ctx->res_synth_long[Geo<N2R>::SHIFT]);
+    const int res = resident_blocks(ctx, synth_long_kernel<N2R, Cfg>, &ctx->res_synth_long[Geo<N2R>::SHIFT],
+                                    N2R >= 16 ? 6 : N2R == 8 ? 8 : 7);
     const size_t need = (nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
     const unsigned grid = (unsigned)(need < (size_t)res ? need : (size_t)res);
     hipLaunchKernelGGL((synth_long_kernel<N2R, Cfg>), dim3(grid), dim3(kWave * kWavesPerBlock), 0, ctx->stream, A,
@@ -418,11 +432,17 @@ static int synth_core(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned 
     if (A.transient) {
         NYQ_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
         NYQ_HIP(ctx, hipStreamWaitEvent(ctx->s_side, ctx->ev_fork, 0));
-        const int res = resident_blocks(ctx, synth_short_kernel<Cfg>, &ctx->res_synth_short);
         const size_t need = (units + kWave * kWavesPerBlock - 1) / (kWave * kWavesPerBlock);
-        const unsigned grid = (unsigned)(need < (size_t)res ? need : (size_t)res);
-        hipLaunchKernelGGL((synth_short_kernel<Cfg>), dim3(grid), dim3(kWave * kWavesPerBlock), 0, ctx->s_side, A, 1 << LM,
-                           ctx->d_trig, ctx->d_window);
+        auto launch_short = [&](auto kernel, int *cache) {
+            const int res = resident_blocks(ctx, kernel, cache);
+            const unsigned grid = (unsigned)(need < (size_t)res ? need : (size_t)res);
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(kWave * kWavesPerBlock), 0, ctx->s_side, A, ctx->d_trig, ctx->d_window);
+        };
+        switch (LM) {
+        case 3: launch_short(synth_short_kernel<3, Cfg>, &ctx->res_synth_short[3]); break;
+        case 2: launch_short(synth_short_kernel<2, Cfg>, &ctx->res_synth_short[2]); break;
+        default: launch_short(synth_short_kernel<1, Cfg>, &ctx->res_synth_short[1]); break;
+        }
         NYQ_HIP(ctx, hipGetLastError());
         NYQ_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->s_side));
     }
@@ -500,25 +520,32 @@ static int launch_post(nyq_ctx *ctx, const PostArgs &A) {
 #endif   // NYQ_AB_FORMS
 
 // the workgroup-pipelined form (nyq_post_pipe.hpp): one workgroup of 2 comb waves + 1 I/O wave per two chains
+constexpr int kPipeGroupsPerCU = 4;      // workgroups kept per CU: one ROUND of the stage is 4 x CUs workgroups = 8 x CUs chains
+extern "C" size_t nyq_celt_post_round_chains(nyq_ctx *ctx) {
+    return ctx ? (size_t)kPipeGroupsPerCU * (size_t)kPipeUnits * (size_t)ctx->cus : 0;
+}
+
 template <int LM>
 static int launch_post_pipe(nyq_ctx *ctx, const PostArgs &A) {
     const size_t nunits = (size_t)A.nstreams * (size_t)A.channels;
     const size_t npairs = (nunits + kPipeUnits - 1) / kPipeUnits;
-    int &res = ctx->res_post_pipe[LM];
+    // the launched instance's own occupancy: <LM, true> for stereo streams, <LM, false> otherwise
+    const bool pair = A.channels == 2;
+    int &res = ctx->res_post_pipe[LM][pair ? 1 : 0];
     if (res == 0) {
         int per_cu = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, celt_post_pipe_kernel<LM>, kWave * kPipeWaves, 0);
+        hipError_t e = pair ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, celt_post_pipe_kernel<LM, true>, kWave * kPipeWaves, 0)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, celt_post_pipe_kernel<LM, false>, kWave * kPipeWaves, 0);
         if (e != hipSuccess || per_cu < 1) per_cu = 1;
-        // one workgroup per CU fewer than what fits on paper, four at most (the design point: 8 chains per CU).  A
-        // workgroup lives for the whole launch, and "exactly what fits" only fits when the CU's LDS and register
+        // one workgroup per CU fewer than what fits on paper, kPipeGroupsPerCU (four) at most: the design point is 8 chains
+        // per CU.  A workgroup lives for the whole launch, and "exactly what fits" only fits when the CU's LDS and register
         // allocators start from zero -- see kPipeHist in nyq_post_pipe.hpp; 1280 stereo streams at five per CU: 1.75 ms,
-        // two rounds for some CUs, where 1024 take 1.0
-        per_cu = per_cu > 4 ? 4 : per_cu > 1 ? per_cu - 1 : 1;
+        // two rounds for some CUs, where 1024 take 1.0 (the round size of this stage)
+        per_cu = per_cu > kPipeGroupsPerCU ? kPipeGroupsPerCU : per_cu > 1 ? per_cu - 1 : 1;
         res = per_cu * ctx->cus;
     }
     const unsigned grid = (unsigned)(npairs < (size_t)res ? npairs : (size_t)res);
-    // (the occupancy figure above is that of the generic instance: the stereo one needs no more registers or LDS)
-    if (A.channels == 2)
+    if (pair)
         hipLaunchKernelGGL((celt_post_pipe_kernel<LM, true>), dim3(grid), dim3(kWave * kPipeWaves), 0, ctx->stream, A, ctx->d_window);
     else
         hipLaunchKernelGGL((celt_post_pipe_kernel<LM, false>), dim3(grid), dim3(kWave * kPipeWaves), 0, ctx->stream, A, ctx->d_window);
@@ -679,19 +706,51 @@ extern "C" int nyq_celt_chain_dev(nyq_ctx *ctx, int LM, const float *d_freq, con
     if (!d_hist) NYQ_HIP(ctx, hipMemsetAsync(t_hi, 0, nsc * kPostHist * sizeof(float), ctx->stream));
     if (!d_deemph) NYQ_HIP(ctx, hipMemsetAsync(t_de, 0, nsc * sizeof(float), ctx->stream));
     const float *pf_in = d_pf_state_in;
+    // NYQ_OPT_CHAIN_OVERLAP: the post-filter of window k runs on a second stream beside the synthesis of window k + 1 (two
+    // window buffers of d_pcm and d_work alternate).  An experiment, measured and not the default: both
+    // kernels stream at the memory system's rate and size their grids for the whole chip, so they take turns.
+    const size_t nwin = (nframes + W - 1) / W;
+    const size_t wfl = round16f(nsc * (W + 1) * NYQ_HALF_OV), pfl = round16f(nsc * W * N);
+    const bool overlap = ctx->opt_chain_overlap && nwin >= 2 && nframes >= 2 * W + 40;
+    if (overlap) {
+        if (!ctx->s_post) NYQ_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_post, hipStreamNonBlocking));
+        while (ctx->ev_pool.size() < 2 * nwin + 1) {
+            hipEvent_t e;
+            NYQ_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->ev_pool.push_back(e);
+        }
+        // temporaries behind BOTH windows' shares of d_work
+        t_ov = d_work + 2 * wfl; t_hi = t_ov + round16f(nsc * NYQ_HALF_OV); t_de = t_hi + round16f(nsc * kPostHist);
+        t_pf[0] = t_de + round16f(nsc); t_pf[1] = t_pf[0] + round16f(nstreams * 6);
+        ov = d_overlap ? d_overlap : t_ov; hi = d_hist ? d_hist : t_hi; de = d_deemph ? d_deemph : t_de;
+        if (!d_overlap) NYQ_HIP(ctx, hipMemsetAsync(t_ov, 0, nsc * NYQ_HALF_OV * sizeof(float), ctx->stream));
+        if (!d_hist) NYQ_HIP(ctx, hipMemsetAsync(t_hi, 0, nsc * kPostHist * sizeof(float), ctx->stream));
+        if (!d_deemph) NYQ_HIP(ctx, hipMemsetAsync(t_de, 0, nsc * sizeof(float), ctx->stream));
+    }
+    hipStream_t main_stream = ctx->stream;
     size_t k = 0;
     for (size_t f0 = 0; f0 < nframes; f0 += W, k++) {
         const size_t len = nframes - f0 < W ? nframes - f0 : W;
         const bool lastw = f0 + len == nframes;
         float *pf_out = lastw ? d_pf_state_out : t_pf[k & 1];
-        int rc = synth_core(ctx, LM, d_freq + f0 * channels * N, d_transient ? d_transient + f0 : nullptr, d_pcm, ov, ov, d_work,
+        float *wpcm = overlap ? d_pcm + (k & 1) * pfl : d_pcm, *wwork = overlap ? d_work + (k & 1) * wfl : d_work;
+        if (overlap && k >= 2) NYQ_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->ev_pool[2 * (k - 2) + 1], 0));   // post(k-2) has read this buffer
+        int rc = synth_core(ctx, LM, d_freq + f0 * channels * N, d_transient ? d_transient + f0 : nullptr, wpcm, ov, ov, wwork,
                             nstreams, len, channels, nframes);
         if (rc != NYQ_OK) return rc;
-        rc = post_core(ctx, LM, d_pcm, d_pf_pitch + f0, d_pf_gain + f0, d_pf_tapset + f0, pf_in, pf_out, hi, de, d_out + f0 * N * channels,
+        if (overlap) {
+            NYQ_HIP(ctx, hipEventRecord(ctx->ev_pool[2 * k], main_stream));
+            NYQ_HIP(ctx, hipStreamWaitEvent(ctx->s_post, ctx->ev_pool[2 * k], 0));
+            ctx->stream = ctx->s_post;
+        }
+        rc = post_core(ctx, LM, wpcm, d_pf_pitch + f0, d_pf_gain + f0, d_pf_tapset + f0, pf_in, pf_out, hi, de, d_out + f0 * N * channels,
                        nstreams, len, channels, nframes);
+        ctx->stream = main_stream;
         if (rc != NYQ_OK) return rc;
+        if (overlap) NYQ_HIP(ctx, hipEventRecord(ctx->ev_pool[2 * k + 1], ctx->s_post));
         pf_in = pf_out;
     }
+    if (overlap) NYQ_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->ev_pool[2 * (k - 1) + 1], 0));
     return NYQ_OK;
 }
 
@@ -993,6 +1052,11 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
     // a handful of waves, piece after piece -- keep at least 32 streams together so they filter side by side
     if (per < 32) per = 32;
     if ((nstreams + per - 1) / per > kHostMaxPieces) per = (nstreams + kHostMaxPieces - 1) / kHostMaxPieces;
+    // ... and whole ROUNDS of it: the post-filter kernel keeps 4 workgroups = 8 chains per CU for the whole launch
+    // (nyq_celt_post_round_chains), so a piece of a few chains more than a round runs a second, nearly empty round at the
+    // price of a full one (1280 stereo streams: 1.75 ms, 1024: 1.0).  Pieces larger than a round are cut at multiples of it.
+    const size_t round_streams = nyq_celt_post_round_chains(ctx) / (size_t)channels;
+    if (round_streams >= 32 && per > round_streams) per = per / round_streams * round_streams;
     const size_t npieces = (nstreams + per - 1) / per;
     rc = need_copy_streams(ctx, 2 * npieces + 1);
     if (rc != NYQ_OK) return rc;

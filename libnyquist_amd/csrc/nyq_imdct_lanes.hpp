@@ -302,32 +302,43 @@ struct FrameLongRows {
     }
 };
 
-// The B <= 8 short blocks of ONE transient frame of one (stream, channel): one group of Geo<4>::G = 16 rows
-// holds them all (h stays for generality), chained through the tail ring.  Always N2R = 4.
-struct FrameShortRows {
+// The short blocks of UP TO 16 / B transient frames -- any (stream, channel, frame) units -- as ONE group of 16 rows
+// (round 3): unit k owns rows k B .. k B + B - 1, its blocks chain through the tail ring (row g takes
+// the tail row g - 1 left, block 0 of every unit is mirrored against zeros and completed by the fix-up pass).  A
+// transient frame of B = 2 blocks used to fill 2 of the 16 rows of its own group (LM 1 synthesis ran at 3800 GB/s where
+// the other sizes reach 4500); eight of them now share one.  LMc = log2 B (1, 2, 3), K = 16 >> LMc units per group.
+// where one transient frame of one (stream, channel) lives: a row of the wave's unit table (LDS; the lane that found the
+// frame in the scan fills it from the indices it already holds)
+struct ShortUnit {
+    const float *in0;      // freq of the frame and channel
+    float *fin0;           // pcm of the frame
+    float *tslot;          // tails slot f + 1 of the channel
+};
+template <int LMc>
+NYQ_HD ShortUnit short_unit(const SynthArgs &A, long s, long c, long f) {
+    constexpr long N = 120L << LMc;
+    const long sc = s * A.channels + c;
+    return ShortUnit{A.freq + ((s * A.fs() + f) * A.channels + c) * N, A.pcm + (sc * A.nframes + f) * N,
+                     A.tails + (sc * (A.nframes + 1) + f + 1) * (long)kHalfOv};
+}
+
+template <int LMc>
+struct FrameShortPacked {
     static constexpr bool STRIDED = true;
     static constexpr bool CHAINS = true;
-    const float *in0;   // freq of this frame and channel
-    float *fin0;        // pcm of this frame
-    float *tail_slot;   // tails slot f+1
-    int B, b0;          // blocks in the frame, first block of this group
-    NYQ_HD FrameShortRows(const SynthArgs &A, long sc, long f, int B_, int h) {
-        const long s = sc / A.channels, c = sc - s * A.channels;
-        const long N = 120L * B_;
-        B = B_;
-        b0 = h * Geo<4>::G;
-        in0 = A.freq + ((s * A.fs() + f) * A.channels + c) * N;
-        fin0 = A.pcm + (sc * A.nframes + f) * N;
-        tail_slot = A.tails + (sc * (A.nframes + 1) + f + 1) * (long)kHalfOv;
-    }
-    NYQ_HD bool valid(int g) const { return b0 + g < B; }
-    NYQ_HD const float *in(int g) const { return in0 + (b0 + g); }
+    static constexpr int B = 1 << LMc;
+    static constexpr int K = Geo<4>::G / B;
+    const ShortUnit *tab;  // K rows, the first nunits valid
+    int nunits;
+    NYQ_HD FrameShortPacked(const ShortUnit *tab_, int n) : tab(tab_), nunits(n) {}
+    NYQ_HD bool valid(int g) const { return (g >> LMc) < nunits; }
+    NYQ_HD const float *in(int g) const { return tab[g >> LMc].in0 + (g & (B - 1)); }
     NYQ_HD int stride() const { return B; }
-    NYQ_HD float *fin(int g) const { return fin0 + 120L * (b0 + g); }
+    NYQ_HD float *fin(int g) const { return tab[g >> LMc].fin0 + 120L * (g & (B - 1)); }
     NYQ_HD float *head(int g) const { return fin(g); }
-    NYQ_HD bool chain(int g) const { return b0 + g > 0; }
+    NYQ_HD bool chain(int g) const { return (g & (B - 1)) > 0; }
     NYQ_HD const float *carry(int) const { return nullptr; }
-    NYQ_HD float *tail(int g) const { return (b0 + g == B - 1) ? tail_slot : nullptr; }
+    NYQ_HD float *tail(int g) const { return (g & (B - 1)) == B - 1 ? tab[g >> LMc].tslot : nullptr; }
 };
 
 // Is the head of frame f (its first 120 samples) already mirrored against the true carry?

@@ -221,48 +221,57 @@ __global__ __launch_bounds__(kWave *Cfg::WPB) void synth_long_kernel(SynthArgs A
     }
 }
 
-// Transient frames: a wave takes one (stream, channel, frame) and runs its B <= 8 short blocks as one group
-// of 16 rows; blocks chain through the tail ring, the last block publishes the frame's tail.
-template <typename Cfg>
-__global__ __launch_bounds__(kWave *Cfg::WPB) void synth_short_kernel(SynthArgs A, int B,
-                                                                       const float *__restrict__ trig,
+// Transient frames: a wave scans 64 (stream * channel, frame) units at a time and runs the short blocks of up to
+// 16 / B of the transient ones among them as ONE group of 16 rows (FrameShortPacked: unit k owns rows k B ..); blocks of a
+// unit chain through the tail ring, its last block publishes the frame's tail.  LMc = log2 B.
+template <int LMc, typename Cfg>
+__global__ __launch_bounds__(kWave *Cfg::WPB) void synth_short_kernel(SynthArgs A, const float *__restrict__ trig,
                                                                        const float *__restrict__ window) {
     using WL = WaveLds<4, Cfg::WPB, true>;
+    using Rows = FrameShortPacked<LMc>;
     __shared__ __attribute__((aligned(16))) float smem[WL::TOTAL];
     const int lane = threadIdx.x & (kWave - 1);
     const int wv = threadIdx.x >> 6;
     cpx *lds = reinterpret_cast<cpx *>(smem + wv * WL::PER_WAVE);
     float *ring = smem + wv * WL::PER_WAVE + WL::ROW_FLOATS;
 
+    __shared__ ShortUnit utab_all[Cfg::WPB][Rows::K];
+    ShortUnit *utab = utab_all[wv];
+
     LaneConst<4> K;
     lane_init<4>(K, lane, trig, window);
 
     // Transient frames are rare (a few per cent), so the scan is vectorised: the wave looks at 64
     // consecutive (stream*channel, frame) units at once -- one flag byte per lane, one ballot --
-    // and then walks only the set bits.
+    // and then takes the set bits Rows::K at a time: the lane that owns the r-th of them writes row r of the unit table
+    // from the indices it computed for the scan.
     const long units = A.nstreams * A.channels * A.nframes;
     const long nwaves = (long)gridDim.x * Cfg::WPB;
     for (long base = ((long)blockIdx.x * Cfg::WPB + wv) * kWave; base < units; base += nwaves * kWave) {
         const long mine = base + lane;
         bool hit = false;
+        long s = 0, c = 0, f = 0;
         if (mine < units) {
-            const long sc = mine / A.nframes, f = mine - sc * A.nframes;
-            hit = A.transient[(sc / A.channels) * A.fs() + f] != 0;
+            const long sc = mine / A.nframes;
+            f = mine - sc * A.nframes;
+            s = sc / A.channels;
+            c = sc - s * A.channels;
+            hit = A.transient[s * A.fs() + f] != 0;
         }
         unsigned long long todo = __ballot(hit);
         while (todo) {
-            const int bit = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const long u = base + bit;
-            const long sc = u / A.nframes, f = u - sc * A.nframes;
-            for (int h = 0; h * Geo<4>::G < B; h++) {
-                FrameShortRows rows(A, sc, f, B, h);
-                StageRegs<4> R;
-                stage_in_load<4, 0>(R, lane, rows);
-                run_group<4, Cfg>(K, lane, lds, ring, rows, R);
-                NYQ_WAVE_SYNC();
-                ring_rotate<4>(lane, ring);
-            }
+            const int rank = __builtin_popcountll(todo & ((1ull << lane) - 1ull));
+            NYQ_WAVE_SYNC();                                   // (the previous group has finished reading the table)
+            if (((todo >> lane) & 1ull) && rank < Rows::K) utab[rank] = short_unit<LMc>(A, s, c, f);
+            const int avail = __builtin_popcountll(todo);
+            const int n = avail < Rows::K ? avail : Rows::K;
+#pragma unroll
+            for (int k = 0; k < Rows::K; k++) todo &= todo - 1;   // (clearing a bit of zero leaves zero)
+            NYQ_WAVE_SYNC();
+            Rows rows(utab, n);
+            StageRegs<4> R;
+            stage_in_load<4, 0>(R, lane, rows);
+            run_group<4, Cfg>(K, lane, lds, ring, rows, R);
         }
     }
 }

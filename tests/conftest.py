@@ -46,7 +46,7 @@ def pytest_sessionstart(session):
     REHEARSAL["proc"] = subprocess.Popen(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--dist-backend", "gloo",
-         "--rows", "65536", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+         "--rows", "65536", "--steps", "2", "--warmup", "1", "--cpu-seconds", "2"],
         cwd=ROOT, env=env, stdout=REHEARSAL["out"], stderr=REHEARSAL["err"])
 
 

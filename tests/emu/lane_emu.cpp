@@ -89,16 +89,27 @@ static void emu_synth_long(const SynthArgs &A, const float *trig, const float *w
         }
 }
 
-static void emu_synth_short(const SynthArgs &A, int B, const float *trig, const float *window) {
+// nyq_kernels.hpp synth_short_kernel<LMc>: 64 units per scan step, the transient ones Rows::K at a time as one group
+template <int LMc>
+static void emu_synth_short(const SynthArgs &A, const float *trig, const float *window) {
+    using Rows = FrameShortPacked<LMc>;
     WaveEmu<4> W(trig, window);
     const long units = A.nstreams * A.channels * A.nframes;
-    for (long u = 0; u < units; u++) {
-        const long sc = u / A.nframes, f = u - sc * A.nframes, s = sc / A.channels;
-        if (!A.transient[s * A.nframes + f]) continue;
-        for (int h = 0; h * Geo<4>::G < B; h++) {
-            FrameShortRows rows(A, sc, f, B, h);
+    for (long base = 0; base < units; base += kWave) {
+        std::vector<ShortUnit> hits;
+        for (long u = base; u < units && u < base + kWave; u++) {
+            const long sc = u / A.nframes, f = u - sc * A.nframes, s = sc / A.channels, c = sc - s * A.channels;
+            if (A.transient[s * A.fs() + f]) hits.push_back(short_unit<LMc>(A, s, c, f));
+        }
+        for (size_t h0 = 0; h0 < hits.size(); h0 += Rows::K) {
+            ShortUnit tab[Rows::K];
+            int n = 0;
+            for (int k = 0; k < Rows::K; k++) {
+                tab[k] = hits[h0];
+                if (h0 + k < hits.size()) { tab[k] = hits[h0 + k]; n = k + 1; }
+            }
+            Rows rows(tab, n);
             W.group(rows);
-            W.rotate();
         }
     }
 }
@@ -154,7 +165,11 @@ extern "C" int emu_celt_synth(int LM, const float *freq, const unsigned char *tr
     case 1: emu_synth_long<8>(A, trig, window); chain_frames = Geo<8>::CHAIN_FRAMES; break;
     default: emu_synth_long<4>(A, trig, window); chain_frames = Geo<4>::CHAIN_FRAMES; break;
     }
-    if (A.transient) emu_synth_short(A, 1 << LM, trig, window);
+    if (A.transient) {
+        if (LM == 3) emu_synth_short<3>(A, trig, window);
+        else if (LM == 2) emu_synth_short<2>(A, trig, window);
+        else emu_synth_short<1>(A, trig, window);
+    }
     emu_synth_fixup(A, 120 << LM, chain_frames, window);
     return 0;
 }

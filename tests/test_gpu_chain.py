@@ -29,7 +29,7 @@ def ctx_ab():
     c.close()
 
 
-def _run_chain(ctx, lm, freq, tr, pitch, gain, taps, pst, ov, hist, dm, ch, fused, window=0):
+def _run_chain(ctx, lm, freq, tr, pitch, gain, taps, pst, ov, hist, dm, ch, fused, window=0, overlap=0):
     import libnyquist_amd as nyq
     import torch
     dev = torch.device("cuda", 0)
@@ -48,6 +48,7 @@ def _run_chain(ctx, lm, freq, tr, pitch, gain, taps, pst, ov, hist, dm, ch, fuse
     if fused:
         ctx.set_option(nyq.binding.OPT_CHAIN_FUSED, 1)
     ctx.set_option(nyq.binding.OPT_CHAIN_WINDOW, window)
+    ctx.set_option(nyq.binding.OPT_CHAIN_OVERLAP, overlap)
     try:
         ctx.celt_chain_dev(lm, d_freq.data_ptr(), d_tr.data_ptr(), d_pp.data_ptr(), d_pg.data_ptr(), d_pt.data_ptr(), d_si.data_ptr(),
                            d_so.data_ptr(), d_ov.data_ptr(), d_h.data_ptr(), d_m.data_ptr(), d_out.data_ptr(), d_pcm.data_ptr(),
@@ -57,6 +58,7 @@ def _run_chain(ctx, lm, freq, tr, pitch, gain, taps, pst, ov, hist, dm, ch, fuse
         if fused:
             ctx.set_option(nyq.binding.OPT_CHAIN_FUSED, 0)
         ctx.set_option(nyq.binding.OPT_CHAIN_WINDOW, 0)
+        ctx.set_option(nyq.binding.OPT_CHAIN_OVERLAP, 0)
     return d_out.cpu().numpy(), d_so.cpu().numpy(), d_ov.cpu().numpy(), d_h.cpu().numpy(), d_m.cpu().numpy()
 
 
@@ -174,6 +176,10 @@ def test_windowed_chain_is_bit_identical_to_one_window(ctx, oracle, lm, ch, ns, 
         one = _run_chain(ctx, lm, freq, tr, pitch, gain, taps, pst, ov, hist, dm, ch, fused=False, window=0)
         win = _run_chain(ctx, lm, freq, tr, pitch, gain, taps, pst, ov, hist, dm, ch, fused=False, window=window)
         for a, b in zip(one, win):
+            assert np.array_equal(a, b)
+        # ... and with the post-filter of window k on a second stream beside the synthesis of window k + 1
+        lap = _run_chain(ctx, lm, freq, tr, pitch, gain, taps, pst, ov, hist, dm, ch, fused=False, window=window, overlap=1)
+        for a, b in zip(one, lap):
             assert np.array_equal(a, b)
         wp, ws = oracle.celt_synth(lm, freq, tr, ov, nthreads=4)
         want, filt, wst, wdm = oracle.celt_post(lm, np.concatenate([hist.reshape(ns, ch, 1088), wp.reshape(ns, ch, nf * n)], axis=2), 1088,

@@ -75,7 +75,7 @@ def test_two_rank_gloo_sharding():
 @pytest.mark.gpu
 def test_bench_two_ranks_on_one_gpu():
     """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 --rehearse-on-one-gpu --dist-backend gloo
-    --rows 65536 --steps 2` must print ONE JSON line with n_gpus 2, both shards in the global batch, a parity figure from
+    --rows 65536 --steps 2 --cpu-seconds 2` must print ONE JSON line with n_gpus 2, both shards in the global batch, a parity figure from
     the oracle, a whole-job Opus chain rate and the per-rank file-decode leg aggregated over both ranks."""
     p = REHEARSAL["proc"]
     if p is None:
@@ -97,3 +97,11 @@ def test_bench_two_ranks_on_one_gpu():
     leg = j["opus_file_decode"]
     assert leg["whole_job"]["n_gpus"] == 2 and leg["whole_job"]["files"] == 2 * leg["files"]
     assert leg["whole_job"]["slowest_rank_wall_seconds"] >= leg["wall_seconds"] * 0.999
+    # the multi-rank line is complete: the reference's CPU path timed in the same run, the process
+    # group that really came up, how many ranks answered, and every rank's own kernel time / roofline fraction
+    cb = j["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "IMDCT/s"
+    assert j["dist_backend"] == "gloo" and j["ranks_seen"] == 2
+    assert len(j["roofline"]["per_rank_kernel_avg_ms"]) == 2 and len(j["roofline"]["per_rank_frac"]) == 2
+    assert j["roofline"]["kernel_avg_ms"] == max(j["roofline"]["per_rank_kernel_avg_ms"])
+    assert abs(j["roofline"]["frac"] - min(j["roofline"]["per_rank_frac"])) < 1e-9

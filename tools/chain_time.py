@@ -105,12 +105,14 @@ if os.environ.get("CHAIN_SPLIT") == "1":
 
 
 if os.environ.get("CHAIN_WINDOWS") is not None:
-    wins = [int(x) for x in os.environ["CHAIN_WINDOWS"].split(",")]
+    # entries: W (sequential windows) or "Wo" (overlapped: post-filter of window k beside the synthesis of window k + 1)
+    wins = os.environ["CHAIN_WINDOWS"].split(",")
     times = {w: [] for w in wins}
     outs = {}
     for rnd in range(int(os.environ.get("CHAIN_ROUNDS", "9"))):
         for w in wins:
-            ctx.set_option(B.OPT_CHAIN_WINDOW, w)
+            ctx.set_option(B.OPT_CHAIN_WINDOW, int(w.rstrip("o")))
+            ctx.set_option(B.OPT_CHAIN_OVERLAP, 1 if w.endswith("o") else 0)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(stream)
             run()

@@ -13,6 +13,8 @@ import libnyquist_amd as nyq  # noqa: E402
 dev = torch.device("cuda", 0)
 ctx = nyq.Context(0, ab=True)     # the tools' A/B build: the product's kernels + the round-1 post-filter forms
 B = nyq.binding
+BPC = int(os.environ.get('SWEEP_BPC', '0'))   # NYQ_OPT_BLOCKS_PER_CU of the persistent row kernels (0 = the per-size built-in)
+ctx.set_option(B.OPT_BLOCKS_PER_CU, BPC)
 stream = torch.cuda.Stream(dev)
 torch.cuda.set_stream(stream)
 ctx.set_stream(stream.cuda_stream)
@@ -96,5 +98,6 @@ if not ONLY or ONLY == 'post':
     ms = timeit(lambda: ctx.celt_post_dev(3, pcm.data_ptr(), pp.data_ptr(), pg.data_ptr(), pt1.data_ptr(), 0, 0, 0, 0, out1.data_ptr(), ns1, nf, ch1), 5)
     res.append(dict(op="celt_post_dev 2048 streams x 256 frames x 1ch, no post-filter", rows=ns1 * nf, ms=ms, alg_GBps=ns1 * nf * 7680 / ms / 1e6, rows_per_s=ns1 * nf / ms * 1e3))
 for r in res:
+    r["blocks_per_cu"] = BPC
     r["frac_8TBps"] = r["alg_GBps"] / 8000.0
     print(json.dumps(r))
