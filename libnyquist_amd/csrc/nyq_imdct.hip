@@ -455,7 +455,10 @@ static int synth_core(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned 
     if (A.transient) NYQ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     if (rc != NYQ_OK) return rc;
     const size_t per_block = (size_t)kWave * kFixupWaves;
-    hipLaunchKernelGGL(synth_fixup_kernel, dim3((unsigned)((units + per_block - 1) / per_block)),
+    // (grid.x = (stream, channel) units, up to 2^31 - 1; grid.y = blocks of 256 frames, up to 65535: 16.7 M frames per call)
+    if (nsc > 0x7fffffffu || (nframes + per_block - 1) / per_block > 65535)
+        return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_synth_dev: more than 2^31 - 1 (stream, channel) units or 16.7 M frames in one call");
+    hipLaunchKernelGGL(synth_fixup_kernel, dim3((unsigned)nsc, (unsigned)((nframes + per_block - 1) / per_block)),
                        dim3(kWave * kFixupWaves), 0, ctx->stream, A, 120 << LM, chain_frames, ctx->d_window);
     NYQ_HIP(ctx, hipGetLastError());
     return NYQ_OK;
