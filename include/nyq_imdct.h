@@ -237,6 +237,11 @@ void processMDCTCudaB1C2(const float *input[2], float *output[2], const float *t
                          int shift, int stride, float sine, int overlap, const float *window);
 /* cuda/mdct_cuda.hpp:100, called from examples/src/Main.cpp:127-129 */
 void cleanupCudaBuffers(void);
+/* Not in the reference.  The two void operators above cannot return a status: by default a failure (no device, a HIP error,
+ * a call outside the static 48 kHz mode) prints and ends the process, as the reference's offload does (mdct_cuda.cu:11-19).
+ * With a handler installed the handler is called instead (entry point, reason) and, when it returns, the call returns with
+ * `output` untouched -- the integrator decides what to do with the stream.  NULL restores the default.  No CPU fallback. */
+void nyq_shim_set_error_handler(void (*handler)(const char *who, const char *what));
 /* cuda/mdct_cuda.hpp:83, called from examples/src/Main.cpp:26-28 */
 void printCudaVersion(void);
 

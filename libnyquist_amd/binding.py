@@ -30,7 +30,7 @@ EXPORTS = [
     "nyq_celt_chain_fused_supported", "nyq_celt_chain_dev",
     "nyq_celt_frames_to_pcm", "nyq_celt_frames_to_pcm_window", "nyq_celt_state_floats", "nyq_vorbis_imdct_batch_dev", "nyq_vorbis_imdct_batch",
     "nyq_ifft_batch", "nyq_imdct_batch", "nyq_imdct_chain", "nyq_host_alloc", "nyq_host_free",
-    "processMDCTCuda", "processMDCTCudaB1C2", "cleanupCudaBuffers", "printCudaVersion",
+    "processMDCTCuda", "processMDCTCudaB1C2", "cleanupCudaBuffers", "printCudaVersion", "nyq_shim_set_error_handler",
 ]
 
 

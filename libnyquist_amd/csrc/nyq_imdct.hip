@@ -1145,8 +1145,26 @@ static std::mutex g_shim_mu;
 static nyq_ctx *g_shim_ctx = nullptr;
 static bool g_shim_tables_set = false;
 
-[[noreturn]] static void shim_die(const char *who, const char *what) {
-    // reference behaviour on device failure is fprintf + exit(1) (mdct_cuda.cu:11-19)
+// What the void entry points do when they cannot do their work.  Default: the reference's behaviour on device failure,
+// fprintf + end of the process (mdct_cuda.cu:11-19 calls exit(1); here abort(), so that a core / a test log shows where).
+// An integrator who would rather degrade -- log, mark the stream as failed, unwind -- installs a handler with
+// nyq_shim_set_error_handler: it is called with the entry point's name and the reason, and if it returns, the call returns
+// with `output` untouched (the carry in output[0 .. overlap/2) and everything behind it as the caller left them).  There is
+// still no CPU fallback in this library: what to decode instead is the integrator's decision.
+static void (*g_shim_handler)(const char *who, const char *what) = nullptr;
+
+extern "C" void nyq_shim_set_error_handler(void (*handler)(const char *who, const char *what)) {
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    g_shim_handler = handler;
+}
+
+struct ShimFailure {};   // unwinds a shim call after the handler has returned
+
+static void shim_die(const char *who, const char *what) {   // call with g_shim_mu held or before it is taken
+    if (g_shim_handler) {
+        g_shim_handler(who, what);
+        throw ShimFailure{};
+    }
     std::fprintf(stderr, "%s: %s\n", who, what);
     std::abort();
 }
@@ -1181,9 +1199,10 @@ static ShimPinned *g_shim_pin = nullptr;
 
 static void shim_rows(const char *who, int nch, const float *const *input, float *const *output, const float *trig,
                       int N, int shift, int stride, int overlap, const float *window) {
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    try {
     if (shift < 0 || shift > 3 || N != (NYQ_MDCT_N >> shift) || overlap != NYQ_OVERLAP || stride < 1 || !trig || !window)
         shim_die(who, "unsupported call: only the static 48 kHz mode (mdct.n 1920, overlap 120, shift 0..3) exists");
-    std::lock_guard<std::mutex> lk(g_shim_mu);
     nyq_ctx *ctx = shim_ctx(who, trig, window);
     if (!g_shim_pin) {
         g_shim_pin = static_cast<ShimPinned *>(nyq_host_alloc(sizeof(ShimPinned)));
@@ -1205,6 +1224,9 @@ static void shim_rows(const char *who, int nch, const float *const *input, float
     for (int c = 0; c < nch; c++) {
         std::memcpy(output[c], pfin + c * n2, sizeof(float) * n2);
         std::memcpy(output[c] + n2, ptail + c * NYQ_HALF_OV, sizeof(float) * NYQ_HALF_OV);
+    }
+    } catch (const ShimFailure &) {
+        // the installed handler has been told; output is untouched
     }
 }
 

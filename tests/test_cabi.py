@@ -57,3 +57,33 @@ def test_header_is_plain_c():
                         "-fsyntax-only", f.name], capture_output=True, text=True)
     os.unlink(f.name)
     assert r.returncode == 0, r.stderr
+
+
+def test_shim_error_handler_instead_of_abort():
+    """The reference-named void operators cannot return a status; by default a failure ends the process as the reference's
+    offload does (mdct_cuda.cu:11-19).  With nyq_shim_set_error_handler installed the handler hears about it and the call
+    returns with `output` untouched: on a box without a GPU every call fails ("no HIP device"), and a call outside the static
+    48 kHz mode fails on any box -- in both cases the process must live and the output must be as it was."""
+    import ctypes as C
+    import numpy as np
+    lib = nyq.load()
+    heard = []
+    CB = C.CFUNCTYPE(None, C.c_char_p, C.c_char_p)
+    cb = CB(lambda who, what: heard.append((who.decode(), what.decode())))
+    lib.nyq_shim_set_error_handler.argtypes = [CB]
+    lib.nyq_shim_set_error_handler.restype = None
+    lib.nyq_shim_set_error_handler(cb)
+    try:
+        trig, win = np.zeros(481, np.float32), np.zeros(120, np.float32)
+        x = np.ones(960, np.float32)
+        out = np.full(960 + 60, 7.0, np.float32)
+        fp = lambda a: a.ctypes.data_as(C.c_void_p)
+        lib.processMDCTCuda(fp(x), fp(out), fp(trig), 1000, 0, 1, C.c_float(0.0), 120, fp(win))     # N is not 1920 >> shift
+        assert heard and heard[-1][0] == "processMDCTCuda" and "unsupported call" in heard[-1][1]
+        assert np.all(out == 7.0)
+        import torch
+        if not torch.cuda.is_available():
+            lib.processMDCTCuda(fp(x), fp(out), fp(trig), 1920, 0, 1, C.c_float(0.0), 120, fp(win))
+            assert "no HIP device" in heard[-1][1] and np.all(out == 7.0)
+    finally:
+        lib.nyq_shim_set_error_handler(CB(0))
