@@ -682,7 +682,8 @@ __global__ __launch_bounds__(kWave *kPipeWaves, NYQ_PIPE_MINWAVES) void celt_pos
 #pragma unroll
                 for (int q = 0; q < NLD; q++) nx[k][q] = vf4{0, 0, 0, 0};
             }
-            auto fetch = [&](long fidx) {                      // frame fidx and its parameters -> registers
+            // frame fidx (float4 columns q0 .. q1-1 of the lane) and, with column 0, its parameters -> registers
+            auto fetch = [&](long fidx, int q0, int q1) {
                 const int ln = opaque(lane);
 #pragma unroll
                 for (int k = 0; k < kPipeUnits; k++) {
@@ -691,12 +692,14 @@ __global__ __launch_bounds__(kWave *kPipeWaves, NYQ_PIPE_MINWAVES) void celt_pos
 #pragma unroll
                     for (int q = 0; q < NLD; q++) {
                         const int v = ln + q * kWave;
-                        nx[k][q] = pipe_ld(fr + (v < NV ? v : NV - 1)); // lanes past the frame re-read its last vector
+                        if (q >= q0 && q < q1) nx[k][q] = pipe_ld(fr + (v < NV ? v : NV - 1)); // lanes past the frame re-read its last vector
                     }
-                    const long pi = sU[k] * pst + fidx;
-                    pT[k] = A.pf_pitch[pi];
-                    pG[k] = A.pf_gain[pi];
-                    pS[k] = A.pf_tapset[pi];
+                    if (q0 == 0) {
+                        const long pi = sU[k] * pst + fidx;
+                        pT[k] = A.pf_pitch[pi];
+                        pG[k] = A.pf_gain[pi];
+                        pS[k] = A.pf_tapset[pi];
+                    }
                 }
             };
             // registers -> frame region of buffer b (float4 columns q0 .. q1-1 of the lane), parameter slot fidx & 1
@@ -726,9 +729,9 @@ __global__ __launch_bounds__(kWave *kPipeWaves, NYQ_PIPE_MINWAVES) void celt_pos
                 for (int j = lane; j < kPipeHist; j += kWave) bufs[k][0][j] = A.hist ? A.hist[(u0 + k) * kPostHist + OLD + j] : 0.f;
             }
             if (nfr > 0) {
-                fetch(0);
+                fetch(0, 0, NLD);
                 land(0, 0, 0, NLD);
-                if (nfr > 1) fetch(1);
+                if (nfr > 1) fetch(1, 0, NLD);
             }
             __syncthreads();
             NYQ_STAMP_DECL();
@@ -838,7 +841,9 @@ __global__ __launch_bounds__(kWave *kPipeWaves, NYQ_PIPE_MINWAVES) void celt_pos
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 NYQ_STAMP(2);                                  // slot 2: pick-up, frame f+1 -> LDS, stores of frame f-1
-                if (f + 2 < nfr) fetch(f + 2);
+                // (issuing each half's loads right behind its landing, in front of its stores, was measured: 2.5-8 % slower,
+                // profiles/r03_k_post_early_fetch_ab.jsonl)
+                if (f + 2 < nfr) fetch(f + 2, 0, NLD);
                 NYQ_STAMP(3);                                  // slot 3: fetch of frame f+2
                 if (f == nfr) {
                     // state for the next call: cur = [history in front of the next frame | ...]
