@@ -105,3 +105,34 @@ def test_bench_two_ranks_on_one_gpu():
     assert len(j["roofline"]["per_rank_kernel_avg_ms"]) == 2 and len(j["roofline"]["per_rank_frac"]) == 2
     assert j["roofline"]["kernel_avg_ms"] == max(j["roofline"]["per_rank_kernel_avg_ms"])
     assert abs(j["roofline"]["frac"] - min(j["roofline"]["per_rank_frac"])) < 1e-9
+
+
+@pytest.mark.gpu
+def test_rccl_process_group_comes_up_on_this_box():
+    """bench.py's N > 1 runs use torch.distributed's "nccl" backend (= RCCL on ROCm) for the barrier, the MAX of the times and
+    the gather of the per-rank kernel times -- never for data.  One-GPU boxes cannot run two RCCL ranks (RCCL refuses two ranks
+    on one device), but a ONE-rank group exercises the same initialisation, a GPU all-reduce, an all-gather and a barrier: if
+    this passes, `dist_backend` of a multi-GPU bench line will read "nccl" and not the gloo fallback.  Runs in a child
+    process with a time limit (a communicator that does not come up must not hang the tier)."""
+    import subprocess
+    code = r'''
+import datetime, os, sys
+import torch, torch.distributed as dist
+port = 29800 + os.getpid() % 150
+dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0,
+                        timeout=datetime.timedelta(seconds=60), device_id=torch.device("cuda", 0))
+t = torch.tensor([1.5], device="cuda", dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+g = [torch.zeros_like(t)]
+dist.all_gather(g, t)
+ones = torch.ones(1, device="cuda", dtype=torch.float64)
+dist.all_reduce(ones)
+dist.barrier()
+torch.cuda.synchronize()
+print("RCCL", dist.get_backend(), float(t.item()), float(g[0].item()), int(ones.item()))
+dist.destroy_process_group()
+'''
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    assert "RCCL nccl 1.5 1.5 1" in r.stdout, r.stdout
