@@ -83,8 +83,8 @@ int  nyq_ctx_device_info(nyq_ctx *ctx, int *compute_units, char *name, size_t na
  *                           size's chain length (16 / 32 / 32 / 64 frames for LM 3 / 2 / 1 / 0) so that the result is
  *                           bit-identical to one window; 0 = the built-in choice
  *   NYQ_OPT_CHAIN_OVERLAP   with windows: 1 = the post-filter of window k on a second stream beside the synthesis of
- *                           window k + 1 (an experiment: measured, not faster -- DESIGN.md 4.8)
- * The alternative forms (POST_FORM != pipeline, CHAIN_FUSED = 1) are measured-and-rejected designs kept for A/B
+ *                           window k + 1 (an A/B form like the two below: measured, not faster -- DESIGN.md 4.8)
+ * The alternative forms (POST_FORM != pipeline, CHAIN_FUSED = 1, CHAIN_OVERLAP = 1) are measured-and-rejected designs kept for A/B
  * runs: they exist only in the tools' build of this library (-DNYQ_AB_FORMS, tools/libnyq_imdct_ab.so);
  * the product build answers NYQ_ERR_INVALID for them.  nyq_ab_forms_built() tells which build this is. */
 #define NYQ_OPT_BLOCKS_PER_CU 1

@@ -173,6 +173,8 @@ extern "C" int nyq_ctx_set_option(nyq_ctx *ctx, int option, long value) {
         return NYQ_OK;
     case NYQ_OPT_CHAIN_OVERLAP:
         if (value != 0 && value != 1) return fail(ctx, NYQ_ERR_INVALID, "nyq_ctx_set_option: NYQ_OPT_CHAIN_OVERLAP must be 0 or 1");
+        if (value == 1 && !nyq_ab_forms_built())
+            return fail(ctx, NYQ_ERR_INVALID, "nyq_ctx_set_option: the overlapped-window chain is an A/B form (tools/libnyq_imdct_ab.so): measured, not faster");
         ctx->opt_chain_overlap = (int)value;
         return NYQ_OK;
     case NYQ_OPT_CHAIN_WINDOW:
@@ -411,6 +413,9 @@ static int synth_core(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned 
                       const float *d_state_in, float *d_state_out, float *d_work, size_t nstreams, size_t nframes,
                       int channels, size_t fstride = 0) {
     const size_t nsc = nstreams * (size_t)channels;
+    // the fix-up pass launches a (stream * channel) x (frames / 256) grid: 2^31 - 1 units, 16.7 M frames per call
+    if (nsc > 0x7fffffffu || (nframes + 255) / 256 > 65535)
+        return fail(ctx, NYQ_ERR_INVALID, "frame synthesis: more than 2^31 - 1 (stream, channel) units or 16.7 M frames in one call");
     // (slot 0 of every (stream, channel)'s tails row is unused: the fix-up pass reads the state handed in instead.  Round 2
     // kept a memset node here because the post-filter kernel behind the synthesis ran 0.9 instead of 1.6 ms with it; the
     // cause turned out to be workgroup placement of that kernel -- nyq_post_pipe.hpp, kPipeHist -- and is fixed there.)
@@ -455,9 +460,7 @@ static int synth_core(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned 
     if (A.transient) NYQ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     if (rc != NYQ_OK) return rc;
     const size_t per_block = (size_t)kWave * kFixupWaves;
-    // (grid.x = (stream, channel) units, up to 2^31 - 1; grid.y = blocks of 256 frames, up to 65535: 16.7 M frames per call)
-    if (nsc > 0x7fffffffu || (nframes + per_block - 1) / per_block > 65535)
-        return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_synth_dev: more than 2^31 - 1 (stream, channel) units or 16.7 M frames in one call");
+    // (grid.x = (stream, channel) units, grid.y = blocks of 256 frames: the limits are checked on entry)
     hipLaunchKernelGGL(synth_fixup_kernel, dim3((unsigned)nsc, (unsigned)((nframes + per_block - 1) / per_block)),
                        dim3(kWave * kFixupWaves), 0, ctx->stream, A, 120 << LM, chain_frames, ctx->d_window);
     NYQ_HIP(ctx, hipGetLastError());

@@ -155,13 +155,15 @@ def test_product_build_refuses_the_ab_forms(ctx):
         ctx.set_option(nyq.binding.OPT_CHAIN_FUSED, 1)
     with pytest.raises(nyq.NyqError):
         ctx.set_option(nyq.binding.OPT_POST_FORM, nyq.binding.POST_FORM_WAVE_PER_CHANNEL)
+    with pytest.raises(nyq.NyqError):
+        ctx.set_option(nyq.binding.OPT_CHAIN_OVERLAP, 1)
     ctx.set_option(nyq.binding.OPT_POST_FORM, nyq.binding.POST_FORM_PIPELINE)
     assert ctx.get_option(nyq.binding.OPT_CHAIN_FUSED) == 0
 
 
 @pytest.mark.parametrize("lm,ch,ns,nf,window,with_state", [(3, 2, 5, 200, 64, True), (3, 2, 3, 131, 64, False), (2, 1, 4, 300, 128, True),
                                                           (1, 2, 3, 257, 64, False), (0, 3, 2, 330, 64, True), (3, 2, 2, 128, 64, True)])
-def test_windowed_chain_is_bit_identical_to_one_window(ctx, oracle, lm, ch, ns, nf, window, with_state):
+def test_windowed_chain_is_bit_identical_to_one_window(ctx, ctx_ab, oracle, lm, ch, ns, nf, window, with_state):
     """nyq_celt_chain_dev over time windows (NYQ_OPT_CHAIN_WINDOW: synthesis and post-filter alternate over windows of 64 k
     frames, the time-domain frames of a window living in the first part of d_pcm only): the samples and every piece of
     decoder state equal the one-window call bit for bit -- with the caller's state buffers and, where the caller passes
@@ -177,8 +179,9 @@ def test_windowed_chain_is_bit_identical_to_one_window(ctx, oracle, lm, ch, ns, 
         win = _run_chain(ctx, lm, freq, tr, pitch, gain, taps, pst, ov, hist, dm, ch, fused=False, window=window)
         for a, b in zip(one, win):
             assert np.array_equal(a, b)
-        # ... and with the post-filter of window k on a second stream beside the synthesis of window k + 1
-        lap = _run_chain(ctx, lm, freq, tr, pitch, gain, taps, pst, ov, hist, dm, ch, fused=False, window=window, overlap=1)
+        # ... and with the post-filter of window k on a second stream beside the synthesis of window k + 1 (A/B build only)
+        ctx_ab.set_tables(*oracle.tables()[:2])
+        lap = _run_chain(ctx_ab, lm, freq, tr, pitch, gain, taps, pst, ov, hist, dm, ch, fused=False, window=window, overlap=1)
         for a, b in zip(one, lap):
             assert np.array_equal(a, b)
         wp, ws = oracle.celt_synth(lm, freq, tr, ov, nthreads=4)

@@ -17,7 +17,7 @@ ns = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 nf = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 case = sys.argv[3] if len(sys.argv) > 3 else "mix"
 dev = torch.device("cuda", 0)
-ctx = nyq.Context(0, ab=os.environ.get('CHAIN_WINDOWS') is None)   # A/B build unless the product's windowed chain is what is timed
+ctx = nyq.Context(0, ab=os.environ.get('CHAIN_WINDOWS') is None or 'o' in os.environ['CHAIN_WINDOWS'])   # A/B build unless the product's windowed chain is what is timed
 B = nyq.binding
 stream = torch.cuda.Stream(dev)
 torch.cuda.set_stream(stream)
