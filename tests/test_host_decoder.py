@@ -163,3 +163,20 @@ def test_plugin_surface_rejects_unknown_extension(host):
     info = np.zeros(4, np.int64)
     assert host.nyqh_nyquistio_load(b"/tmp/whatever.flac", None, 0, info) == -2      # UnsupportedExtensionEx
     assert host.nyqh_nyquistio_load(b"/nonexistent/file.opus", None, 0, info) == -1  # std::runtime_error
+
+
+def test_device_list_from_the_environment_is_parsed_strictly(host):
+    """NYQ_DEVICES / NYQ_DEVICE select the GPUs of the C batch entry points (tests and tools); anything that is not a list of
+    non-negative integers is an error with a message -- round 2 parsed with atoi, so junk silently meant device 0."""
+    import ctypes as C
+    raw = open(os.path.join(GOLDEN, "short.opus"), "rb").read()
+    files = (C.c_char_p * 1)(raw)
+    sizes = (C.c_long * 1)(len(raw))
+    ns = (C.c_long * 1)()
+    for bad in ("0,x", "zero", "0,,1", "-1", "0,"):
+        os.environ["NYQ_DEVICES"] = bad
+        try:
+            assert host.nyqh_batch_decode_files(files, sizes, 1, 1, ns, None, 0) == -1, bad
+            assert b"device list" in host.nyqh_last_error(), (bad, host.nyqh_last_error())
+        finally:
+            del os.environ["NYQ_DEVICES"]
