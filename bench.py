@@ -13,7 +13,9 @@ One "step" = one pass of nyq_imdct_batch_dev over the whole batch.  Rows shard
 embarrassingly across GPUs (each rank owns its own 2^20 rows: weak scaling, no data-path
 collective; torch.distributed is used only for the barrier and the max-over-ranks time).
 
-Rank 0 prints ONE JSON line; see README/DESIGN.md for the fields.  `roofline.achieved`
+Before its W warm-up steps every leg runs its own operator back to back for --preroll-ms (40) of GPU time, untimed, so that
+the K timed steps see the steady clocks of a running service and not the 10-20 ms ramp after idle (DESIGN.md section 6;
+config.clock_preroll_ms in the line).  Rank 0 prints ONE JSON line; see README/DESIGN.md for the fields.  `roofline.achieved`
 = 7680 algorithmic bytes x rows / mean kernel duration (HIP events on the kernel's own
 stream); `cpu_baseline` = the reference's own clt_mdct_backward (oracle/_ref, kind
 "reference") or this repo's C restatement (kind "port") timed on this host's cores over a
