@@ -49,8 +49,8 @@ def test_two_devices_equal_one_device(harness):
 def test_long_streams_in_time_slices(harness):
     """a 224 s stream is walked in time slices next to short ones"""
     out = run(harness, ["sb-reverie.opus", "corpus/st_20ms_32k.opus", "corpus/twosize_st_20ms_then_10ms_10s.opus", "short.opus"],
-              SCHED_THREADS="4", SCHED_REPS="2")
-    assert "1 batches" in out
+              SCHED_THREADS="4", SCHED_REPS="1")      # (one copy of each: two 224 s streams under TSan took 25-250 s here,
+    assert "1 batches" in out                      # depending on the kernel's page-fault mood -- sys time, not ours)
 
 
 def test_damaged_files_under_address_sanitizer():
