@@ -20,6 +20,11 @@
 #include "nyq_post_kernels.hpp"
 #include "nyq_post_pipe.hpp"
 using namespace nyq;
+#ifdef CHB_MONO
+#define CHB_PAIR false
+#else
+#define CHB_PAIR true
+#endif
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 struct Variant {
@@ -32,7 +37,11 @@ int main(int argc, char **argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 10;
     const long ns = argc > 2 ? atol(argv[2]) : 1024, nf = argc > 3 ? atol(argv[3]) : 256;
     const char *cs = argc > 4 ? argv[4] : "mix";
+#ifdef CHB_MONO   // mono streams through the generic instance (-DCHB_MONO: pass twice the stream count for the same bytes)
+    const int ch = 1, N = 960;
+#else
     const int ch = 2, N = 960;
+#endif
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
@@ -87,6 +96,7 @@ int main(int argc, char **argv) {
         char nm[128]; snprintf(nm, sizeof nm, "r1 wave per channel (occ %d blk/CU)", occ);
         v.push_back({nm, [=] { hipLaunchKernelGGL((celt_post_kernel<3, 4, 1>), dim3(grid), dim3(kWave * 4), 0, 0, A, d_win); }, {}});
     }
+#ifndef CHB_MONO
     {
         int occ = 0;
         CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, celt_post_kernel<3, 2, 2>, kWave * 2, 0));
@@ -94,12 +104,15 @@ int main(int argc, char **argv) {
         char nm[128]; snprintf(nm, sizeof nm, "r1 wave per stereo pair (occ %d blk/CU)", occ);
         v.push_back({nm, [=] { hipLaunchKernelGGL((celt_post_kernel<3, 2, 2>), dim3(grid), dim3(kWave * 2), 0, 0, A, d_win); }, {}});
     }
+#else
+    v.push_back({"(no stereo-pair form for mono)", [=] {}, {}});
+#endif
     {
         int occ = 0;
-        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, celt_post_pipe_kernel<3, true>, kWave * kPipeWaves, 0));
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, celt_post_pipe_kernel<3, CHB_PAIR>, kWave * kPipeWaves, 0));
         const unsigned grid = (unsigned)std::min<long>((ns * ch + 1) / 2, (long)occ * cus);
         char nm[128]; snprintf(nm, sizeof nm, "r2 workgroup pipeline (occ %d blk/CU, grid %u)", occ, grid);
-        v.push_back({nm, [=] { hipLaunchKernelGGL((celt_post_pipe_kernel<3, true>), dim3(grid), dim3(kWave * kPipeWaves), 0, 0, A, d_win); }, {}});
+        v.push_back({nm, [=] { hipLaunchKernelGGL((celt_post_pipe_kernel<3, CHB_PAIR>), dim3(grid), dim3(kWave * kPipeWaves), 0, 0, A, d_win); }, {}});
     }
     // experiment: the pipeline kernel behind a large memset node (a fill kernel of the runtime) on unrelated memory
     {
