@@ -85,9 +85,6 @@ def report(what, fn):
 
 
 report("post alone", post)
-report("synth + post (fill node inside synth)", lambda: (synth(), post()))
-os.environ["NYQ_SYNTH_NO_FILL"] = "1"
-report("synth + post, NYQ_SYNTH_NO_FILL=1", lambda: (synth(), post()))
-del os.environ["NYQ_SYNTH_NO_FILL"]
+report("synth + post", lambda: (synth(), post()))       # (the fill node that round 2's synthesis still had is gone: nothing to switch)
 report("memset + post", lambda: (big.zero_(), post()))
 report("post alone, again", post)
