@@ -50,14 +50,9 @@ struct nyq_ctx {
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev_block = nullptr;       // hipEventBlockingSync: host waits on it sleep instead of spinning
-    // frame synthesis runs its transient-frame kernel BESIDE the long-frame kernel (fork / join with two events: the two
-    // touch disjoint frames; capturable into a hipGraph)
-    hipStream_t s_side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int res_imdct[4] = {0, 0, 0, 0};   // resident blocks per kernel instance (occupancy query, cached)
     int res_ifft[4] = {0, 0, 0, 0};
-    int res_synth_long[4] = {0, 0, 0, 0};
-    int res_synth_short[4] = {0, 0, 0, 0};
+    int res_synth_long[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};   // [frame size][with the transient-frame role]
     int res_post[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
     int res_post_pipe[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};   // [LM][stereo instance]
     int res_chain_fused = 0;
@@ -153,8 +148,7 @@ extern "C" int nyq_ctx_set_option(nyq_ctx *ctx, int option, long value) {
     case NYQ_OPT_BLOCKS_PER_CU:
         if (value < 0 || value > 64) return fail(ctx, NYQ_ERR_INVALID, "nyq_ctx_set_option: NYQ_OPT_BLOCKS_PER_CU must be 0..64");
         if ((int)value != ctx->opt_blocks_per_cu) {            // the cached grid sizes of the row kernels depend on it
-            for (int k = 0; k < 4; k++) ctx->res_imdct[k] = ctx->res_ifft[k] = ctx->res_synth_long[k] = 0;
-            for (int k = 0; k < 4; k++) ctx->res_synth_short[k] = 0;
+            for (int k = 0; k < 4; k++) ctx->res_imdct[k] = ctx->res_ifft[k] = ctx->res_synth_long[k][0] = ctx->res_synth_long[k][1] = 0;
         }
         ctx->opt_blocks_per_cu = (int)value;
         return NYQ_OK;
@@ -215,9 +209,6 @@ extern "C" int nyq_ctx_create(nyq_ctx **out, int device) {
     hipDeviceProp_t prop;
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&ctx->s_side, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess ||
         (e = hipMalloc(&ctx->d_trig, sizeof ctx->h_trig)) != hipSuccess ||
         (e = hipMalloc(&ctx->d_window, sizeof ctx->h_window)) != hipSuccess) {
         std::string m = std::string("nyq_ctx_create: ") + hipGetErrorString(e);
@@ -252,10 +243,7 @@ extern "C" void nyq_ctx_destroy(nyq_ctx *ctx) {
     if (ctx->s_d2h) { (void)hipStreamSynchronize(ctx->s_d2h); (void)hipStreamDestroy(ctx->s_d2h); }
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->ev_block) (void)hipEventDestroy(ctx->ev_block);
-    if (ctx->s_side) { (void)hipStreamSynchronize(ctx->s_side); (void)hipStreamDestroy(ctx->s_side); }
     if (ctx->s_post) { (void)hipStreamSynchronize(ctx->s_post); (void)hipStreamDestroy(ctx->s_post); }
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_vtab) (void)hipFree(ctx->d_vtab);
     if (ctx->d_trig) (void)hipFree(ctx->d_trig);
@@ -394,15 +382,26 @@ extern "C" size_t nyq_celt_synth_work_floats(size_t nstreams, size_t nframes, in
     return nstreams * (size_t)(channels > 0 ? channels : 0) * (nframes + 1) * NYQ_HALF_OV;
 }
 
-template <int N2R>
-static int launch_synth_long(nyq_ctx *ctx, const SynthArgs &A) {
+// ONE launch for the long frames and the transient frames of a call (synth_frames_kernel): workgroups [0, nlong) take the
+// long frames -- the persistent grid of the size's measured sweet spot --, kShortWavesPerCU more per CU the transient ones
+// (they are a few per cent of the frames and finish well inside the long frames' span at one wave per CU: measured with
+// 1, 2, 3, 4 and 6, the call took the same time to 0.4 %).
+constexpr int kShortWavesPerCU = 2;
+template <int N2R, int LMc>
+static int launch_synth_frames(nyq_ctx *ctx, const SynthArgs &A, int *cache) {
     const size_t nchunks = (size_t)A.nstreams * A.channels * FrameLongRows<N2R>::chunks_per_channel(A.nframes);
-    const int res = resident_blocks(ctx, synth_long_kernel<N2R, Cfg>, &ctx->res_synth_long[Geo<N2R>::SHIFT],
-                                    N2R >= 16 ? 6 : N2R == 8 ? 8 : 7);
+    const int res = resident_blocks(ctx, synth_frames_kernel<N2R, LMc, Cfg>, cache, N2R >= 16 ? 6 : N2R == 8 ? 8 : 7);
     const size_t need = (nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
-    const unsigned grid = (unsigned)(need < (size_t)res ? need : (size_t)res);
-    hipLaunchKernelGGL((synth_long_kernel<N2R, Cfg>), dim3(grid), dim3(kWave * kWavesPerBlock), 0, ctx->stream, A,
-                       ctx->d_trig, ctx->d_window);
+    const unsigned nlong = (unsigned)(need < (size_t)res ? need : (size_t)res);
+    unsigned nshort = 0;
+    if (LMc > 0) {
+        const size_t units = (size_t)A.nstreams * A.channels * A.nframes;
+        const size_t want = (units + kWave * kWavesPerBlock - 1) / (kWave * kWavesPerBlock);
+        const size_t cap = (size_t)ctx->cus * ((kShortWavesPerCU + kWavesPerBlock - 1) / kWavesPerBlock);
+        nshort = (unsigned)(want < cap ? want : cap);
+    }
+    hipLaunchKernelGGL((synth_frames_kernel<N2R, LMc, Cfg>), dim3(nlong + nshort), dim3(kWave * kWavesPerBlock), 0, ctx->stream, A,
+                       ctx->d_trig, ctx->d_window, (int)nlong);
     NYQ_HIP(ctx, hipGetLastError());
     return NYQ_OK;
 }
@@ -431,33 +430,17 @@ static int synth_core(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned 
     A.state_out = d_state_out;
     A.fstride = (long)fstride;                      // 0: freq / transient are dense
     int rc, chain_frames;
-    const size_t units = nsc * nframes;
-    // transient frames: their own kernel, forked onto the side stream so that it runs beside the long-frame kernel (the
-    // two write disjoint frames and disjoint tails slots; the fix-up below joins them)
-    if (A.transient) {
-        NYQ_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-        NYQ_HIP(ctx, hipStreamWaitEvent(ctx->s_side, ctx->ev_fork, 0));
-        const size_t need = (units + kWave * kWavesPerBlock - 1) / (kWave * kWavesPerBlock);
-        auto launch_short = [&](auto kernel, int *cache) {
-            const int res = resident_blocks(ctx, kernel, cache);
-            const unsigned grid = (unsigned)(need < (size_t)res ? need : (size_t)res);
-            hipLaunchKernelGGL(kernel, dim3(grid), dim3(kWave * kWavesPerBlock), 0, ctx->s_side, A, ctx->d_trig, ctx->d_window);
-        };
-        switch (LM) {
-        case 3: launch_short(synth_short_kernel<3, Cfg>, &ctx->res_synth_short[3]); break;
-        case 2: launch_short(synth_short_kernel<2, Cfg>, &ctx->res_synth_short[2]); break;
-        default: launch_short(synth_short_kernel<1, Cfg>, &ctx->res_synth_short[1]); break;
-        }
-        NYQ_HIP(ctx, hipGetLastError());
-        NYQ_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->s_side));
-    }
+    // [LM][with transient frames]: the instance without the transient role is what chains and flag-less calls launch
+    const bool tr = A.transient != nullptr;
     switch (LM) {
-    case 3: rc = launch_synth_long<32>(ctx, A); chain_frames = Geo<32>::CHAIN_FRAMES; break;
-    case 2: rc = launch_synth_long<16>(ctx, A); chain_frames = Geo<16>::CHAIN_FRAMES; break;
-    case 1: rc = launch_synth_long<8>(ctx, A); chain_frames = Geo<8>::CHAIN_FRAMES; break;
-    default: rc = launch_synth_long<4>(ctx, A); chain_frames = Geo<4>::CHAIN_FRAMES; break;
+    case 3: rc = tr ? launch_synth_frames<32, 3>(ctx, A, &ctx->res_synth_long[0][1]) : launch_synth_frames<32, 0>(ctx, A, &ctx->res_synth_long[0][0]);
+            chain_frames = Geo<32>::CHAIN_FRAMES; break;
+    case 2: rc = tr ? launch_synth_frames<16, 2>(ctx, A, &ctx->res_synth_long[1][1]) : launch_synth_frames<16, 0>(ctx, A, &ctx->res_synth_long[1][0]);
+            chain_frames = Geo<16>::CHAIN_FRAMES; break;
+    case 1: rc = tr ? launch_synth_frames<8, 1>(ctx, A, &ctx->res_synth_long[2][1]) : launch_synth_frames<8, 0>(ctx, A, &ctx->res_synth_long[2][0]);
+            chain_frames = Geo<8>::CHAIN_FRAMES; break;
+    default: rc = launch_synth_frames<4, 0>(ctx, A, &ctx->res_synth_long[3][0]); chain_frames = Geo<4>::CHAIN_FRAMES; break;
     }
-    if (A.transient) NYQ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     if (rc != NYQ_OK) return rc;
     const size_t per_block = (size_t)kWave * kFixupWaves;
     // (grid.x = (stream, channel) units, grid.y = blocks of 256 frames: the limits are checked on entry)

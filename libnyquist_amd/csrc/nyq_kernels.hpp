@@ -5,9 +5,9 @@
 // Kernels (all wave-autonomous: 64 lanes own 4 rows, meet only in their LDS slice):
 //   imdct_rows_kernel<N2R,Cfg>  clt_mdct_backward  (mdct.c:267-379)  on independent rows
 //   ifft_rows_kernel<N2R,WPB>   opus_ifft          (kiss_fft.c:696-747)
-//   synth_long_kernel<N2R,Cfg>  compute_inv_mdcts (celt_decoder_clean.c:264-312), long frames,
-//                               16-frame chunks chained in-wave
-//   synth_short_kernel<Cfg>     the same for the interleaved short blocks of transient frames
+//   synth_frames_kernel<N2R,LMc,Cfg>  compute_inv_mdcts (celt_decoder_clean.c:264-312): workgroups [0, nlong) the long
+//                               frames (chunks of 4 G frames chained in-wave), the others the interleaved short blocks
+//                               of the transient frames
 //   synth_fixup_kernel          adds the carry terms of the TDAC mirror (mdct.c:371-372) to the
 //                               few heads that could not be chained in-wave
 #pragma once
@@ -176,12 +176,17 @@ __global__ __launch_bounds__(kWave *Cfg::WPB) void imdct_rows_kernel(
 }
 
 // ---- frame sequences: the compute_inv_mdcts replacement (celt_decoder_clean.c:264-312) ----
+// ONE launch, two roles by workgroup index (round 3): workgroups [0, nlong) run the long frames, the rest the transient
+// frames.  (Rounds 1-2 launched the transient-frame kernel on a side stream between two events: whether it then ran BESIDE
+// the long-frame kernel or behind it depended on which hardware queue the runtime had given that stream -- identical
+// builds of the chain differed by 0.1 ms, 6 %, inside one process.  One dispatch has no such lottery, and two events and
+// a launch less.)  LMc = log2 of the short blocks per transient frame; 0 = the call has no transient frames.
+
 // Long frames: chunks of 4 G consecutive frames of one (stream, channel), chained in-wave.
 template <int N2R, typename Cfg>
-__global__ __launch_bounds__(kWave *Cfg::WPB) void synth_long_kernel(SynthArgs A, const float *__restrict__ trig,
-                                                                      const float *__restrict__ window) {
+__device__ __forceinline__ void synth_long_role(const SynthArgs &A, const float *__restrict__ trig, const float *__restrict__ window,
+                                                float *smem, long bid, long nblocks) {
     using WL = WaveLds<N2R, Cfg::WPB, true>;
-    __shared__ __attribute__((aligned(16))) float smem[WL::TOTAL];
     const int lane = threadIdx.x & (kWave - 1);
     const int wv = threadIdx.x >> 6;
     cpx *lds = reinterpret_cast<cpx *>(smem + wv * WL::PER_WAVE);
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(kWave *Cfg::WPB) void synth_long_kernel(SynthArgs A
     lane_init<N2R>(K, lane, trig, window);
 
     const long nchunks = A.nstreams * A.channels * FrameLongRows<N2R>::chunks_per_channel(A.nframes);
-    const long nwaves = (long)gridDim.x * Cfg::WPB;
+    const long nwaves = nblocks * Cfg::WPB;
     // The transient flags of a chunk in one go -- lane i holds frame (chunk start - 1 + i), a ballot makes the mask --
     // and one chunk AHEAD: the flag bytes of the next chunk are on their way while this one is transformed.
     auto flag_of = [&](long ci) {
@@ -204,8 +209,8 @@ __global__ __launch_bounds__(kWave *Cfg::WPB) void synth_long_kernel(SynthArgs A
         }
         return tr;
     };
-    bool tr_next = flag_of((long)blockIdx.x * Cfg::WPB + wv);
-    for (long ci = (long)blockIdx.x * Cfg::WPB + wv; ci < nchunks; ci += nwaves) {
+    bool tr_next = flag_of(bid * Cfg::WPB + wv);
+    for (long ci = bid * Cfg::WPB + wv; ci < nchunks; ci += nwaves) {
         const unsigned long long tmask = __ballot(tr_next);
         tr_next = flag_of(ci + nwaves);
 #pragma unroll 1
@@ -225,18 +230,15 @@ __global__ __launch_bounds__(kWave *Cfg::WPB) void synth_long_kernel(SynthArgs A
 // 16 / B of the transient ones among them as ONE group of 16 rows (FrameShortPacked: unit k owns rows k B ..); blocks of a
 // unit chain through the tail ring, its last block publishes the frame's tail.  LMc = log2 B.
 template <int LMc, typename Cfg>
-__global__ __launch_bounds__(kWave *Cfg::WPB) void synth_short_kernel(SynthArgs A, const float *__restrict__ trig,
-                                                                       const float *__restrict__ window) {
+__device__ __forceinline__ void synth_short_role(const SynthArgs &A, const float *__restrict__ trig, const float *__restrict__ window,
+                                                 float *smem, ShortUnit *utab_all, long bid, long nblocks) {
     using WL = WaveLds<4, Cfg::WPB, true>;
     using Rows = FrameShortPacked<LMc>;
-    __shared__ __attribute__((aligned(16))) float smem[WL::TOTAL];
     const int lane = threadIdx.x & (kWave - 1);
     const int wv = threadIdx.x >> 6;
     cpx *lds = reinterpret_cast<cpx *>(smem + wv * WL::PER_WAVE);
     float *ring = smem + wv * WL::PER_WAVE + WL::ROW_FLOATS;
-
-    __shared__ ShortUnit utab_all[Cfg::WPB][Rows::K];
-    ShortUnit *utab = utab_all[wv];
+    ShortUnit *utab = utab_all + wv * Rows::K;
 
     LaneConst<4> K;
     lane_init<4>(K, lane, trig, window);
@@ -246,8 +248,8 @@ __global__ __launch_bounds__(kWave *Cfg::WPB) void synth_short_kernel(SynthArgs 
     // and then takes the set bits Rows::K at a time: the lane that owns the r-th of them writes row r of the unit table
     // from the indices it computed for the scan.
     const long units = A.nstreams * A.channels * A.nframes;
-    const long nwaves = (long)gridDim.x * Cfg::WPB;
-    for (long base = ((long)blockIdx.x * Cfg::WPB + wv) * kWave; base < units; base += nwaves * kWave) {
+    const long nwaves = nblocks * Cfg::WPB;
+    for (long base = (bid * Cfg::WPB + wv) * kWave; base < units; base += nwaves * kWave) {
         const long mine = base + lane;
         bool hit = false;
         long s = 0, c = 0, f = 0;
@@ -274,6 +276,23 @@ __global__ __launch_bounds__(kWave *Cfg::WPB) void synth_short_kernel(SynthArgs 
             run_group<4, Cfg>(K, lane, lds, ring, rows, R);
         }
     }
+}
+
+template <int N2R, int LMc, typename Cfg>
+__global__ __launch_bounds__(kWave *Cfg::WPB) void synth_frames_kernel(SynthArgs A, const float *__restrict__ trig,
+                                                                        const float *__restrict__ window, int nlong) {
+    using WLL = WaveLds<N2R, Cfg::WPB, true>;
+    using WLS = WaveLds<4, Cfg::WPB, true>;
+    constexpr int kFloats = (LMc > 0 && WLS::TOTAL > WLL::TOTAL) ? WLS::TOTAL : WLL::TOTAL;
+    __shared__ __attribute__((aligned(16))) float smem[kFloats];
+    if constexpr (LMc > 0) {
+        __shared__ ShortUnit utab[Cfg::WPB * FrameShortPacked<LMc>::K];
+        if ((int)blockIdx.x >= nlong) {
+            synth_short_role<LMc, Cfg>(A, trig, window, smem, utab, (long)blockIdx.x - nlong, (long)gridDim.x - nlong);
+            return;
+        }
+    }
+    synth_long_role<N2R, Cfg>(A, trig, window, smem, (long)blockIdx.x, (long)nlong);
 }
 
 // Heads that were mirrored against zeros receive their carry: slot f of the tails buffer holds

@@ -4,7 +4,7 @@
 Usage: tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <rows> <out.json>
 
 Emits one record per kernel of interest -- the headline kernel `imdct_rows_kernel<32>` (what bench.py's
-`roofline.traffic` quotes), and the two stages of the frames -> PCM chain, `synth_long_kernel<32>` and the post-filter
+`roofline.traffic` quotes), and the two stages of the frames -> PCM chain, `synth_frames_kernel<32, 3>` (key `synth_long_kernel<32>`, its name before round 3's single launch) and the post-filter
 kernel (`celt_post_pipe_kernel<3>`, or `celt_post_kernel<3,...>` when the round-1 form ran) -- each with its algorithmic
 bytes and the ratio to them, plus the sha of the kernel sources the passes were taken with: bench.py replays the
 headline figure only while `libnyquist_amd/csrc` still has that sha.
@@ -48,15 +48,15 @@ def main():
     chain_units = 1024 * 256 * 2          # bench.py's frames -> PCM leg: streams x frames x channels
     recs = {"imdct_rows_kernel<32>": record(fetch_csv, write_csv, "imdct_rows_kernelILi32E", 7680 * rows) or
             record(fetch_csv, write_csv, "imdct_rows_kernel<32", 7680 * rows),
-            "synth_long_kernel<32>": record(fetch_csv, write_csv, "synth_long_kernelILi32E", 7680 * chain_units) or
-            record(fetch_csv, write_csv, "synth_long_kernel<32", 7680 * chain_units),
+            "synth_long_kernel<32>": record(fetch_csv, write_csv, "synth_frames_kernelILi32ELi3", 7680 * chain_units) or
+            record(fetch_csv, write_csv, "synth_frames_kernel<32, 3", 7680 * chain_units),
             "post_filter_kernel": record(fetch_csv, write_csv, "celt_post_pipe_kernel", 7680 * chain_units) or
             record(fetch_csv, write_csv, "celt_post_kernel", 7680 * chain_units)}
     head_rec = recs["imdct_rows_kernel<32>"]
     d = {"rows": rows, "kernel": "imdct_rows_kernel<32>", "csrc_sha16": csrc_digest(), "git_head": head,
          "measured_on": datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%dT%H:%MZ"),
          "corrections": "FETCH_SIZE x2 (gfx950 wide-read under-count), KiB -> bytes x1024; separate --pmc passes",
-         "note": "synth_long_kernel<32> is the long-frame part of the synthesis stage (2.8 % of the frames are transient and go "
+         "note": "synth_long_kernel<32> = synth_frames_kernel<32, 3>, long-frame and transient-frame roles in one launch since round 3 (before: the long-frame part only; 2.8 % of the frames are transient and went "
                  "through synth_short_kernel): its algorithmic bytes are counted for all frames, so its ratio reads slightly low",
          "kernels": recs}
     if head_rec:
