@@ -385,8 +385,10 @@ extern "C" size_t nyq_celt_synth_work_floats(size_t nstreams, size_t nframes, in
 // ONE launch for the long frames and the transient frames of a call (synth_frames_kernel): workgroups [0, nlong) take the
 // long frames -- the persistent grid of the size's measured sweet spot --, kShortWavesPerCU more per CU the transient ones
 // (they are a few per cent of the frames and finish well inside the long frames' span at one wave per CU: measured with
-// 1, 2, 3, 4 and 6, the call took the same time to 0.4 %).
-constexpr int kShortWavesPerCU = 2;
+// 1, 2, 3, 4 and 6, the call took the same time to 0.4 %).  ONE, not more: the 960- and 480-sample instances take 205 / 175
+// VGPRs (a cap of 168 makes them spill), i.e. eight waves fit a CU, six are the long frames' -- a seventh leaves a slot of
+// slack, an eighth would be the exact fit that places long-lived workgroups late (nyq_post_pipe.hpp).
+constexpr int kShortWavesPerCU = 1;
 template <int N2R, int LMc>
 static int launch_synth_frames(nyq_ctx *ctx, const SynthArgs &A, int *cache) {
     const size_t nchunks = (size_t)A.nstreams * A.channels * FrameLongRows<N2R>::chunks_per_channel(A.nframes);
