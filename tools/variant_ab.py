@@ -77,7 +77,11 @@ def run(ns, nf, cases):
             tap = torch.randint(0, 3, (ns, nf), generator=g, device=dev, dtype=torch.int32)
         ctxs[0].celt_synth_dev(3, freq.data_ptr(), trans.data_ptr(), pcm.data_ptr(), 0, work.data_ptr(), ns, nf, ch)
         torch.cuda.synchronize(dev)
-        ops = {"post": lambda c: c.celt_post_dev(3, pcm.data_ptr(), pitch.data_ptr(), gain.data_ptr(), tap.data_ptr(), 0, 0, 0, 0, out.data_ptr(), ns, nf, ch),
+        rows = ns * nf * ch
+        tail_buf = torch.empty((rows, 60), device=dev)
+        ops = {"imdct_rows": lambda c: c.imdct_batch_dev(0, freq.data_ptr(), 0, pcm.data_ptr(), tail_buf.data_ptr(), rows),
+               "synth": lambda c: c.celt_synth_dev(3, freq.data_ptr(), trans.data_ptr(), pcm.data_ptr(), 0, work.data_ptr(), ns, nf, ch),
+               "post": lambda c: c.celt_post_dev(3, pcm.data_ptr(), pitch.data_ptr(), gain.data_ptr(), tap.data_ptr(), 0, 0, 0, 0, out.data_ptr(), ns, nf, ch),
                "chain": lambda c: c.celt_chain_dev(3, freq.data_ptr(), trans.data_ptr(), pitch.data_ptr(), gain.data_ptr(), tap.data_ptr(), 0, 0, 0, 0, 0,
                                                    out.data_ptr(), pcm.data_ptr(), work.data_ptr(), ns, nf, ch)}
         for opname, op in ops.items():
