@@ -78,13 +78,16 @@ int  nyq_ctx_device_info(nyq_ctx *ctx, int *compute_units, char *name, size_t na
  *                           (a profiling knob: the occupancy caches of the context are dropped when it changes)
  *   NYQ_OPT_POST_FORM       kernel form of nyq_celt_post_dev: NYQ_POST_FORM_PIPELINE (default, the only form in the
  *                           product build), NYQ_POST_FORM_WAVE_PER_CHANNEL, NYQ_POST_FORM_WAVE_PER_PAIR
- *   NYQ_OPT_CHAIN_FUSED     nyq_celt_chain_dev: 1 = the one-launch kernel where nyq_celt_chain_fused_supported()
+ *   NYQ_OPT_CHAIN_FUSED     nyq_celt_chain_dev, where nyq_celt_chain_fused_supported(): NYQ_CHAIN_ONE_LAUNCH (default: the
+ *                           post-filter's workgroup plus a transform wave working in place in its frame regions),
+ *                           NYQ_CHAIN_TWO_KERNELS (synthesis + post-filter through d_pcm, the form of every other shape),
+ *                           NYQ_CHAIN_FUSED_R2 (round 2's fused kernel: A/B build only, 3x slower)
  *   NYQ_OPT_CHAIN_WINDOW    nyq_celt_chain_dev: frames per time window of the two-kernel chain, rounded up to the frame
  *                           size's chain length (16 / 32 / 32 / 64 frames for LM 3 / 2 / 1 / 0) so that the result is
  *                           bit-identical to one window; 0 = the built-in choice
  *   NYQ_OPT_CHAIN_OVERLAP   with windows: 1 = the post-filter of window k on a second stream beside the synthesis of
  *                           window k + 1 (an A/B form like the two below: measured, not faster -- DESIGN.md 4.8)
- * The alternative forms (POST_FORM != pipeline, CHAIN_FUSED = 1, CHAIN_OVERLAP = 1) are measured-and-rejected designs kept for A/B
+ * The alternative forms (POST_FORM != pipeline, CHAIN_FUSED = FUSED_R2, CHAIN_OVERLAP = 1) are measured-and-rejected designs kept for A/B
  * runs: they exist only in the tools' build of this library (-DNYQ_AB_FORMS, tools/libnyq_imdct_ab.so);
  * the product build answers NYQ_ERR_INVALID for them.  nyq_ab_forms_built() tells which build this is. */
 #define NYQ_OPT_BLOCKS_PER_CU 1
@@ -92,6 +95,9 @@ int  nyq_ctx_device_info(nyq_ctx *ctx, int *compute_units, char *name, size_t na
 #define NYQ_OPT_CHAIN_FUSED   3
 #define NYQ_OPT_CHAIN_WINDOW  4
 #define NYQ_OPT_CHAIN_OVERLAP 5
+#define NYQ_CHAIN_TWO_KERNELS 0
+#define NYQ_CHAIN_ONE_LAUNCH  1
+#define NYQ_CHAIN_FUSED_R2    2
 #define NYQ_POST_FORM_PIPELINE         0
 #define NYQ_POST_FORM_WAVE_PER_CHANNEL 1
 #define NYQ_POST_FORM_WAVE_PER_PAIR    2

@@ -14,8 +14,10 @@ CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libnyq_imdct.so")
 LIB_AB = os.path.join(ROOT, "tools", "libnyq_imdct_ab.so")   # the same + the A/B kernel forms (-DNYQ_AB_FORMS): tools and tests only
 SOURCES = [os.path.join(CSRC, "nyq_imdct.hip")]
+AB_DIR = os.path.join(ROOT, "tools", "ab")                     # sources of the measured-and-rejected kernel forms (A/B build only)
 DEPS = sorted(set(SOURCES + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.hip"))
                   + [os.path.join(ROOT, "include", "nyq_imdct.h")]))
+DEPS_AB = sorted(set(DEPS + glob.glob(os.path.join(AB_DIR, "*.hpp"))))
 
 
 def hipcc():
@@ -30,7 +32,7 @@ def stale(lib=None):
     if not os.path.exists(lib):
         return True
     t = os.path.getmtime(lib)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    return any(os.path.getmtime(d) > t for d in (DEPS_AB if lib == LIB_AB else DEPS))
 
 
 def build(force=False, verbose=False):
@@ -52,7 +54,7 @@ def build_ab(force=False, verbose=False):
     fused chain kernel compiled in, selectable through nyq_ctx_set_option).  Not part of the product."""
     if not force and not stale(LIB_AB):
         return LIB_AB
-    cmd = [hipcc(), "-O3", "-fno-slp-vectorize", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-DNYQ_AB_FORMS",
+    cmd = [hipcc(), "-O3", "-fno-slp-vectorize", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-DNYQ_AB_FORMS", "-I" + AB_DIR, "-I" + CSRC,
            "-Wl,-Bsymbolic-functions", "-o", LIB_AB] + SOURCES
     if verbose:
         print(" ".join(cmd))

@@ -1,0 +1,379 @@
+// nyq_chain_kernel.hpp -- freq[] -> interleaved PCM in ONE launch (round 4: the third fusion, the one that ships).
+//
+// Everything celt_decode_with_ec does after denormalise_bands (celt_decoder_clean.c:620-723) for many stereo 20 ms
+// streams at once:  compute_inv_mdcts (:264-312, clt_mdct_backward mdct.c:267-379)  ->  comb_filter (celt.c:114-172 as
+// applied :658-683)  ->  deemphasis (:192-256) with scaling and channel interleave.  The two-kernel chain
+// (nyq_celt_synth_dev + nyq_celt_post_dev) writes the time-domain frame to HBM and reads it back: 2 x 7680 B per
+// channel-frame.  Here it never leaves the CU: 3840 B in, 3840 B out.
+//
+// Workgroup = the post-filter pipeline of nyq_post_pipe.hpp (one stereo stream = 2 chains) plus ONE transform wave:
+//     wave 0, 1   comb wave of chain 0 / 1: the recursion of frame f, nothing else (unchanged)
+//     wave 2      I/O wave: de-emphasis + interleave + 16-byte global stores of frame f-1 STRAIGHT out of the filtered
+//                 history (two adjacent samples of both channels per lane: the output's own order, so there is no staging
+//                 pass and the frame region of `nxt` is free), history carry-over, post-filter parameters of frame f+1
+//     wave 3      transform wave: the inverse MDCT of frame f+1 of both channels IN PLACE in the frame regions of `nxt`
+//                 (nyq_fuse_lanes.hpp: no LDS of its own), the coefficients of frame f+2 prefetched into registers
+//   one s_barrier per frame, 32 544 B of LDS as before: four workgroups (8 chains, 16 waves) per CU, 128 VGPRs.
+// What made the earlier fusions lose was the transform's 16 KB LDS slice per wave against the 8
+// resident chains x 16 KB the recursion needs; this transform needs none.
+#pragma once
+#include "nyq_fuse_lanes.hpp"
+#include "nyq_kernels.hpp"
+#include "nyq_post_pipe.hpp"
+
+namespace nyq {
+
+constexpr int kChainWaves = 4;     // 2 comb + I/O + transform
+
+struct ChainArgs {
+    const float *freq;               // [nstreams][nframes][2][960]   as the decoder leaves freq[]
+    const unsigned char *transient;  // [nstreams][nframes] or null
+    float *ov_state;                 // [nstreams*2][60] overlap carry in/out, or null (zeros, discarded)
+    const int *pf_pitch;             // [nstreams][nframes]
+    const float *pf_gain;
+    const int *pf_tapset;
+    const float *pf_state;           // [nstreams][6] or null
+    float *pf_state_out;             // must not alias pf_state
+    float *hist;                     // [nstreams*2][1088] filtered history in/out, or null
+    float *deemph;                   // [nstreams*2] in/out, or null
+    float *out;                      // [nstreams][nframes*960][2]
+    long nstreams, nframes;
+    // freq / transient, and pf_* / out, may be WINDOWS into longer per-stream arrays: consecutive streams are `fstride` /
+    // `pstride` frames apart (0 = dense: nframes)
+    long fstride, pstride;
+    __host__ __device__ long fs() const { return fstride ? fstride : nframes; }
+    __host__ __device__ long ps() const { return pstride ? pstride : nframes; }
+};
+
+// weighted inclusive scan over the 64 lanes, ratio q per lane (the DPP steps of deemph_frames)
+__device__ __forceinline__ float deemph_scan(float e, const DeConst &D) {
+    e += D.cstep[0] * dpp_zero<0x111, 0xf>(e);      // row_shr:1
+    e += D.cstep[1] * dpp_zero<0x112, 0xf>(e);      // row_shr:2
+    e += D.cstep[2] * dpp_zero<0x114, 0xf>(e);      // row_shr:4
+    e += D.cstep[3] * dpp_zero<0x118, 0xf>(e);      // row_shr:8
+    e += D.wA * dpp_zero<0x142, 0xa>(e);            // row_bcast:15 into rows 1, 3
+    e += D.wB * dpp_zero<0x143, 0xc>(e);            // row_bcast:31 into rows 2, 3
+    return e;
+}
+
+// scan constants for CH consecutive samples per lane, all 64 lanes (ratio q = c^CH)
+template <int CH>
+__device__ __forceinline__ void deemph_init_lanes(DeConst &D, float &pwHalf, int lane) {
+    float q = 1.f;
+#pragma unroll
+    for (int k = 0; k < CH; k++) q *= kPreemph;
+    float st[7];
+    st[0] = q;
+#pragma unroll
+    for (int k = 1; k < 7; k++) st[k] = st[k - 1] * st[k - 1];
+    auto powq = [&](int e) {
+        float r = 1.f;
+#pragma unroll
+        for (int k = 0; k < 7; k++)
+            if (e & (1 << k)) r *= st[k];
+        return r;
+    };
+#pragma unroll
+    for (int k = 0; k < 4; k++) D.cstep[k] = st[k];
+    D.wA = powq((lane & 15) + 1);
+    D.wB = powq(lane >= 32 ? lane - 31 : 0);
+    D.pw = powq(lane);
+    D.pwEnd = st[6];      // q^64
+    pwHalf = st[5];       // q^32
+}
+
+// deemphasis() (celt_decoder_clean.c:243-248) + 1/32768 + stereo interleave of ONE frame, from the filtered samples in
+// LDS straight to global memory: lane l of block b owns samples 2 (l + 64 b), + 1 of both channels = float4 l + 64 b of
+// the interleaved frame.  Per block: two-sample recurrence, one weighted scan over the lanes, carry from the block before.
+template <int N>
+__device__ __forceinline__ void deemph_store_pair(const float *sL, const float *sR, vf4 *d4, float &memL, float &memR,
+                                                  int lane, const DeConst &D, float pwHalf) {
+    constexpr int NV2 = N / 2;                       // float4 of the interleaved frame
+    constexpr int NB = (NV2 + kWave - 1) / kWave;    // blocks of 64
+    static_assert(NV2 % kWave == 0 || NV2 % kWave == 32, "the last block is whole or half");
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        const int v = lane + b * kWave;
+        const bool on = v < NV2;
+        const int vv = on ? v : 0;
+        const float2 l = *reinterpret_cast<const float2 *>(sL + 2 * vv);
+        const float2 r = *reinterpret_cast<const float2 *>(sR + 2 * vv);
+        const float l0 = l.x + 1e-30f, r0 = r.x + 1e-30f;                    // + VERY_SMALL
+        const float l1 = (l.y + 1e-30f) + kPreemph * l0, r1 = (r.y + 1e-30f) + kPreemph * r0;
+        const float eL = deemph_scan(on ? l1 : 0.f, D), eR = deemph_scan(on ? r1 : 0.f, D);
+        // value entering the lane's pair: c t[2l-1] = c e[l-1] + q^l mem, with mem = c t[-1]
+        const float cL = kPreemph * dpp_shr1(0.f, eL) + D.pw * memL, cR = kPreemph * dpp_shr1(0.f, eR) + D.pw * memR;
+        const vf4 o = {(l0 + cL) * (1.f / 32768.f), (r0 + cR) * (1.f / 32768.f), (l1 + kPreemph * cL) * (1.f / 32768.f),
+                       (r1 + kPreemph * cR) * (1.f / 32768.f)};
+        if (on) pipe_st(d4 + v, o);
+        const bool half = (b + 1) * kWave > NV2;     // the last block ends at lane 31
+        const int last = half ? 31 : 63;
+        const float pe = half ? pwHalf : D.pwEnd;
+        memL = kPreemph * __shfl(eL, last) + pe * memL;
+        memR = kPreemph * __shfl(eR, last) + pe * memR;
+    }
+}
+
+// ---- the transform wave's frame: coefficients in R -> finished samples in reg[0], reg[1] ----
+// (the tails travel as native vectors: an array of 16-byte structs is copied with memcpy and stays in scratch memory)
+__device__ __forceinline__ void xf_long_frame(const fx::XfRegs &R, const fx::XfConst &K, int lane, float *const (&reg)[2], vf4 &tail0, vf4 &tail1) {
+    using namespace fx;
+#pragma unroll
+    for (int r = 0; r < 2; r++) xf_long_s0(R, K, opaque(lane), r, reg[r]);
+    NYQ_WAVE_SYNC();
+    {
+        cpx u[16];
+        const int ln = opaque(lane);
+        xf_long_s2_load(ln, reg, u);
+        xf_long_s2_store(ln, reg, u);
+    }
+    NYQ_WAVE_SYNC();
+    {
+        cpx v[15];
+        const int ln = opaque(lane);
+        xf_long_s3_load(ln, reg, v);
+        NYQ_WAVE_SYNC();
+        xf_long_s3_store(ln, reg, v);
+    }
+    NYQ_WAVE_SYNC();
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        XfOut O;
+        const int ln = opaque(lane);
+        xf_long_s4_load(K, ln, reg[r], O);
+        NYQ_WAVE_SYNC();
+        vf4 &tv = r ? tail1 : tail0;
+        f4 t = {tv.x, tv.y, tv.z, tv.w};
+        xf_long_s4_store(K, ln, reg[r], O, t);
+        tv = vf4{t.x, t.y, t.z, t.w};
+    }
+    NYQ_WAVE_SYNC();
+}
+
+__device__ __forceinline__ void xf_short_frame(const fx::XfRegs &R, const fx::XfConst &K, int lane, float *const (&reg)[2], vf4 &tail0, vf4 &tail1,
+                                               const float *__restrict__ trig) {
+    using namespace fx;
+    // (the short program's six rotation values are fetched where a transient frame needs them: a few per cent of the frames)
+    XfShortConst S;
+    xf_short_init(S, opaque(lane), trig);
+    xf_short_t0(R, opaque(lane), reg);
+    NYQ_WAVE_SYNC();
+#pragma unroll 1
+    for (int s = 0; s < 4; s++) {
+        XfShortIn I;
+        const int ln = opaque(lane);
+        xf_short_t1_load(ln, s, reg, I);
+        NYQ_WAVE_SYNC();
+        xf_short_t1_store(S, ln, s, reg, I);
+        NYQ_WAVE_SYNC();
+    }
+#pragma unroll 1
+    for (int it = 0; it < 4; it++) xf_short_t2(opaque(lane), it, reg);
+    NYQ_WAVE_SYNC();
+    {
+        cpx v[15];
+        const int ln = opaque(lane);
+        xf_short_t3_load(ln, reg, v);
+        NYQ_WAVE_SYNC();
+        xf_short_t3_store(ln, reg, v);
+    }
+    NYQ_WAVE_SYNC();
+    vf4 bk7a = {0, 0, 0, 0}, bk7b = {0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const f4 bk = xf_short_t4(S, opaque(lane), s, reg);
+        if (s == 1) bk7a = vf4{bk.x, bk.y, bk.z, bk.w};
+        if (s == 3) bk7b = vf4{bk.x, bk.y, bk.z, bk.w};
+    }
+    NYQ_WAVE_SYNC();
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int h = 1; h >= 0; h--) {
+            XfMirror M;
+            const int ln = opaque(lane);
+            const vf4 tv = c ? tail1 : tail0;
+            xf_short_t5_load(ln, c, h, reg, f4{tv.x, tv.y, tv.z, tv.w}, M);
+            NYQ_WAVE_SYNC();
+            xf_short_t5_store(K, ln, c, h, reg, M);
+            NYQ_WAVE_SYNC();
+        }
+    // the frame's tails: raw second half of block 7 of each channel, from the lanes that post-rotated it
+    const int src = short_tail_src(lane);
+    tail0 = vf4{__shfl(bk7a.x, src), __shfl(bk7a.y, src), __shfl(bk7a.z, src), __shfl(bk7a.w, src)};
+    tail1 = vf4{__shfl(bk7b.x, src), __shfl(bk7b.y, src), __shfl(bk7b.z, src), __shfl(bk7b.w, src)};
+}
+
+#ifndef NYQ_CHAIN_MINWAVES
+#define NYQ_CHAIN_MINWAVES 4
+#endif
+
+// LM 3 (20 ms frames), stereo streams.  Workgroup unit = one stream.
+__global__ __launch_bounds__(kWave *kChainWaves, NYQ_CHAIN_MINWAVES) void celt_chain_kernel(ChainArgs A, const float *__restrict__ trig,
+                                                                                     const float *__restrict__ window) {
+    constexpr int N = fx::kN;
+    constexpr int R0 = kPipeHist;
+    constexpr int KEEP = kPipeHist - N;
+    constexpr int OLD = kPostHist - kPipeHist;
+    static_assert(N >= OLD, "the previous buffer still holds the history the state hand-over needs");
+    __shared__ __attribute__((aligned(16))) float bufs[kPipeUnits][2][kPipeHist + N];
+    __shared__ __attribute__((aligned(16))) float win2[kOverlap];
+    __shared__ __attribute__((aligned(16))) PipeParams pslot[2];           // [frame parity]: both chains share the stream's parameters
+    for (int i = threadIdx.x; i < kOverlap; i += kWave * kChainWaves) win2[i] = window[i] * window[i];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long nfr = A.nframes;
+    const long pst = A.ps(), fst = A.fs();
+    __syncthreads();
+
+    // Every role runs the same unit loop and the same barriers per unit: P (prologues done), then nfr + 1 frame barriers
+    // (the last also separates this unit's LDS use from the next unit's prologue).
+    if (wave < kPipeUnits) {
+        // ------------------------------- comb wave of chain `wave` (as nyq_post_pipe.hpp) -------------------------------
+        __builtin_amdgcn_s_setprio(3);
+        for (long s = blockIdx.x; s < A.nstreams; s += gridDim.x) {
+            float *bA = bufs[wave][0], *bB = bufs[wave][1];
+            int T_old = 0, T_cur = 0, ts_old = 0, ts_cur = 0;
+            float g_old = 0.f, g_cur = 0.f;
+            if (A.pf_state) {
+                const float *ps = A.pf_state + 6 * s;
+                T_old = (int)ps[0]; T_cur = (int)ps[1]; g_old = ps[2]; g_cur = ps[3]; ts_old = (int)ps[4]; ts_cur = (int)ps[5];
+            }
+            __syncthreads();                                                   // P
+            for (long f = 0; f <= nfr; f++) {
+                if (f < nfr) {
+                    float *cur = (f & 1) ? bB : bA, *nxt = (f & 1) ? bA : bB;
+                    float *mir = nxt - N;                                      // mir[idx] = nxt[idx - N]
+                    const PipeParams P = pslot[f & 1];
+                    const int T_new = __builtin_amdgcn_readfirstlane(P.T), ts_new = __builtin_amdgcn_readfirstlane(P.ts);
+                    const float g_new = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, P.g)));
+                    if (T_cur < kCombMinPeriod) T_cur = kCombMinPeriod;       // celt_decoder_clean.c:661-662
+                    if (T_old < kCombMinPeriod) T_old = kCombMinPeriod;
+                    if (T_cur > kCombMaxPeriod) T_cur = kCombMaxPeriod;
+                    if (T_old > kCombMaxPeriod) T_old = kCombMaxPeriod;
+                    const int T_nw = T_new < kCombMinPeriod ? kCombMinPeriod : T_new > kCombMaxPeriod ? kCombMaxPeriod : T_new;
+                    pipe_comb_call<true>(cur, mir, lane, R0, kOverlap, T_old, T_cur, g_old, g_cur, ts_old, ts_cur, win2);
+                    pipe_comb_call<true>(cur, mir, lane, R0 + kOverlap, N - kOverlap, T_cur, T_nw, g_cur, g_new, ts_cur, ts_new, win2);
+                    T_old = T_cur = T_new; g_old = g_cur = g_new; ts_old = ts_cur = ts_new;   // :672-683 (LM != 0)
+                }
+                __syncthreads();
+            }
+            if (A.pf_state_out && wave == 0 && lane == 0) {
+                float *ps = A.pf_state_out + 6 * s;
+                ps[0] = (float)T_old; ps[1] = (float)T_cur; ps[2] = g_old; ps[3] = g_cur; ps[4] = (float)ts_old; ps[5] = (float)ts_cur;
+            }
+        }
+    } else if (wave == kPipeUnits) {
+        // ------------------------------- I/O wave -------------------------------
+        DeConst D;
+        float pwHalf;
+        deemph_init_lanes<2>(D, pwHalf, lane);
+        for (long s = blockIdx.x; s < A.nstreams; s += gridDim.x) {
+            const long u0 = 2 * s;
+            float memL = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, A.deemph ? A.deemph[u0] : 0.f)));
+            float memR = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, A.deemph ? A.deemph[u0 + 1] : 0.f)));
+            int pT = 0, pS = 0;
+            float pG = 0.f;
+            auto fetch_params = [&](long fidx) {
+                const long pi = s * pst + fidx;
+                pT = A.pf_pitch[pi];
+                pG = A.pf_gain[pi];
+                pS = A.pf_tapset[pi];
+            };
+            auto put_params = [&](long fidx) {
+                if (lane == 0) {
+                    PipeParams *ps = &pslot[fidx & 1];
+                    ps->T = pT;
+                    ps->g = pG;
+                    ps->ts = pS;
+                }
+            };
+            // prologue: buffer A's history = what precedes frame 0
+#pragma unroll
+            for (int k = 0; k < kPipeUnits; k++) {
+#pragma unroll 1
+                for (int j = lane; j < kPipeHist; j += kWave) bufs[k][0][j] = A.hist ? A.hist[(u0 + k) * kPostHist + OLD + j] : 0.f;
+            }
+            if (nfr > 0) {
+                fetch_params(0);
+                put_params(0);
+                if (nfr > 1) fetch_params(1);
+            }
+            __syncthreads();                                                   // P
+            for (long f = 0; f <= nfr; f++) {
+                const int cb = (int)(f & 1), nb = cb ^ 1;
+                if (f < nfr && KEEP > 0) {
+#pragma unroll
+                    for (int k = 0; k < kPipeUnits; k++) pipe_copy<true>(bufs[k][cb] + N, bufs[k][nb], lane, 0, KEEP);
+                }
+                if (f + 1 < nfr) {
+                    put_params(f + 1);
+                    if (f + 2 < nfr) fetch_params(f + 2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // frame f-1 is final in cur[R0 - N, R0)
+                if (f >= 1)
+                    deemph_store_pair<N>(bufs[0][cb] + R0 - N, bufs[1][cb] + R0 - N,
+                                         reinterpret_cast<vf4 *>(A.out + (s * pst * N + (f - 1) * N) * 2), memL, memR, opaque(lane), D, pwHalf);
+                if (f == nfr) {
+                    // state for the next call: the last 1088 outputs (1040 in cur's history region, the 48 before them in nxt's)
+#pragma unroll
+                    for (int k = 0; k < kPipeUnits; k++) {
+                        if (A.hist && nfr > 0)
+#pragma unroll 1
+                            for (int j = lane; j < kPostHist; j += kWave)
+                                A.hist[(u0 + k) * kPostHist + j] = j < OLD ? bufs[k][nb][N - OLD + j] : bufs[k][cb][j - OLD];
+                    }
+                    if (A.deemph && lane == 0) {
+                        A.deemph[u0] = memL;
+                        A.deemph[u0 + 1] = memR;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    } else {
+        // ------------------------------- transform wave -------------------------------
+        fx::XfConst K;
+        fx::xf_init(K, lane, trig, window);
+        for (long s = blockIdx.x; s < A.nstreams; s += gridDim.x) {
+            float *const regA[2] = {bufs[0][0] + R0, bufs[1][0] + R0};
+            float *const regB[2] = {bufs[0][1] + R0, bufs[1][1] + R0};
+            vf4 tail0 = {0, 0, 0, 0}, tail1 = {0, 0, 0, 0};
+            if (A.ov_state && fx::tail_lane(lane)) {
+                tail0 = *reinterpret_cast<const vf4 *>(A.ov_state + 2 * s * kHalfOv + fx::tail_offset(lane, 0));
+                tail1 = *reinterpret_cast<const vf4 *>(A.ov_state + 2 * s * kHalfOv + fx::tail_offset(lane, 1));
+            }
+            const float *fbase = A.freq + s * fst * 2 * (long)N;
+            const unsigned char *tbase = A.transient ? A.transient + s * fst : nullptr;
+            // transient flags of 64 frames at a time: one byte per lane + a ballot
+            unsigned long long tmask = 0;
+            auto flags = [&](long f0) {
+                bool t = false;
+                if (tbase && f0 + lane < nfr) t = tbase[f0 + lane] != 0;
+                return __ballot(t);
+            };
+            fx::XfRegs R;
+            if (nfr > 0) fx::xf_load<NYQ_PIPE_NT & 1>(R, lane, fbase);
+            // iteration g transforms frame g in front of barrier g: frame 0 in front of P, frame f + 1 beside the filtering of
+            // frame f; the last two barriers have no transform beside them (one call site for each of the two programs)
+            for (long g = 0; g < nfr + 2; g++) {
+                if (g < nfr) {
+                    if ((g & 63) == 0) tmask = flags(g);
+                    float *const reg[2] = {bufs[0][g & 1] + R0, bufs[1][g & 1] + R0};
+                    if ((tmask >> (g & 63)) & 1ull) xf_short_frame(R, K, lane, reg, tail0, tail1, trig);
+                    else xf_long_frame(R, K, lane, reg, tail0, tail1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g + 1 < nfr) fx::xf_load<NYQ_PIPE_NT & 1>(R, opaque(lane), fbase + (g + 1) * 2 * (long)N);
+                }
+                __syncthreads();
+            }
+            if (A.ov_state && fx::tail_lane(lane)) {
+                *reinterpret_cast<vf4 *>(A.ov_state + 2 * s * kHalfOv + fx::tail_offset(lane, 0)) = tail0;
+                *reinterpret_cast<vf4 *>(A.ov_state + 2 * s * kHalfOv + fx::tail_offset(lane, 1)) = tail1;
+            }
+        }
+    }
+}
+
+}  // namespace nyq

@@ -18,12 +18,13 @@
 #include "../../include/nyq_imdct.h"
 
 #include "nyq_kernels.hpp"
-#include "nyq_post_pipe.hpp"       // (includes nyq_post_kernels.hpp for the pieces both forms share)
-// The round-1 post-filter kernels (one wave per channel / per stereo pair) and the fused one-launch chain are measured-and-
-// rejected designs kept for A/B runs: they are compiled only into the tools' build of this library (-DNYQ_AB_FORMS,
-// tools/libnyq_imdct_ab.so) and selected through nyq_ctx_set_option; the product launches neither.
+#include "nyq_post_pipe.hpp"
+#include "nyq_chain_kernel.hpp"    // the one-launch frames -> PCM kernel (round 4)
+// The round-1 post-filter kernels (one wave per channel / per stereo pair) and round 2's fused chain are measured-and-
+// rejected designs kept for A/B runs: their sources live under tools/ab/ and are compiled only into the tools' build of this
+// library (-DNYQ_AB_FORMS -Itools/ab, tools/libnyq_imdct_ab.so), selected through nyq_ctx_set_option; the product has neither.
 #ifdef NYQ_AB_FORMS
-#include "nyq_chain_fused.hpp"
+#include "nyq_chain_fused_r2.hpp"
 #endif
 
 using namespace nyq;
@@ -55,12 +56,13 @@ struct nyq_ctx {
     int res_synth_long[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};   // [frame size][with the transient-frame role]
     int res_post[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
     int res_post_pipe[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};   // [LM][stereo instance]
-    int res_chain_fused = 0;
+    int res_chain_fused = 0;             // (A/B build: round 2's fused kernel)
+    int res_chain = 0;                   // celt_chain_kernel
     int res_vorbis[12] = {0};
     // options (nyq_ctx_set_option): nothing on a launch path reads the process environment
     int opt_blocks_per_cu = 0;           // 0 = built-in choice
     int opt_post_form = NYQ_POST_FORM_PIPELINE;
-    int opt_chain_fused = 0;
+    int opt_chain_fused = NYQ_CHAIN_ONE_LAUNCH;
     long opt_chain_window = 0;           // frames per window of the two-kernel chain; 0 = built-in choice
     int opt_chain_overlap = 0;           // windows: post-filter of window k on a second stream beside the synthesis of window k + 1
     hipStream_t s_post = nullptr;        // (created on first use)
@@ -160,9 +162,10 @@ extern "C" int nyq_ctx_set_option(nyq_ctx *ctx, int option, long value) {
         ctx->opt_post_form = (int)value;
         return NYQ_OK;
     case NYQ_OPT_CHAIN_FUSED:
-        if (value != 0 && value != 1) return fail(ctx, NYQ_ERR_INVALID, "nyq_ctx_set_option: NYQ_OPT_CHAIN_FUSED must be 0 or 1");
-        if (value == 1 && !nyq_ab_forms_built())
-            return fail(ctx, NYQ_ERR_INVALID, "nyq_ctx_set_option: this build has no fused chain kernel (tools/libnyq_imdct_ab.so has)");
+        if (value != NYQ_CHAIN_TWO_KERNELS && value != NYQ_CHAIN_ONE_LAUNCH && value != NYQ_CHAIN_FUSED_R2)
+            return fail(ctx, NYQ_ERR_INVALID, "nyq_ctx_set_option: unknown NYQ_OPT_CHAIN_FUSED value");
+        if (value == NYQ_CHAIN_FUSED_R2 && !nyq_ab_forms_built())
+            return fail(ctx, NYQ_ERR_INVALID, "nyq_ctx_set_option: round 2's fused chain kernel is an A/B form (tools/libnyq_imdct_ab.so): measured, 3x slower");
         ctx->opt_chain_fused = (int)value;
         return NYQ_OK;
     case NYQ_OPT_CHAIN_OVERLAP:
@@ -619,11 +622,12 @@ static size_t default_chain_window(size_t nstreams, size_t nframes, int channels
     return nframes;                                 // one window: see DESIGN.md 4.8 for the measurements behind it
 }
 
-extern "C" int nyq_celt_chain_dev(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned char *d_transient,
-                                  const int *d_pf_pitch, const float *d_pf_gain, const int *d_pf_tapset,
-                                  const float *d_pf_state_in, float *d_pf_state_out, float *d_overlap, float *d_hist,
-                                  float *d_deemph, float *d_out, float *d_pcm, float *d_work, size_t nstreams,
-                                  size_t nframes, int channels) {
+// fstride: 0 = dense; otherwise freq / transient / pf_* / out are windows of per-stream arrays `fstride` frames long
+static int chain_core(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned char *d_transient,
+                      const int *d_pf_pitch, const float *d_pf_gain, const int *d_pf_tapset,
+                      const float *d_pf_state_in, float *d_pf_state_out, float *d_overlap, float *d_hist,
+                      float *d_deemph, float *d_out, float *d_pcm, float *d_work, size_t nstreams,
+                      size_t nframes, int channels, size_t fstride) {
     if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_celt_chain_dev: ctx is NULL");
     if (LM < 0 || LM > 3) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_chain_dev: LM must be 0..3");
     if (channels < 1 || channels > 255) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_chain_dev: channels must be 1..255");
@@ -634,12 +638,43 @@ extern "C" int nyq_celt_chain_dev(nyq_ctx *ctx, int LM, const float *d_freq, con
         return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_chain_dev: pf_state_in and pf_state_out must not alias");
     if (!aligned16(d_freq) || !aligned16(d_out) || !aligned16(d_overlap) || !aligned16(d_hist))
         return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_chain_dev: device pointers must be 16-byte aligned");
+    // The one-launch kernel (nyq_chain_kernel.hpp): the post-filter's workgroup plus a transform wave that works in place in
+    // the frame regions -- the time-domain frame never leaves the CU.
+    if (ctx->opt_chain_fused == NYQ_CHAIN_ONE_LAUNCH && nyq_celt_chain_fused_supported(LM, channels)) {
+        ChainArgs A;
+        A.freq = d_freq;
+        A.transient = d_transient;
+        A.ov_state = d_overlap;
+        A.pf_pitch = d_pf_pitch;
+        A.pf_gain = d_pf_gain;
+        A.pf_tapset = d_pf_tapset;
+        A.pf_state = d_pf_state_in;
+        A.pf_state_out = d_pf_state_out;
+        A.hist = d_hist;
+        A.deemph = d_deemph;
+        A.out = d_out;
+        A.nstreams = (long)nstreams;
+        A.nframes = (long)nframes;
+        A.fstride = (long)fstride;
+        A.pstride = (long)fstride;
+        if (ctx->res_chain == 0) {
+            int per_cu = 0;
+            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, celt_chain_kernel, kWave * kChainWaves, 0);
+            if (e != hipSuccess || per_cu < 1) per_cu = 1;
+            // four workgroups = 8 chains per CU, as the post-filter pipeline (nyq_celt_post_round_chains)
+            ctx->res_chain = (per_cu > kPipeGroupsPerCU ? kPipeGroupsPerCU : per_cu) * ctx->cus;
+        }
+        const unsigned grid = (unsigned)(nstreams < (size_t)ctx->res_chain ? nstreams : (size_t)ctx->res_chain);
+        hipLaunchKernelGGL(celt_chain_kernel, dim3(grid), dim3(kWave * kChainWaves), 0, ctx->stream, A, ctx->d_trig, ctx->d_window);
+        NYQ_HIP(ctx, hipGetLastError());
+        return NYQ_OK;
+    }
 #ifdef NYQ_AB_FORMS
-    // The fused kernel (A/B build only) is correct (tests/test_gpu_chain.py) but measured 3x SLOWER than the two launches
+    // Round 2's fused kernel (A/B build only) is correct (tests/test_gpu_chain.py) and measured 3x SLOWER than the two launches
     // (6.1 ms vs 1.9 ms for 1024 x 256 stereo frames, profiles/r02_*): one IMDCT wave per four chains cannot keep up with
     // the comb waves, and the LDS that would hold more IMDCT slices is what keeps every chain resident.
-    if (ctx->opt_chain_fused && nyq_celt_chain_fused_supported(LM, channels)) {
-        ChainArgs A;
+    if (ctx->opt_chain_fused == NYQ_CHAIN_FUSED_R2 && nyq_celt_chain_fused_supported(LM, channels) && fstride == 0) {
+        FusedR2Args A;
         A.freq = d_freq;
         A.transient = d_transient;
         A.ov_state = d_overlap;
@@ -681,11 +716,11 @@ extern "C" int nyq_celt_chain_dev(nyq_ctx *ctx, int LM, const float *d_freq, con
     size_t W = ctx->opt_chain_window > 0 ? (size_t)ctx->opt_chain_window : default_chain_window(nstreams, nframes, channels, LM);
     const size_t chainlen = LM == 3 ? Geo<32>::CHAIN_FRAMES : LM == 2 ? Geo<16>::CHAIN_FRAMES : LM == 1 ? Geo<8>::CHAIN_FRAMES : Geo<4>::CHAIN_FRAMES;
     W = (W + chainlen - 1) / chainlen * chainlen;   // windows start where the in-wave carry chains start: bit-identical to one window
-    if (W >= nframes || nframes - W < 20) {         // (the temporaries below need 20 frames' worth of d_work beyond a window's own)
-        int rc = synth_core(ctx, LM, d_freq, d_transient, d_pcm, d_overlap, d_overlap, d_work, nstreams, nframes, channels);
+    if (W >= nframes || nframes - W < 20 || fstride != 0) {   // (the temporaries below need 20 frames' worth of d_work beyond a window's own)
+        int rc = synth_core(ctx, LM, d_freq, d_transient, d_pcm, d_overlap, d_overlap, d_work, nstreams, nframes, channels, fstride);
         if (rc != NYQ_OK) return rc;
         return post_core(ctx, LM, d_pcm, d_pf_pitch, d_pf_gain, d_pf_tapset, d_pf_state_in, d_pf_state_out, d_hist, d_deemph,
-                         d_out, nstreams, nframes, channels, 0);
+                         d_out, nstreams, nframes, channels, fstride);
     }
     // temporaries behind the window's own share of d_work (nsc * (W + 1) * 60 floats of nsc * (nframes + 1) * 60):
     // overlap [nsc][60], hist [nsc][1088], deemph [nsc], post-filter state ping / pong [nstreams][6] -- 1150 floats per
@@ -743,6 +778,15 @@ extern "C" int nyq_celt_chain_dev(nyq_ctx *ctx, int LM, const float *d_freq, con
     }
     if (overlap) NYQ_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->ev_pool[2 * (k - 1) + 1], 0));
     return NYQ_OK;
+}
+
+extern "C" int nyq_celt_chain_dev(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned char *d_transient,
+                                  const int *d_pf_pitch, const float *d_pf_gain, const int *d_pf_tapset,
+                                  const float *d_pf_state_in, float *d_pf_state_out, float *d_overlap, float *d_hist,
+                                  float *d_deemph, float *d_out, float *d_pcm, float *d_work, size_t nstreams,
+                                  size_t nframes, int channels) {
+    return chain_core(ctx, LM, d_freq, d_transient, d_pf_pitch, d_pf_gain, d_pf_tapset, d_pf_state_in, d_pf_state_out, d_overlap,
+                      d_hist, d_deemph, d_out, d_pcm, d_work, nstreams, nframes, channels, 0);
 }
 
 // ---- Vorbis inverse MDCT ---------------------------------------------------------------------
@@ -1081,12 +1125,11 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
         }
         NYQ_HIP(ctx, hipEventRecord(up, hs));
         NYQ_HIP(ctx, hipStreamWaitEvent(ctx->stream, up, 0));
-        rc = nyq_celt_synth_dev(ctx, LM, d_x + xo, transient ? d_t + fo : nullptr, d_pcm + xo, state ? d_ov + co * NYQ_HALF_OV : nullptr,
-                                d_w + s0 * work_per_stream, cnt, nframes, channels);
-        if (rc == NYQ_OK)
-            rc = nyq_celt_post_dev(ctx, LM, d_pcm + xo, d_pp + fo, d_pg + fo, d_pt + fo, state ? d_pfi + s0 * 6 : nullptr,
-                                   state ? d_pfo + s0 * 6 : nullptr, state ? d_hi + co * kPostHist : nullptr,
-                                   state ? d_de + co : nullptr, d_out + xo, cnt, nframes, channels);
+        // (one launch for 20 ms stereo frames, synthesis + post-filter through d_pcm otherwise)
+        rc = nyq_celt_chain_dev(ctx, LM, d_x + xo, transient ? d_t + fo : nullptr, d_pp + fo, d_pg + fo, d_pt + fo,
+                                state ? d_pfi + s0 * 6 : nullptr, state ? d_pfo + s0 * 6 : nullptr,
+                                state ? d_ov + co * NYQ_HALF_OV : nullptr, state ? d_hi + co * kPostHist : nullptr,
+                                state ? d_de + co : nullptr, d_out + xo, d_pcm + xo, d_w + s0 * work_per_stream, cnt, nframes, channels);
         if (rc != NYQ_OK) {
             (void)hipStreamSynchronize(hs);
             (void)hipStreamSynchronize(ctx->stream);

@@ -246,3 +246,80 @@ extern "C" int emu_dft(int r, float *io) {
     }
     return -1;
 }
+
+// ---- the transform wave of the one-launch frames -> PCM kernel (nyq_fuse_lanes.hpp, celt_chain_kernel's XF role) ----
+#include "nyq_fuse_lanes.hpp"
+
+// One stereo stream: freq [nframes][2][960], transient [nframes] or null, state [2][60] in/out or null,
+// pcm [2][nframes * 960].  Phase order as in nyq_chain_kernel.hpp.
+extern "C" int emu_fuse_synth(const float *freq, const unsigned char *transient, float *pcm, float *state, long nframes,
+                              const float *trig, const float *window) {
+    using namespace nyq::fx;
+    std::vector<float> r0(kN, 0.f), r1(kN, 0.f);
+    float *const reg[2] = {r0.data(), r1.data()};
+    std::vector<XfConst> K(kWave);
+    std::vector<XfShortConst> S(kWave);
+    std::vector<f4> tail[2] = {std::vector<f4>(kWave, f4{0, 0, 0, 0}), std::vector<f4>(kWave, f4{0, 0, 0, 0})};
+    for (int l = 0; l < kWave; l++) {
+        xf_init(K[l], l, trig, window);
+        xf_short_init(S[l], l, trig);
+        for (int c = 0; c < 2; c++)
+            if (state && tail_lane(l)) tail[c][l] = *reinterpret_cast<const f4 *>(state + tail_offset(l, c));
+    }
+    std::vector<XfRegs> R(kWave);
+    for (long f = 0; f < nframes; f++) {
+        const float *frame = freq + f * 2 * kN;
+        for (int l = 0; l < kWave; l++) xf_load<0>(R[l], l, frame);
+        if (!(transient && transient[f])) {
+            for (int r = 0; r < 2; r++)
+                for (int l = 0; l < kWave; l++) xf_long_s0(R[l], K[l], l, r, reg[r]);
+            {
+                cpx u[kWave][16];
+                for (int l = 0; l < kWave; l++) xf_long_s2_load(l, reg, u[l]);
+                for (int l = 0; l < kWave; l++) xf_long_s2_store(l, reg, u[l]);
+            }
+            {
+                cpx v[kWave][15];
+                for (int l = 0; l < kWave; l++) xf_long_s3_load(l, reg, v[l]);
+                for (int l = 0; l < kWave; l++) xf_long_s3_store(l, reg, v[l]);
+            }
+            for (int r = 0; r < 2; r++) {
+                std::vector<XfOut> O(kWave);
+                for (int l = 0; l < kWave; l++) xf_long_s4_load(K[l], l, reg[r], O[l]);
+                for (int l = 0; l < kWave; l++) xf_long_s4_store(K[l], l, reg[r], O[l], tail[r][l]);
+            }
+        } else {
+            for (int l = 0; l < kWave; l++) xf_short_t0(R[l], l, reg);
+            for (int s = 0; s < 4; s++) {
+                std::vector<XfShortIn> I(kWave);
+                for (int l = 0; l < kWave; l++) xf_short_t1_load(l, s, reg, I[l]);
+                for (int l = 0; l < kWave; l++) xf_short_t1_store(S[l], l, s, reg, I[l]);
+            }
+            for (int it = 0; it < 4; it++)
+                for (int l = 0; l < kWave; l++) xf_short_t2(l, it, reg);
+            {
+                cpx v[kWave][15];
+                for (int l = 0; l < kWave; l++) xf_short_t3_load(l, reg, v[l]);
+                for (int l = 0; l < kWave; l++) xf_short_t3_store(l, reg, v[l]);
+            }
+            std::vector<f4> bk(4 * kWave);
+            for (int s = 0; s < 4; s++)
+                for (int l = 0; l < kWave; l++) bk[s * kWave + l] = xf_short_t4(S[l], l, s, reg);
+            for (int c = 0; c < 2; c++)
+                for (int h = 1; h >= 0; h--) {
+                    std::vector<XfMirror> M(kWave);
+                    for (int l = 0; l < kWave; l++) xf_short_t5_load(l, c, h, reg, tail[c][l], M[l]);
+                    for (int l = 0; l < kWave; l++) xf_short_t5_store(K[l], l, c, h, reg, M[l]);
+                }
+            for (int c = 0; c < 2; c++)
+                for (int l = 0; l < kWave; l++)
+                    if (tail_lane(l)) tail[c][l] = bk[(2 * c + 1) * kWave + short_tail_src(l)];
+        }
+        for (int c = 0; c < 2; c++) std::memcpy(pcm + (c * nframes + f) * kN, reg[c], kN * sizeof(float));
+    }
+    if (state)
+        for (int c = 0; c < 2; c++)
+            for (int l = 0; l < kWave; l++)
+                if (tail_lane(l)) *reinterpret_cast<f4 *>(state + tail_offset(l, c)) = tail[c][l];
+    return 0;
+}

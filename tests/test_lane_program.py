@@ -127,3 +127,40 @@ def test_frame_synth_lane_program_on_real_decoder_frames(emu, ref_tables):
                        st.ctypes.data_as(C.c_void_p), ns, nf, ch, ref_tables["trig"], ref_tables["window"])
     assert rel_rms(pcm, z["pcm"]) <= 1e-6
     assert rel_rms(st, z["state_out"]) <= 1e-6
+
+
+@pytest.mark.parametrize("nf,ptr", [(1, 0.0), (5, 0.0), (1, 1.0), (3, 1.0), (24, 0.3), (70, 0.1)])
+def test_fused_transform_wave_program_vs_oracle(emu, oracle, nf, ptr):
+    """The transform wave of the one-launch frames -> PCM kernel (nyq_fuse_lanes.hpp: one wave, both channels of a 20 ms
+    frame, in place in two 3840-byte regions; 480 = 2 x 16 x 15 long program, 16 x nfft-60 transient program, tails in
+    registers) replayed on the CPU: long / transient / mixed sequences, state in and out."""
+    emu.emu_fuse_synth.argtypes = [_f32p, C.c_void_p, _f32p, C.c_void_p, C.c_long, _f32p, _f32p]
+    trig, win, _ = oracle.tables()
+    rng = np.random.default_rng(nf)
+    freq = (rng.standard_normal((1, nf, 2, 960)) * 30).astype(np.float32)
+    tr = (rng.uniform(size=(1, nf)) < ptr).astype(np.uint8)
+    st = (rng.standard_normal((2, 60)) * 30).astype(np.float32)
+    for use_state in (True, False):
+        pcm = np.zeros((1, 2, nf * 960), np.float32)
+        st2 = st.copy()
+        assert emu.emu_fuse_synth(freq.reshape(-1), tr.ctypes.data_as(C.c_void_p), pcm.reshape(-1),
+                                  st2.ctypes.data_as(C.c_void_p) if use_state else None, nf, trig, win) == 0
+        wp, ws = oracle.celt_synth(3, freq, tr, st if use_state else None)
+        assert rel_rms(pcm, wp) <= 1e-6
+        if use_state:
+            assert rel_rms(st2, ws) <= 1e-6
+
+
+def test_fused_transform_wave_program_on_real_decoder_frames(emu, ref_tables):
+    emu.emu_fuse_synth.argtypes = [_f32p, C.c_void_p, _f32p, C.c_void_p, C.c_long, _f32p, _f32p]
+    z = np.load(os.path.join(GOLDEN, "real_opus_frames.npz"))
+    freq, tr = np.ascontiguousarray(z["freq"]), np.ascontiguousarray(z["transient"])
+    ns, nf, ch, n = freq.shape
+    assert ch == 2 and n == 960
+    for s in range(ns):
+        pcm = np.zeros((ch, nf * n), np.float32)
+        st = np.ascontiguousarray(z["state_in"][2 * s:2 * s + 2])
+        emu.emu_fuse_synth(np.ascontiguousarray(freq[s]).reshape(-1), np.ascontiguousarray(tr[s]).ctypes.data_as(C.c_void_p),
+                           pcm.reshape(-1), st.ctypes.data_as(C.c_void_p), nf, ref_tables["trig"], ref_tables["window"])
+        assert rel_rms(pcm, z["pcm"][s]) <= 1e-6
+        assert rel_rms(st, z["state_out"][2 * s:2 * s + 2]) <= 1e-6

@@ -1,4 +1,4 @@
-// nyq_chain_fused.hpp -- freq[] -> interleaved PCM in ONE kernel (round 2): everything celt_decode_with_ec does after
+// nyq_chain_fused_r2.hpp -- freq[] -> interleaved PCM in ONE kernel (round 2): everything celt_decode_with_ec does after
 // denormalise_bands (celt_decoder_clean.c:620-723) for many stereo streams at once:
 //   compute_inv_mdcts (:264-312, clt_mdct_backward mdct.c:267-379)  ->  comb_filter (celt.c:114-172, as applied
 //   :658-683)  ->  deemphasis (:192-256) with scaling and channel interleave.
@@ -36,7 +36,7 @@ constexpr int kFuseChains = 4;                      // chains (stream, channel) 
 constexpr int kFuseWaves = kFuseChains + 2;         // + I/O wave + IMDCT wave
 constexpr int kFuseN = 960;                         // LM 3 only: 20 ms frames
 
-struct ChainArgs {
+struct FusedR2Args {
     const float *freq;               // [nstreams][nframes][2][960]   as the decoder leaves freq[]
     const unsigned char *transient;  // [nstreams][nframes] or null
     float *ov_state;                 // [nstreams*2][60] overlap carry in/out, or null (zeros, discarded)
@@ -92,7 +92,7 @@ struct FusedShortRows {
     __device__ float *tail(int g) const { return (g & 7) == 7 ? tails + (g >> 3) * kHalfOv : nullptr; }
 };
 
-__global__ __launch_bounds__(kWave *kFuseWaves, NYQ_FUSE_MINWAVES) void celt_chain_fused_kernel(ChainArgs A, const float *__restrict__ trig,
+__global__ __launch_bounds__(kWave *kFuseWaves, NYQ_FUSE_MINWAVES) void celt_chain_fused_kernel(FusedR2Args A, const float *__restrict__ trig,
                                                                                  const float *__restrict__ window) {
     constexpr int N = kFuseN, NV = N / 4, NLD = 4;
     constexpr int R0 = kPostHist;

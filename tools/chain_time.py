@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time the frames -> PCM chain (nyq_celt_chain_dev) fused vs as two kernels, same process, interleaved; HIP events on
+"""Time the frames -> PCM chain (nyq_celt_chain_dev) as ONE launch (nyq_chain_kernel.hpp) vs as two kernels, same process, interleaved; HIP events on
 the operator's stream.  usage: chain_time.py [nstreams] [nframes] [mix|short|long|off|real]
 CHAIN_SPLIT=1: the two stages alone next to the chain; CHAIN_WINDOWS="0,64,128": the two-kernel chain of the PRODUCT library
 over time windows of that many frames (NYQ_OPT_CHAIN_WINDOW; 0 = one window), interleaved, medians.
@@ -134,7 +134,7 @@ if os.environ.get("CHAIN_WINDOWS") is not None:
 res = {}
 outs = {}
 times = {"0": [], "1": []}
-for rnd in range(8):
+for rnd in range(int(os.environ.get("CHAIN_ROUNDS", "12"))):
     for mode in ("0", "1"):
         ctx.set_option(B.OPT_CHAIN_FUSED, int(mode))
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -146,9 +146,9 @@ for rnd in range(8):
             times[mode].append(a.elapsed_time(b))
         if rnd == 0:
             outs[mode] = out.clone()
-for mode, name in (("0", "two kernels"), ("1", "fused")):
+for mode, name in (("0", "two kernels"), ("1", "one launch")):
     ms = sorted(times[mode])[len(times[mode]) // 2]
     res[name] = {"ms": ms, "stereo_frames_per_sec": ns * nf / ms * 1e3, "GBps_in_plus_out": ns * nf * ch * 7680 / ms / 1e6}
-res["max_abs_diff_fused_vs_two_kernels"] = float((outs["0"] - outs["1"]).abs().max())
+res["max_abs_diff_one_launch_vs_two_kernels"] = float((outs["0"] - outs["1"]).abs().max())
 res["case"] = f"{ns} streams x {nf} frames x 2 ch, LM 3, 2.8 % transient, post-filter case {case}"
 print(json.dumps(res))
