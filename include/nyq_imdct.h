@@ -194,6 +194,14 @@ int nyq_celt_chain_dev(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned
  * no window, no overlap-add (libvorbis does those in block.c). */
 int nyq_vorbis_imdct_batch_dev(nyq_ctx *ctx, int n, const float *d_in, float *d_out, size_t batch);
 
+/* A measurement utility, not a decoder operator: plain device copies of `bytes` (a multiple of 16) from d_src to d_dst in
+ * `form` 0 .. nyq_device_copy_forms() - 1 (grid-stride and chunk-per-wave float4 copies at several occupancies).  The row
+ * kernels read and write equal byte counts, so the best of these on the box at hand is their practical ceiling; bench.py
+ * reports it as roofline.measured_device_copy_GBps.  Asynchronous on the context stream. */
+int nyq_device_copy_forms(void);
+const char *nyq_device_copy_form_name(int form);
+int nyq_device_copy_dev(nyq_ctx *ctx, void *d_dst, const void *d_src, size_t bytes, int form);
+
 /* ---- host-buffer variants (synchronous: H2D, kernel, D2H through context scratch) ----
  * This is the shape of the reference's own FFI (host pointers in, host pointers out:
  * third_party/opus/celt/mdct.c:52-55).  nyq_imdct_batch / nyq_imdct_chain cut a large batch into pieces
@@ -241,12 +249,19 @@ void processMDCTCuda(const float *input, float *output, const float *trig, int N
 /* cuda/mdct_cuda.hpp:92-94 (impl mdct_cuda.cu:562-584): two channels per call. */
 void processMDCTCudaB1C2(const float *input[2], float *output[2], const float *trig, int N,
                          int shift, int stride, float sine, int overlap, const float *window);
+/* cuda/mdct_cuda.hpp:96-98: declared, never called, and defined with another signature in the reference
+ * (mdct_cuda_b8.cu:482-501).  Exported so that the header's whole symbol set links; it does what the DECLARATION says:
+ * eight rows of one size per call (= four B1C2 calls), one launch. */
+void processMDCTCudaB8C2(const float *input[8], float *output[8], const float *trig, int N,
+                         int shift, int stride, float sine, int overlap, const float *window);
 /* cuda/mdct_cuda.hpp:100, called from examples/src/Main.cpp:127-129 */
 void cleanupCudaBuffers(void);
-/* Not in the reference.  The two void operators above cannot return a status: by default a failure (no device, a HIP error,
+/* Not in the reference.  The void operators above cannot return a status: by default a failure (no device, a HIP error,
  * a call outside the static 48 kHz mode) prints and ends the process, as the reference's offload does (mdct_cuda.cu:11-19).
  * With a handler installed the handler is called instead (entry point, reason) and, when it returns, the call returns with
- * `output` untouched -- the integrator decides what to do with the stream.  NULL restores the default.  No CPU fallback. */
+ * `output` untouched -- the integrator decides what to do with the stream.  The handler runs with no library lock held: it
+ * may call any entry point (the operators and cleanupCudaBuffers included).  After a HIP failure the operators' context is
+ * dropped and the next call creates a new one.  NULL restores the default.  No CPU fallback. */
 void nyq_shim_set_error_handler(void (*handler)(const char *who, const char *what));
 /* cuda/mdct_cuda.hpp:83, called from examples/src/Main.cpp:26-28 */
 void printCudaVersion(void);

@@ -27,10 +27,10 @@ EXPORTS = [
     "nyq_ctx_synchronize", "nyq_ctx_set_tables", "nyq_ctx_get_tables", "nyq_ctx_device_info",
     "nyq_ifft_batch_dev", "nyq_imdct_batch_dev", "nyq_imdct_chain_dev",
     "nyq_celt_synth_work_floats", "nyq_celt_synth_dev", "nyq_celt_synth", "nyq_celt_post_dev",
-    "nyq_celt_chain_fused_supported", "nyq_celt_chain_dev",
+    "nyq_celt_chain_fused_supported", "nyq_celt_chain_dev", "nyq_device_copy_forms", "nyq_device_copy_form_name", "nyq_device_copy_dev",
     "nyq_celt_frames_to_pcm", "nyq_celt_frames_to_pcm_window", "nyq_celt_state_floats", "nyq_vorbis_imdct_batch_dev", "nyq_vorbis_imdct_batch",
     "nyq_ifft_batch", "nyq_imdct_batch", "nyq_imdct_chain", "nyq_host_alloc", "nyq_host_free",
-    "processMDCTCuda", "processMDCTCudaB1C2", "cleanupCudaBuffers", "printCudaVersion", "nyq_shim_set_error_handler",
+    "processMDCTCuda", "processMDCTCudaB1C2", "processMDCTCudaB8C2", "cleanupCudaBuffers", "printCudaVersion", "nyq_shim_set_error_handler",
 ]
 
 
@@ -75,11 +75,13 @@ def load_ab():
     global _lib_ab
     if _lib_ab is None:
         try:
-            path = _build.build_ab()
-        except Exception:                        # no hipcc here: use the library that travelled with the tree, if any
+            _build.hipcc()
+        except RuntimeError:                     # no hipcc here: use the library that travelled with the tree, if any
             path = _build.LIB_AB
             if not os.path.exists(path):
                 raise
+        else:
+            path = _build.build_ab()             # (a compile error of the A/B sources propagates: no stale binary is loaded)
         _lib_ab = load(path)
     return _lib_ab
 
@@ -134,6 +136,10 @@ def load(path=None):
     L.nyq_celt_post_round_chains.argtypes = [vp]
     L.nyq_celt_post_round_chains.restype = sz
     L.nyq_celt_chain_fused_supported.argtypes = [i, i]
+    L.nyq_device_copy_forms.restype = i
+    L.nyq_device_copy_form_name.argtypes = [i]
+    L.nyq_device_copy_form_name.restype = C.c_char_p
+    L.nyq_device_copy_dev.argtypes = [vp, vp, vp, sz, i]
     L.nyq_celt_chain_dev.argtypes = [vp, i] + [fp] * 13 + [sz, sz, i]
     L.nyq_celt_frames_to_pcm.argtypes = [vp, i, fp, fp, fp, fp, fp, fp, fp, sz, sz, i]
     L.nyq_celt_frames_to_pcm_window.argtypes = [vp, i, fp, fp, fp, fp, fp, fp, fp, sz, sz, i, sz]
@@ -152,6 +158,8 @@ def load(path=None):
     L.processMDCTCuda.restype = None
     L.processMDCTCudaB1C2.argtypes = [C.POINTER(fp), C.POINTER(fp), fp, i, i, i, C.c_float, i, fp]
     L.processMDCTCudaB1C2.restype = None
+    L.processMDCTCudaB8C2.argtypes = [C.POINTER(fp), C.POINTER(fp), fp, i, i, i, C.c_float, i, fp]
+    L.processMDCTCudaB8C2.restype = None
     L.cleanupCudaBuffers.restype = None
     L.printCudaVersion.restype = None
     if path is None:

@@ -7,12 +7,13 @@
 // channel-frame.  Here it never leaves the CU: 3840 B in, 3840 B out.
 //
 // Workgroup = the post-filter pipeline of nyq_post_pipe.hpp (one stereo stream = 2 chains) plus ONE transform wave:
-//     wave 0, 1   comb wave of chain 0 / 1: the recursion of frame f, nothing else (unchanged)
+//     wave 0, 1   comb wave of chain 0 / 1: post-rotation + TDAC mirror of ITS frame f (the transform's last phase, in place,
+//                 the carry in four of its registers), then the recursion of frame f
 //     wave 2      I/O wave: de-emphasis + interleave + 16-byte global stores of frame f-1 STRAIGHT out of the filtered
 //                 history (two adjacent samples of both channels per lane: the output's own order, so there is no staging
 //                 pass and the frame region of `nxt` is free), history carry-over, post-filter parameters of frame f+1
-//     wave 3      transform wave: the inverse MDCT of frame f+1 of both channels IN PLACE in the frame regions of `nxt`
-//                 (nyq_fuse_lanes.hpp: no LDS of its own), the coefficients of frame f+2 prefetched into registers
+//     wave 3      transform wave: pre-rotation and the inverse FFT of frame f+1 of both channels IN PLACE in the frame regions
+//                 of `nxt` (nyq_fuse_lanes.hpp: no LDS of its own), the coefficients of frame f+2 prefetched into registers
 //   one s_barrier per frame, 32 544 B of LDS as before: four workgroups (8 chains, 16 waves) per CU, 128 VGPRs.
 // What made the earlier fusions lose was the transform's 16 KB LDS slice per wave against the 8
 // resident chains x 16 KB the recursion needs; this transform needs none.
@@ -24,6 +25,32 @@
 namespace nyq {
 
 constexpr int kChainWaves = 4;     // 2 comb + I/O + transform
+
+// Diagnostic build only (-DNYQ_PIPE_STAMPS, tools/chain_stamps.py): s_memtime accounting per role and phase, summed over
+// the workgroups into a buffer nothing else reads.  The product build compiles none of it.
+#ifdef NYQ_PIPE_STAMPS
+__device__ unsigned long long g_chain_stamps[32];
+#define NYQ_CSTAMP_DECL() unsigned long long cs_t = __builtin_amdgcn_s_memtime(), cs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define NYQ_CSTAMP(slot)                                               \
+    do {                                                               \
+        const unsigned long long cs_n = __builtin_amdgcn_s_memtime();  \
+        cs_acc[slot] += cs_n - cs_t;                                   \
+        cs_t = cs_n;                                                   \
+    } while (0)
+#define NYQ_CSTAMP_FLUSH(base)                                                                                      \
+    do {                                                                                                            \
+        if (lane == 0)                                                                                              \
+            for (int cs_i = 0; cs_i < 8; cs_i++) atomicAdd(&g_chain_stamps[(base) + cs_i], cs_acc[cs_i]);           \
+    } while (0)
+#define NYQ_CSTAMP_ARGS , unsigned long long &cs_t, unsigned long long (&cs_acc)[8]
+#define NYQ_CSTAMP_PASS , cs_t, cs_acc
+#else
+#define NYQ_CSTAMP_DECL() do { } while (0)
+#define NYQ_CSTAMP(slot) do { } while (0)
+#define NYQ_CSTAMP_FLUSH(base) do { } while (0)
+#define NYQ_CSTAMP_ARGS
+#define NYQ_CSTAMP_PASS
+#endif
 
 struct ChainArgs {
     const float *freq;               // [nstreams][nframes][2][960]   as the decoder leaves freq[]
@@ -82,45 +109,103 @@ __device__ __forceinline__ void deemph_init_lanes(DeConst &D, float &pwHalf, int
     pwHalf = st[5];       // q^32
 }
 
+// K weighted scans side by side: their dependent chains (a DPP move and a multiply-add per step, wait states between them)
+// interleave, which is what the I/O wave's time is made of
+template <int K>
+__device__ __forceinline__ void deemph_scan_n(float (&e)[K], const DeConst &D) {
+#pragma unroll
+    for (int k = 0; k < K; k++) e[k] += D.cstep[0] * dpp_zero<0x111, 0xf>(e[k]);      // row_shr:1
+#pragma unroll
+    for (int k = 0; k < K; k++) e[k] += D.cstep[1] * dpp_zero<0x112, 0xf>(e[k]);      // row_shr:2
+#pragma unroll
+    for (int k = 0; k < K; k++) e[k] += D.cstep[2] * dpp_zero<0x114, 0xf>(e[k]);      // row_shr:4
+#pragma unroll
+    for (int k = 0; k < K; k++) e[k] += D.cstep[3] * dpp_zero<0x118, 0xf>(e[k]);      // row_shr:8
+#pragma unroll
+    for (int k = 0; k < K; k++) e[k] += D.wA * dpp_zero<0x142, 0xa>(e[k]);            // row_bcast:15 into rows 1, 3
+#pragma unroll
+    for (int k = 0; k < K; k++) e[k] += D.wB * dpp_zero<0x143, 0xc>(e[k]);            // row_bcast:31 into rows 2, 3
+}
+__device__ __forceinline__ float lane_value(float v, int l) {   // v of lane l (a compile-time lane), through an SGPR
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
 // deemphasis() (celt_decoder_clean.c:243-248) + 1/32768 + stereo interleave of ONE frame, from the filtered samples in
 // LDS straight to global memory: lane l of block b owns samples 2 (l + 64 b), + 1 of both channels = float4 l + 64 b of
 // the interleaved frame.  Per block: two-sample recurrence, one weighted scan over the lanes, carry from the block before.
+// Blocks go two at a time (four scans side by side); only the carry (one multiply-add per block and channel) is serial.
 template <int N>
 __device__ __forceinline__ void deemph_store_pair(const float *sL, const float *sR, vf4 *d4, float &memL, float &memR,
                                                   int lane, const DeConst &D, float pwHalf) {
     constexpr int NV2 = N / 2;                       // float4 of the interleaved frame
     constexpr int NB = (NV2 + kWave - 1) / kWave;    // blocks of 64
     static_assert(NV2 % kWave == 0 || NV2 % kWave == 32, "the last block is whole or half");
+    static_assert(NB % 2 == 0, "blocks go in pairs");
 #pragma unroll
-    for (int b = 0; b < NB; b++) {
-        const int v = lane + b * kWave;
-        const bool on = v < NV2;
-        const int vv = on ? v : 0;
-        const float2 l = *reinterpret_cast<const float2 *>(sL + 2 * vv);
-        const float2 r = *reinterpret_cast<const float2 *>(sR + 2 * vv);
-        const float l0 = l.x + 1e-30f, r0 = r.x + 1e-30f;                    // + VERY_SMALL
-        const float l1 = (l.y + 1e-30f) + kPreemph * l0, r1 = (r.y + 1e-30f) + kPreemph * r0;
-        const float eL = deemph_scan(on ? l1 : 0.f, D), eR = deemph_scan(on ? r1 : 0.f, D);
-        // value entering the lane's pair: c t[2l-1] = c e[l-1] + q^l mem, with mem = c t[-1]
-        const float cL = kPreemph * dpp_shr1(0.f, eL) + D.pw * memL, cR = kPreemph * dpp_shr1(0.f, eR) + D.pw * memR;
-        const vf4 o = {(l0 + cL) * (1.f / 32768.f), (r0 + cR) * (1.f / 32768.f), (l1 + kPreemph * cL) * (1.f / 32768.f),
-                       (r1 + kPreemph * cR) * (1.f / 32768.f)};
-        if (on) pipe_st(d4 + v, o);
-        const bool half = (b + 1) * kWave > NV2;     // the last block ends at lane 31
-        const int last = half ? 31 : 63;
-        const float pe = half ? pwHalf : D.pwEnd;
-        memL = kPreemph * __shfl(eL, last) + pe * memL;
-        memR = kPreemph * __shfl(eR, last) + pe * memR;
+    for (int b0 = 0; b0 < NB; b0 += 2) {
+        float x0[4], x1[4], e[4];                    // [2 * block + channel]
+        bool on[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int v = lane + (b0 + k) * kWave;
+            on[k] = v < NV2;
+            const int vv = on[k] ? v : 0;
+            const float2 l = *reinterpret_cast<const float2 *>(sL + 2 * vv);
+            const float2 r = *reinterpret_cast<const float2 *>(sR + 2 * vv);
+            x0[2 * k] = l.x + 1e-30f;                // + VERY_SMALL
+            x0[2 * k + 1] = r.x + 1e-30f;
+            x1[2 * k] = (l.y + 1e-30f) + kPreemph * x0[2 * k];
+            x1[2 * k + 1] = (r.y + 1e-30f) + kPreemph * x0[2 * k + 1];
+            e[2 * k] = on[k] ? x1[2 * k] : 0.f;
+            e[2 * k + 1] = on[k] ? x1[2 * k + 1] : 0.f;
+        }
+        deemph_scan_n<4>(e, D);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int v = lane + (b0 + k) * kWave;
+            // value entering the lane's pair: c t[2l-1] = c e[l-1] + q^l mem, with mem = c t[-1]
+            const float cL = kPreemph * dpp_shr1(0.f, e[2 * k]) + D.pw * memL, cR = kPreemph * dpp_shr1(0.f, e[2 * k + 1]) + D.pw * memR;
+            const vf4 o = {(x0[2 * k] + cL) * (1.f / 32768.f), (x0[2 * k + 1] + cR) * (1.f / 32768.f),
+                           (x1[2 * k] + kPreemph * cL) * (1.f / 32768.f), (x1[2 * k + 1] + kPreemph * cR) * (1.f / 32768.f)};
+            if (on[k]) pipe_st(d4 + v, o);
+            const bool half = (b0 + k + 1) * kWave > NV2;     // the last block ends at lane 31
+            const float pe = half ? pwHalf : D.pwEnd;
+            memL = kPreemph * lane_value(e[2 * k], half ? 31 : 63) + pe * memL;
+            memR = kPreemph * lane_value(e[2 * k + 1], half ? 31 : 63) + pe * memR;
+        }
     }
 }
 
-// ---- the transform wave's frame: coefficients in R -> finished samples in reg[0], reg[1] ----
-// (the tails travel as native vectors: an array of 16-byte structs is copied with memcpy and stays in scratch memory)
-__device__ __forceinline__ void xf_long_frame(const fx::XfRegs &R, const fx::XfConst &K, int lane, float *const (&reg)[2], vf4 &tail0, vf4 &tail1) {
+// ---- the transform wave's frame: coefficients in R -> FFT output (natural order) in reg[0], reg[1] ----
+// `next`: the coefficients of the frame after this one, or null.  Their loads are issued at the END of the frame's transform
+// (NYQ_CHAIN_EARLY_LOAD = 0: they have the rest of the iteration and the barrier to arrive in -- the comb waves, not this wave,
+// are what a frame waits for).  Measured in one process (profiles/r04_*): issued behind S2 (= 2) 1-3 % SLOWER -- the eight
+// 1 KB loads take 2400 cycles to ISSUE in the middle of the iteration against 400-800 at its end --, behind S0 (= 1) 128
+// VGPRs and a spilled lane id inside the frame loop.
+#ifndef NYQ_CHAIN_EARLY_LOAD
+#define NYQ_CHAIN_EARLY_LOAD 0
+#endif
+// NYQ_CHAIN_TOUCH: right behind S0 / T0 every lane reads one dword of one of the next frame's 60 cache lines (default cache
+// policy), so that the 16-byte loads issued later find the lines in L2.  Measured: +-1 %, not used.
+#ifndef NYQ_CHAIN_TOUCH
+#define NYQ_CHAIN_TOUCH 0
+#endif
+__device__ __forceinline__ float xf_touch(const float *next, int lane) {
+    return (NYQ_CHAIN_TOUCH && next && lane < 60) ? next[32 * lane] : 0.f;
+}
+__device__ __forceinline__ void xf_long_front(fx::XfRegs &R, const fx::XfRot &K, const fx::XfTw &W, int lane, float *const (&reg)[2],
+                                              const float *next, float &touch NYQ_CSTAMP_ARGS) {
     using namespace fx;
+#ifdef NYQ_PIPE_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NYQ_CSTAMP(1);                                                 // slot 1: wait for the prefetched coefficients
+#endif
 #pragma unroll
-    for (int r = 0; r < 2; r++) xf_long_s0(R, K, opaque(lane), r, reg[r]);
+    for (int r = 0; r < 2; r++) xf_long_s0(R, K, W, opaque(lane), r, reg[r]);
     NYQ_WAVE_SYNC();
+    touch = xf_touch(next, opaque(lane));
+    if (NYQ_CHAIN_EARLY_LOAD == 1 && next) xf_load<NYQ_PIPE_NT & 1>(R, opaque(lane), next);
+    NYQ_CSTAMP(2);                                                 // slot 2: S0
     {
         cpx u[16];
         const int ln = opaque(lane);
@@ -128,6 +213,8 @@ __device__ __forceinline__ void xf_long_frame(const fx::XfRegs &R, const fx::XfC
         xf_long_s2_store(ln, reg, u);
     }
     NYQ_WAVE_SYNC();
+    NYQ_CSTAMP(3);                                                 // slot 3: S2
+    if (NYQ_CHAIN_EARLY_LOAD == 2 && next) xf_load<NYQ_PIPE_NT & 1>(R, opaque(lane), next);
     {
         cpx v[15];
         const int ln = opaque(lane);
@@ -136,28 +223,20 @@ __device__ __forceinline__ void xf_long_frame(const fx::XfRegs &R, const fx::XfC
         xf_long_s3_store(ln, reg, v);
     }
     NYQ_WAVE_SYNC();
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-        XfOut O;
-        const int ln = opaque(lane);
-        xf_long_s4_load(K, ln, reg[r], O);
-        NYQ_WAVE_SYNC();
-        vf4 &tv = r ? tail1 : tail0;
-        f4 t = {tv.x, tv.y, tv.z, tv.w};
-        xf_long_s4_store(K, ln, reg[r], O, t);
-        tv = vf4{t.x, t.y, t.z, t.w};
-    }
-    NYQ_WAVE_SYNC();
+    NYQ_CSTAMP(4);                                                 // slot 4: S3
 }
 
-__device__ __forceinline__ void xf_short_frame(const fx::XfRegs &R, const fx::XfConst &K, int lane, float *const (&reg)[2], vf4 &tail0, vf4 &tail1,
-                                               const float *__restrict__ trig) {
+// transient frame: de-interleave, pre-rotation, the two passes -> natural-order FFT output of the 16 rows
+__device__ __forceinline__ void xf_short_front(fx::XfRegs &R, int lane, float *const (&reg)[2], const float *__restrict__ trig,
+                                               const float *next, float &touch) {
     using namespace fx;
     // (the short program's six rotation values are fetched where a transient frame needs them: a few per cent of the frames)
     XfShortConst S;
     xf_short_init(S, opaque(lane), trig);
     xf_short_t0(R, opaque(lane), reg);
     NYQ_WAVE_SYNC();
+    touch = xf_touch(next, opaque(lane));
+    if (NYQ_CHAIN_EARLY_LOAD == 1 && next) xf_load<NYQ_PIPE_NT & 1>(R, opaque(lane), next);
 #pragma unroll 1
     for (int s = 0; s < 4; s++) {
         XfShortIn I;
@@ -178,30 +257,46 @@ __device__ __forceinline__ void xf_short_frame(const fx::XfRegs &R, const fx::Xf
         xf_short_t3_store(ln, reg, v);
     }
     NYQ_WAVE_SYNC();
-    vf4 bk7a = {0, 0, 0, 0}, bk7b = {0, 0, 0, 0};
+    if (NYQ_CHAIN_EARLY_LOAD >= 2 && next) xf_load<NYQ_PIPE_NT & 1>(R, opaque(lane), next);
+}
+
+// ---- the comb wave's share: FFT output of ITS chain's frame -> finished samples, in place, right before it filters them ----
+// (the tail travels as a native vector: an array of 16-byte structs is copied with memcpy and stays in scratch memory)
+__device__ __forceinline__ void xf_long_back(const fx::XfRot &K, const fx::XfWin &Wn, int lane, float *region, vf4 &tail) {
+    using namespace fx;
+    XfOut O;
+    const int ln = opaque(lane);
+    xf_long_s4_load(K, ln, region, O);
+    NYQ_WAVE_SYNC();
+    f4 t = {tail.x, tail.y, tail.z, tail.w};
+    xf_long_s4_store(Wn, ln, region, O, t);
+    tail = vf4{t.x, t.y, t.z, t.w};
+    NYQ_WAVE_SYNC();
+}
+__device__ __forceinline__ void xf_short_back(const fx::XfWin &Wn, int lane, int c, float *region, vf4 &tail, const float *__restrict__ trig) {
+    using namespace fx;
+    XfShortConst S;
+    xf_short_init(S, opaque(lane), trig);
+    float *const reg[2] = {region, region};                        // (both slots: the lane functions select by channel)
+    vf4 bk7 = {0, 0, 0, 0};
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
-        const f4 bk = xf_short_t4(S, opaque(lane), s, reg);
-        if (s == 1) bk7a = vf4{bk.x, bk.y, bk.z, bk.w};
-        if (s == 3) bk7b = vf4{bk.x, bk.y, bk.z, bk.w};
+    for (int s = 0; s < 2; s++) {                                  // post-rotation of the channel's 8 rows, in place
+        const f4 bk = xf_short_t4(S, opaque(lane), 2 * c + s, reg);
+        if (s == 1) bk7 = vf4{bk.x, bk.y, bk.z, bk.w};
     }
     NYQ_WAVE_SYNC();
 #pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-        for (int h = 1; h >= 0; h--) {
-            XfMirror M;
-            const int ln = opaque(lane);
-            const vf4 tv = c ? tail1 : tail0;
-            xf_short_t5_load(ln, c, h, reg, f4{tv.x, tv.y, tv.z, tv.w}, M);
-            NYQ_WAVE_SYNC();
-            xf_short_t5_store(K, ln, c, h, reg, M);
-            NYQ_WAVE_SYNC();
-        }
-    // the frame's tails: raw second half of block 7 of each channel, from the lanes that post-rotated it
+    for (int h = 1; h >= 0; h--) {
+        XfMirror M;
+        const int ln = opaque(lane);
+        xf_short_t5_load(ln, c, h, reg, f4{tail.x, tail.y, tail.z, tail.w}, M);
+        NYQ_WAVE_SYNC();
+        xf_short_t5_store(Wn, ln, c, h, reg, M);
+        NYQ_WAVE_SYNC();
+    }
+    // the frame's tail: raw second half of block 7, from the lanes that post-rotated it
     const int src = short_tail_src(lane);
-    tail0 = vf4{__shfl(bk7a.x, src), __shfl(bk7a.y, src), __shfl(bk7a.z, src), __shfl(bk7a.w, src)};
-    tail1 = vf4{__shfl(bk7b.x, src), __shfl(bk7b.y, src), __shfl(bk7b.z, src), __shfl(bk7b.w, src)};
+    tail = vf4{__shfl(bk7.x, src), __shfl(bk7.y, src), __shfl(bk7.z, src), __shfl(bk7.w, src)};
 }
 
 #ifndef NYQ_CHAIN_MINWAVES
@@ -230,17 +325,32 @@ __global__ __launch_bounds__(kWave *kChainWaves, NYQ_CHAIN_MINWAVES) void celt_c
     // (the last also separates this unit's LDS use from the next unit's prologue).
     if (wave < kPipeUnits) {
         // ------------------------------- comb wave of chain `wave` (as nyq_post_pipe.hpp) -------------------------------
-        __builtin_amdgcn_s_setprio(3);
+#ifndef NYQ_CHAIN_COMB_PRIO
+#define NYQ_CHAIN_COMB_PRIO 3
+#endif
+        __builtin_amdgcn_s_setprio(NYQ_CHAIN_COMB_PRIO);
+        fx::XfRot Kr;
+        fx::XfWin Kw;
+        fx::xf_init_rot(Kr, lane, trig);
+        fx::xf_init_win(Kw, lane, window);
         for (long s = blockIdx.x; s < A.nstreams; s += gridDim.x) {
             float *bA = bufs[wave][0], *bB = bufs[wave][1];
             int T_old = 0, T_cur = 0, ts_old = 0, ts_cur = 0;
             float g_old = 0.f, g_cur = 0.f;
+            // overlap carry of this chain (lane j < 15 holds state[56-4j .. 59-4j]) and the stream's transient flags, 64 frames
+            // at a time (one byte per lane + a ballot)
+            vf4 tail = {0, 0, 0, 0};
+            if (A.ov_state && fx::tail_lane(lane)) tail = *reinterpret_cast<const vf4 *>(A.ov_state + (2 * s + wave) * kHalfOv + fx::tail_offset(lane, 0));
+            const unsigned char *tbase = A.transient ? A.transient + s * fst : nullptr;
+            unsigned long long tmask = 0;
             if (A.pf_state) {
                 const float *ps = A.pf_state + 6 * s;
                 T_old = (int)ps[0]; T_cur = (int)ps[1]; g_old = ps[2]; g_cur = ps[3]; ts_old = (int)ps[4]; ts_cur = (int)ps[5];
             }
             __syncthreads();                                                   // P
+            NYQ_CSTAMP_DECL();
             for (long f = 0; f <= nfr; f++) {
+                NYQ_CSTAMP(0);                                                 // slot 0: at the barrier
                 if (f < nfr) {
                     float *cur = (f & 1) ? bB : bA, *nxt = (f & 1) ? bA : bB;
                     float *mir = nxt - N;                                      // mir[idx] = nxt[idx - N]
@@ -252,12 +362,31 @@ __global__ __launch_bounds__(kWave *kChainWaves, NYQ_CHAIN_MINWAVES) void celt_c
                     if (T_cur > kCombMaxPeriod) T_cur = kCombMaxPeriod;
                     if (T_old > kCombMaxPeriod) T_old = kCombMaxPeriod;
                     const int T_nw = T_new < kCombMinPeriod ? kCombMinPeriod : T_new > kCombMaxPeriod ? kCombMaxPeriod : T_new;
+                    // the frame arrives as the transform wave left it: natural-order FFT output.  Post-rotation + TDAC mirror
+                    // (mdct.c:322-377) here, in place, then the filter.
+                    if ((f & 63) == 0) {
+                        bool t = false;
+                        if (tbase && f + lane < nfr) t = tbase[f + lane] != 0;
+                        tmask = __ballot(t);
+                    }
+#ifndef NYQ_CHAIN_DBG_NO_BACK
+                    if ((tmask >> (f & 63)) & 1ull) xf_short_back(Kw, lane, wave, cur + R0, tail, trig);
+                    else xf_long_back(Kr, Kw, lane, cur + R0, tail);
+#endif
+                    NYQ_CSTAMP(2);                                             // slot 2: post-rotation + mirror
+#ifndef NYQ_CHAIN_DBG_NO_COMB
                     pipe_comb_call<true>(cur, mir, lane, R0, kOverlap, T_old, T_cur, g_old, g_cur, ts_old, ts_cur, win2);
                     pipe_comb_call<true>(cur, mir, lane, R0 + kOverlap, N - kOverlap, T_cur, T_nw, g_cur, g_new, ts_cur, ts_new, win2);
+#else
+                    (void)T_nw; (void)mir; (void)cur;
+#endif
                     T_old = T_cur = T_new; g_old = g_cur = g_new; ts_old = ts_cur = ts_new;   // :672-683 (LM != 0)
                 }
+                NYQ_CSTAMP(1);                                                 // slot 1: the frame's comb steps
                 __syncthreads();
             }
+            if (wave == 0) NYQ_CSTAMP_FLUSH(0);
+            if (A.ov_state && fx::tail_lane(lane)) *reinterpret_cast<vf4 *>(A.ov_state + (2 * s + wave) * kHalfOv + fx::tail_offset(lane, 0)) = tail;
             if (A.pf_state_out && wave == 0 && lane == 0) {
                 float *ps = A.pf_state_out + 6 * s;
                 ps[0] = (float)T_old; ps[1] = (float)T_cur; ps[2] = g_old; ps[3] = g_cur; ps[4] = (float)ts_old; ps[5] = (float)ts_cur;
@@ -300,7 +429,9 @@ __global__ __launch_bounds__(kWave *kChainWaves, NYQ_CHAIN_MINWAVES) void celt_c
                 if (nfr > 1) fetch_params(1);
             }
             __syncthreads();                                                   // P
+            NYQ_CSTAMP_DECL();
             for (long f = 0; f <= nfr; f++) {
+                NYQ_CSTAMP(0);                                                 // slot 0: at the barrier
                 const int cb = (int)(f & 1), nb = cb ^ 1;
                 if (f < nfr && KEEP > 0) {
 #pragma unroll
@@ -311,8 +442,13 @@ __global__ __launch_bounds__(kWave *kChainWaves, NYQ_CHAIN_MINWAVES) void celt_c
                     if (f + 2 < nfr) fetch_params(f + 2);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                NYQ_CSTAMP(1);                                                 // slot 1: carry-over, parameters
                 // frame f-1 is final in cur[R0 - N, R0)
+#ifndef NYQ_CHAIN_DBG_NO_IO
                 if (f >= 1)
+#else
+                if (f >= 1 && nfr < 0)
+#endif
                     deemph_store_pair<N>(bufs[0][cb] + R0 - N, bufs[1][cb] + R0 - N,
                                          reinterpret_cast<vf4 *>(A.out + (s * pst * N + (f - 1) * N) * 2), memL, memR, opaque(lane), D, pwHalf);
                 if (f == nfr) {
@@ -329,21 +465,21 @@ __global__ __launch_bounds__(kWave *kChainWaves, NYQ_CHAIN_MINWAVES) void celt_c
                         A.deemph[u0 + 1] = memR;
                     }
                 }
+                NYQ_CSTAMP(2);                                                 // slot 2: de-emphasis + stores
                 __syncthreads();
             }
+            NYQ_CSTAMP_FLUSH(8);
         }
     } else {
         // ------------------------------- transform wave -------------------------------
-        fx::XfConst K;
-        fx::xf_init(K, lane, trig, window);
+#ifdef NYQ_CHAIN_XF_PRIO
+        __builtin_amdgcn_s_setprio(NYQ_CHAIN_XF_PRIO);
+#endif
+        fx::XfRot K;
+        fx::XfTw W;
+        fx::xf_init_rot(K, lane, trig);
+        fx::xf_init_tw(W, lane);
         for (long s = blockIdx.x; s < A.nstreams; s += gridDim.x) {
-            float *const regA[2] = {bufs[0][0] + R0, bufs[1][0] + R0};
-            float *const regB[2] = {bufs[0][1] + R0, bufs[1][1] + R0};
-            vf4 tail0 = {0, 0, 0, 0}, tail1 = {0, 0, 0, 0};
-            if (A.ov_state && fx::tail_lane(lane)) {
-                tail0 = *reinterpret_cast<const vf4 *>(A.ov_state + 2 * s * kHalfOv + fx::tail_offset(lane, 0));
-                tail1 = *reinterpret_cast<const vf4 *>(A.ov_state + 2 * s * kHalfOv + fx::tail_offset(lane, 1));
-            }
             const float *fbase = A.freq + s * fst * 2 * (long)N;
             const unsigned char *tbase = A.transient ? A.transient + s * fst : nullptr;
             // transient flags of 64 frames at a time: one byte per lane + a ballot
@@ -354,24 +490,29 @@ __global__ __launch_bounds__(kWave *kChainWaves, NYQ_CHAIN_MINWAVES) void celt_c
                 return __ballot(t);
             };
             fx::XfRegs R;
-            if (nfr > 0) fx::xf_load<NYQ_PIPE_NT & 1>(R, lane, fbase);
+            float touch = 0.f;
+            if (nfr > 0) fx::xf_load<NYQ_PIPE_NT & 1>(R, opaque(lane), fbase);
             // iteration g transforms frame g in front of barrier g: frame 0 in front of P, frame f + 1 beside the filtering of
             // frame f; the last two barriers have no transform beside them (one call site for each of the two programs)
+            NYQ_CSTAMP_DECL();
             for (long g = 0; g < nfr + 2; g++) {
+                NYQ_CSTAMP(0);                                     // slot 0: at the barrier
                 if (g < nfr) {
                     if ((g & 63) == 0) tmask = flags(g);
                     float *const reg[2] = {bufs[0][g & 1] + R0, bufs[1][g & 1] + R0};
-                    if ((tmask >> (g & 63)) & 1ull) xf_short_frame(R, K, lane, reg, tail0, tail1, trig);
-                    else xf_long_frame(R, K, lane, reg, tail0, tail1);
+                    const float *next = g + 1 < nfr ? fbase + (g + 1) * 2 * (long)N : nullptr;
+#ifndef NYQ_CHAIN_DBG_NO_XF
+                    if (NYQ_CHAIN_TOUCH) asm volatile("" ::"v"(touch));          // (the touch of this frame's lines has come back)
+                    if ((tmask >> (g & 63)) & 1ull) xf_short_front(R, lane, reg, trig, next, touch);
+                    else xf_long_front(R, K, W, lane, reg, next, touch NYQ_CSTAMP_PASS);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
-                    if (g + 1 < nfr) fx::xf_load<NYQ_PIPE_NT & 1>(R, opaque(lane), fbase + (g + 1) * 2 * (long)N);
+                    if (!NYQ_CHAIN_EARLY_LOAD && next) fx::xf_load<NYQ_PIPE_NT & 1>(R, opaque(lane), next);
+                    NYQ_CSTAMP(6);                                 // slot 6: transient frames whole; issue of the next frame's loads
                 }
                 __syncthreads();
             }
-            if (A.ov_state && fx::tail_lane(lane)) {
-                *reinterpret_cast<vf4 *>(A.ov_state + 2 * s * kHalfOv + fx::tail_offset(lane, 0)) = tail0;
-                *reinterpret_cast<vf4 *>(A.ov_state + 2 * s * kHalfOv + fx::tail_offset(lane, 1)) = tail1;
-            }
+            NYQ_CSTAMP_FLUSH(16);
         }
     }
 }

@@ -13,8 +13,9 @@
 //   S2  lane (row r = lane >> 5, v = lane & 31 < 30): radix-16 over slots v + 30 k, in place.  Both rows at once.
 //   S3  lane (row, n2): radix-15 over slots 15 n2 + k1, natural order out.  All 64 lanes.
 //   S4  (once per row) same tasks as S0: post-rotation (mdct.c:322-359) -> raw[], TDAC mirror (mdct.c:362-377) of the head
-//       against the tail the SAME lane kept from the previous frame (registers: lane j < 15 holds tail[r][56-4j..59-4j]),
-//       finished samples out[0..960) back into the region.
+//       against the tail the SAME lane kept from the previous frame (registers: lane j < 15 holds tail[56-4j..59-4j]),
+//       finished samples out[0..960) back into the region.  S4 (and the transient program's T4, T5) of a row run on the
+//       chain's COMB wave, one iteration later, right before it filters the frame: the transform wave was the slowest role.
 // LDS layout of a row while it is being transformed (float2 slots): point (k1, k2lo, na) at 15 (na + 2 k2lo) + k1 after
 // S0, (k1, n2 = na + 2 nb) at 15 n2 + k1 after S2, natural order after S3.  Bank conflicts: S2, S3 none, S0 a few
 // 2-way ones that a ds_write_b64's issue time covers (searched: tools/scripts/fuse_layout_search.py).
@@ -50,12 +51,17 @@ NYQ_HD cpx cmul(cpx a, cpx w) { return {a.re * w.re - a.im * w.im, a.re * w.im +
 NYQ_HD int pfa_k1(int k) { return (8 * k) % 15; }
 NYQ_HD int pfa_k2(int k) { return (15 * k) & 31; }
 
-// lane-invariant values of the long program (and the window values of both programs' TDAC lanes)
-struct XfConst {
+// lane-invariant values.  The transform is split over two waves (nyq_chain_kernel.hpp): S0 .. S3 run on the transform
+// wave (XfRot + XfTw), S4 / T4 / T5 on the chain's own comb wave right before it filters the frame (XfRot + XfWin).
+struct XfRot {
     float tr[2][6];   // task t: trig[2j], [2j+1], [2j+2], [478-2j], [479-2j], [480-2j]
+};
+struct XfTw {
     cpx tw[4];        // point set R: e^{+2 pi i k2b / 32} (k2b = k2 of the set's m = 0 point)
-    int sb[4];        // point set R: slot of its na = 0 output, 30 k2lo + k1 (na = 1: + 15)
-    float wlo[4], whi[4];   // window[56-4j..59-4j], window[60+4j..63+4j], j = lane & 15 (< 15)
+    int sb01, sb23;   // point set R: slot of its na = 0 output, 30 k2lo + k1 (na = 1: + 15); two 16-bit fields per register
+};
+struct XfWin {
+    float wlo[4], whi[4];   // window[56-4j..59-4j], window[60+4j..63+4j], j = lane & 15 (< 15): TDAC lanes of both programs
 };
 
 // residue (mod 240) of point set R of lane v: 2v, 2v+1, 238-2v, 239-2v
@@ -71,7 +77,7 @@ NYQ_HD cpx w32(int m) {
 #endif
 }
 
-NYQ_HD void xf_init(XfConst &K, int lane, const float *trig, const float *window) {
+NYQ_HD void xf_init_rot(XfRot &K, int lane, const float *trig) {
     const int v = lane < kStageLanes ? lane : 0;   // idle lane: any valid index
 #pragma unroll
     for (int t = 0; t < 2; t++) {
@@ -83,13 +89,22 @@ NYQ_HD void xf_init(XfConst &K, int lane, const float *trig, const float *window
         K.tr[t][4] = trig[479 - 2 * j];
         K.tr[t][5] = trig[480 - 2 * j];
     }
+}
+NYQ_HD void xf_init_tw(XfTw &K, int lane) {
+    const int v = lane < kStageLanes ? lane : 0;
 #pragma unroll
     for (int R = 0; R < 4; R++) {
         const int k0 = set_residue(v, R);
         const int k1 = pfa_k1(k0), k2b = pfa_k2(k0);
-        K.sb[R] = 30 * (k2b & 15) + k1;
+        const int sb = 30 * (k2b & 15) + k1;
+        if (R == 0) K.sb01 = sb;
+        if (R == 1) K.sb01 |= sb << 16;
+        if (R == 2) K.sb23 = sb;
+        if (R == 3) K.sb23 |= sb << 16;
         K.tw[R] = w32(k2b);
     }
+}
+NYQ_HD void xf_init_win(XfWin &K, int lane, const float *window) {
     int j = lane & 15;
     if (j >= 15) j = 0;
 #pragma unroll
@@ -127,7 +142,7 @@ constexpr float kSineShort = Geo<4>::SINE;
 
 // ---- long frame ------------------------------------------------------------------------------------------
 // S0 of row r: pre-rotation, radix-2 over m, twiddle, scatter.  region = the row's 960 floats = 480 slots.
-NYQ_HD void xf_long_s0(const XfRegs &R, const XfConst &K, int lane, int r, float *region) {
+NYQ_HD void xf_long_s0(const XfRegs &R, const XfRot &K, const XfTw &W, int lane, int r, float *region) {
     if (!stage_lane(lane)) return;
     cpx *row = reinterpret_cast<cpx *>(region);
     cpx p[2][4];
@@ -144,9 +159,10 @@ NYQ_HD void xf_long_s0(const XfRegs &R, const XfConst &K, int lane, int r, float
     const cpx s1[4] = {p[1][2], p[1][3], p[0][2], p[0][3]};     // 240+2v, 241+2v, 478-2v, 479-2v
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        cpx *o = row + K.sb[q];
+        const int pk = q < 2 ? W.sb01 : W.sb23;
+        cpx *o = row + ((q & 1) ? (pk >> 16) : (pk & 0xffff));
         o[0] = cadd(s0[q], s1[q]);
-        o[15] = cmul(csub(s0[q], s1[q]), K.tw[q]);
+        o[15] = cmul(csub(s0[q], s1[q]), W.tw[q]);
     }
 }
 
@@ -184,7 +200,7 @@ NYQ_HD void xf_long_s3_store(int lane, float *const (&reg)[2], cpx (&v)[15]) {
 }
 
 // the TDAC mirror of one head task (nyq_imdct_lanes.hpp tdac_mix, on this program's window registers)
-NYQ_HD void xf_tdac(const XfConst &K, f4 F, f4 C, f4 &hi, f4 &lo) {
+NYQ_HD void xf_tdac(const XfWin &K, f4 F, f4 C, f4 &hi, f4 &lo) {
     hi.x = K.wlo[3] * C.w + K.whi[0] * F.x;
     hi.y = K.wlo[2] * C.z + K.whi[1] * F.y;
     hi.z = K.wlo[1] * C.y + K.whi[2] * F.z;
@@ -209,7 +225,7 @@ NYQ_HD void xf_postrot4(f4 P01, f4 P23, const float (&tr)[6], float sine, f4 &F,
 struct XfOut {
     f4 F[2], Bk[2];
 };
-NYQ_HD void xf_long_s4_load(const XfConst &K, int lane, const float *region, XfOut &O) {
+NYQ_HD void xf_long_s4_load(const XfRot &K, int lane, const float *region, XfOut &O) {
     const int v = stage_lane(lane) ? lane : 0;
 #pragma unroll
     for (int t = 0; t < 2; t++) {
@@ -221,7 +237,7 @@ NYQ_HD void xf_long_s4_load(const XfConst &K, int lane, const float *region, XfO
 }
 // out[60 + 4j ..] = raw[4j ..]; out[1016 - 4j ..] = raw[956 - 4j ..] (j >= 15); heads j < 15: mirror against `tail`,
 // which then becomes this frame's raw[956-4j..959-4j]
-NYQ_HD void xf_long_s4_store(const XfConst &K, int lane, float *region, const XfOut &O, f4 &tail) {
+NYQ_HD void xf_long_s4_store(const XfWin &K, int lane, float *region, const XfOut &O, f4 &tail) {
     if (!stage_lane(lane)) return;
     const int v = lane;
     {
@@ -367,7 +383,7 @@ NYQ_HD void xf_short_t5_load(int lane, int c, int h, float *const (&reg)[2], con
     M.F = *reinterpret_cast<const f4 *>(r + 120 * blk + 4 * j);
     M.C = blk > 0 ? *reinterpret_cast<const f4 *>(r + 120 * (blk - 1) + 116 - 4 * j) : tail;   // (blk 0 <=> lane j: `tail` = the channel's)
 }
-NYQ_HD void xf_short_t5_store(const XfConst &K, int lane, int c, int h, float *const (&reg)[2], const XfMirror &M) {
+NYQ_HD void xf_short_t5_store(const XfWin &K, int lane, int c, int h, float *const (&reg)[2], const XfMirror &M) {
     const int j = lane & 15;
     if (j >= 15) return;
     const int blk = 4 * h + (lane >> 4);

@@ -1167,6 +1167,74 @@ extern "C" int nyq_celt_frames_to_pcm_window(nyq_ctx *ctx, int LM, const float *
                               frames_per_stream);
 }
 
+// ---- device copy: a measurement utility -----------------------------------------------------------
+// How fast does THIS box stream N bytes in + N bytes out?  The row kernels read and write the same number of bytes, so a
+// tuned plain copy is their practical ceiling; bench.py times these forms in-process and reports the best
+// as roofline.measured_device_copy_GBps.  (tools/copybench.hip is the stand-alone survey the forms were picked from.)
+template <int U>
+__global__ __launch_bounds__(256) void copy_gs_kernel(const vf4 *__restrict__ in, vf4 *__restrict__ out, size_t n4) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (U - 1) * stride < n4; i += U * stride) {
+        vf4 r[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) r[k] = in[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < U; k++) out[i + k * stride] = r[k];
+    }
+    for (; i < n4; i += stride) out[i] = in[i];
+}
+template <int CH, int NT>
+__global__ __launch_bounds__(128) void copy_chunk_kernel(const vf4 *__restrict__ in, vf4 *__restrict__ out, size_t n4) {
+    // each wave owns contiguous chunks of CH KB, loads a whole chunk into registers, then stores it (the row kernels' shape)
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const size_t nchunks = n4 / (CH * 64);
+    for (size_t c = wave; c < nchunks; c += nw) {
+        const vf4 *p = in + c * (CH * 64) + lane;
+        vf4 *q = out + c * (CH * 64) + lane;
+        vf4 r[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) r[k] = NT ? __builtin_nontemporal_load(p + 64 * k) : p[64 * k];
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            if (NT) __builtin_nontemporal_store(r[k], q + 64 * k);
+            else q[64 * k] = r[k];
+        }
+    }
+    for (size_t i = nchunks * (CH * 64) + wave * 64 + lane; i < n4; i += nw * 64) out[i] = in[i];
+}
+
+static const char *const kCopyForms[] = {"grid-stride float4, 8 blocks/CU", "grid-stride float4 x4, 4 blocks/CU", "grid-stride float4 x4, 6 blocks/CU",
+                                         "15 KB chunk per wave, 6 waves/CU", "15 KB chunk per wave, 4 waves/CU", "4 KB chunk per wave, 6 waves/CU",
+                                         "15 KB chunk per wave, non-temporal, 6 waves/CU"};
+extern "C" int nyq_device_copy_forms(void) { return (int)(sizeof kCopyForms / sizeof kCopyForms[0]); }
+extern "C" const char *nyq_device_copy_form_name(int form) {
+    return form >= 0 && form < nyq_device_copy_forms() ? kCopyForms[form] : "";
+}
+extern "C" int nyq_device_copy_dev(nyq_ctx *ctx, void *d_dst, const void *d_src, size_t bytes, int form) {
+    if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_device_copy_dev: ctx is NULL");
+    if (!d_dst || !d_src || !aligned16(d_dst) || !aligned16(d_src) || (bytes & 15))
+        return fail(ctx, NYQ_ERR_INVALID, "nyq_device_copy_dev: 16-byte aligned buffers and a multiple of 16 bytes");
+    if (form < 0 || form >= nyq_device_copy_forms()) return fail(ctx, NYQ_ERR_INVALID, "nyq_device_copy_dev: unknown form");
+    const size_t n4 = bytes / 16;
+    if (n4 == 0) return NYQ_OK;
+    const vf4 *in = static_cast<const vf4 *>(d_src);
+    vf4 *out = static_cast<vf4 *>(d_dst);
+    const unsigned cus = (unsigned)ctx->cus;
+    switch (form) {
+    case 0: hipLaunchKernelGGL(copy_gs_kernel<1>, dim3(cus * 8), dim3(256), 0, ctx->stream, in, out, n4); break;
+    case 1: hipLaunchKernelGGL(copy_gs_kernel<4>, dim3(cus * 4), dim3(256), 0, ctx->stream, in, out, n4); break;
+    case 2: hipLaunchKernelGGL(copy_gs_kernel<4>, dim3(cus * 6), dim3(256), 0, ctx->stream, in, out, n4); break;
+    case 3: hipLaunchKernelGGL((copy_chunk_kernel<15, 0>), dim3(cus * 3), dim3(128), 0, ctx->stream, in, out, n4); break;
+    case 4: hipLaunchKernelGGL((copy_chunk_kernel<15, 0>), dim3(cus * 2), dim3(128), 0, ctx->stream, in, out, n4); break;
+    case 5: hipLaunchKernelGGL((copy_chunk_kernel<4, 0>), dim3(cus * 3), dim3(128), 0, ctx->stream, in, out, n4); break;
+    default: hipLaunchKernelGGL((copy_chunk_kernel<15, 1>), dim3(cus * 3), dim3(128), 0, ctx->stream, in, out, n4); break;
+    }
+    NYQ_HIP(ctx, hipGetLastError());
+    return NYQ_OK;
+}
+
 // ---- the reference's operator names (cuda/mdct_cuda.hpp:79-103) --------------------
 // State of the drop-in entry points.  The reference keeps an unsynchronised global map keyed by a sum of buffer sizes
 // (mdct_cuda.cu:558-584); here one mutex serialises the calls (the interface is synchronous and moves ~8 KB per call:
@@ -1189,59 +1257,74 @@ extern "C" void nyq_shim_set_error_handler(void (*handler)(const char *who, cons
     g_shim_handler = handler;
 }
 
-struct ShimFailure {};   // unwinds a shim call after the handler has returned
-
-static void shim_die(const char *who, const char *what) {   // call with g_shim_mu held or before it is taken
-    if (g_shim_handler) {
-        g_shim_handler(who, what);
-        throw ShimFailure{};
+// A failed shim call: the reason, recorded under the lock; the handler runs AFTER the lock is released (it may call any
+// entry point of this library, the shims and cleanupCudaBuffers included), and nothing is thrown across the foreign callback.
+struct ShimFault {
+    bool failed = false;
+    bool hip = false;                 // a HIP failure: the shim's context is dropped so that the next call starts afresh
+    std::string what;
+    void set(const std::string &w, bool from_hip = false) {
+        if (!failed) { failed = true; hip = from_hip; what = w; }
     }
-    std::fprintf(stderr, "%s: %s\n", who, what);
-    std::abort();
+};
+
+static void shim_drop_ctx() {                                  // call with g_shim_mu held
+    if (g_shim_ctx) nyq_ctx_destroy(g_shim_ctx);
+    g_shim_ctx = nullptr;
+    g_shim_tables_set = false;
 }
 
-static nyq_ctx *shim_ctx(const char *who, const float *trig, const float *window) {   // call with g_shim_mu held
+static nyq_ctx *shim_ctx(ShimFault &F, const float *trig, const float *window) {   // call with g_shim_mu held
     if (!g_shim_ctx) {
         const char *dev = std::getenv("NYQ_DEVICE");
-        if (nyq_ctx_create(&g_shim_ctx, dev ? std::atoi(dev) : 0) != NYQ_OK) shim_die(who, nyq_last_error(nullptr));
+        if (nyq_ctx_create(&g_shim_ctx, dev ? std::atoi(dev) : 0) != NYQ_OK) {
+            F.set(nyq_last_error(nullptr));
+            g_shim_ctx = nullptr;
+            return nullptr;
+        }
         g_shim_tables_set = false;
     }
     // the reference uploads trig/window once per state (mdct_cuda.cu:577-579); here whenever their CONTENT differs from
     // what the context holds (2.4 KB compared per call)
     if (!g_shim_tables_set || std::memcmp(g_shim_ctx->h_trig, trig, sizeof g_shim_ctx->h_trig) != 0 ||
         std::memcmp(g_shim_ctx->h_window, window, sizeof g_shim_ctx->h_window) != 0) {
-        if (nyq_ctx_set_tables(g_shim_ctx, trig, window) != NYQ_OK) shim_die(who, nyq_last_error(g_shim_ctx));
+        if (nyq_ctx_set_tables(g_shim_ctx, trig, window) != NYQ_OK) {
+            F.set(nyq_last_error(g_shim_ctx), true);
+            return nullptr;
+        }
         g_shim_tables_set = true;
     }
     return g_shim_ctx;
 }
 
-// One call of the reference's offload interface = one or two rows.  The round trip is latency, not
+// One call of the reference's offload interface = one, two or eight rows.  The round trip is latency, not
 // bandwidth, so the rows go through a small page-locked block that the GPU reads and writes in place over
 // PCIe (host memory from hipHostMalloc is device-addressable): marshal -> ONE kernel launch -> synchronise
 // -> copy out.  No H2D/D2H copy commands, no events.
+constexpr int kShimRows = 8;
 struct ShimPinned {
-    float in[2][NYQ_MDCT_N / 2];
-    float fin[2][NYQ_MDCT_N / 2];
-    float carry[2][NYQ_HALF_OV + 4];   // rows stay 16-byte aligned: 64 floats apart
-    float tail[2][NYQ_HALF_OV + 4];
+    float in[kShimRows][NYQ_MDCT_N / 2];
+    float fin[kShimRows][NYQ_MDCT_N / 2];
+    float carry[kShimRows][NYQ_HALF_OV + 4];   // (rows of `nch` calls are packed 60 floats apart from the start of the block)
+    float tail[kShimRows][NYQ_HALF_OV + 4];
 };
 static ShimPinned *g_shim_pin = nullptr;
 
-static void shim_rows(const char *who, int nch, const float *const *input, float *const *output, const float *trig,
-                      int N, int shift, int stride, int overlap, const float *window) {
-    std::lock_guard<std::mutex> lk(g_shim_mu);
-    try {
+static void shim_rows_locked(ShimFault &F, int nch, const float *const *input, float *const *output, const float *trig,
+                             int N, int shift, int stride, int overlap, const float *window) {
     if (shift < 0 || shift > 3 || N != (NYQ_MDCT_N >> shift) || overlap != NYQ_OVERLAP || stride < 1 || !trig || !window)
-        shim_die(who, "unsupported call: only the static 48 kHz mode (mdct.n 1920, overlap 120, shift 0..3) exists");
-    nyq_ctx *ctx = shim_ctx(who, trig, window);
+        return F.set("unsupported call: only the static 48 kHz mode (mdct.n 1920, overlap 120, shift 0..3) exists");
+    for (int c = 0; c < nch; c++)
+        if (!input[c] || !output[c]) return F.set("NULL input / output row");
+    nyq_ctx *ctx = shim_ctx(F, trig, window);
+    if (!ctx) return;
     if (!g_shim_pin) {
         g_shim_pin = static_cast<ShimPinned *>(nyq_host_alloc(sizeof(ShimPinned)));
-        if (!g_shim_pin) shim_die(who, "cannot allocate page-locked staging memory");
+        if (!g_shim_pin) return F.set("cannot allocate page-locked staging memory");
     }
     ShimPinned &P = *g_shim_pin;
     const int n2 = N >> 1;
-    // rows must be contiguous per array: channel 1 right after channel 0 (n2 floats apart; carries 60 apart)
+    // rows must be contiguous per array: channel c + 1 right after channel c (n2 floats apart; carries 60 apart)
     float *pin = &P.in[0][0], *pfin = &P.fin[0][0], *pcar = &P.carry[0][0], *ptail = &P.tail[0][0];
     for (int c = 0; c < nch; c++) {
         const float *src = input[c];
@@ -1251,14 +1334,30 @@ static void shim_rows(const char *who, int nch, const float *const *input, float
         std::memcpy(pcar + c * NYQ_HALF_OV, output[c], sizeof(float) * NYQ_HALF_OV);
     }
     if (nyq_imdct_batch_dev(ctx, shift, pin, pcar, pfin, ptail, (size_t)nch) != NYQ_OK || nyq_ctx_synchronize(ctx) != NYQ_OK)
-        shim_die(who, nyq_last_error(ctx));
+        return F.set(nyq_last_error(ctx), true);
     for (int c = 0; c < nch; c++) {
         std::memcpy(output[c], pfin + c * n2, sizeof(float) * n2);
         std::memcpy(output[c] + n2, ptail + c * NYQ_HALF_OV, sizeof(float) * NYQ_HALF_OV);
     }
-    } catch (const ShimFailure &) {
-        // the installed handler has been told; output is untouched
+}
+
+static void shim_rows(const char *who, int nch, const float *const *input, float *const *output, const float *trig,
+                      int N, int shift, int stride, int overlap, const float *window) {
+    ShimFault F;
+    void (*handler)(const char *, const char *) = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_shim_mu);
+        shim_rows_locked(F, nch, input, output, trig, N, shift, stride, overlap, window);
+        if (F.failed && F.hip) shim_drop_ctx();      // (a context that has seen a HIP error is not reused)
+        handler = g_shim_handler;
     }
+    if (!F.failed) return;
+    if (handler) {
+        handler(who, F.what.c_str());                // lock released: the handler may call back into the library
+        return;                                      // `output` is untouched
+    }
+    std::fprintf(stderr, "%s: %s\n", who, F.what.c_str());
+    std::abort();
 }
 
 extern "C" void processMDCTCuda(const float *input, float *output, const float *trig, int N, int shift, int stride,
@@ -1275,13 +1374,20 @@ extern "C" void processMDCTCudaB1C2(const float *input[2], float *output[2], con
     shim_rows("processMDCTCudaB1C2", 2, input, output, trig, N, shift, stride, overlap, window);
 }
 
+// cuda/mdct_cuda.hpp:96-98.  Declared with eight row pointers; the reference never calls it and its own definition
+// (mdct_cuda_b8.cu:482-501) takes two -- here it is what the declaration says: eight clt_mdct_backward rows of one size in
+// one launch (= four B1C2 calls), so that a program linking the header's whole symbol set links and gets defined results.
+extern "C" void processMDCTCudaB8C2(const float *input[8], float *output[8], const float *trig, int N, int shift,
+                                    int stride, float sine, int overlap, const float *window) {
+    (void)sine;
+    shim_rows("processMDCTCudaB8C2", 8, input, output, trig, N, shift, stride, overlap, window);
+}
+
 extern "C" void cleanupCudaBuffers(void) {
     std::lock_guard<std::mutex> lk(g_shim_mu);
     if (g_shim_pin) nyq_host_free(g_shim_pin);
     g_shim_pin = nullptr;
-    if (g_shim_ctx) nyq_ctx_destroy(g_shim_ctx);
-    g_shim_ctx = nullptr;
-    g_shim_tables_set = false;
+    shim_drop_ctx();
 }
 
 extern "C" void printCudaVersion(void) {
@@ -1293,6 +1399,13 @@ extern "C" void printCudaVersion(void) {
 }
 
 #ifdef NYQ_PIPE_STAMPS
+// diagnostic build only (tools/chain_stamps.py): the one-launch chain kernel's per-role cycle sums; reset != 0 clears them
+extern "C" int nyq_debug_chain_stamps(unsigned long long *out32, int reset) {
+    unsigned long long z[32] = {0};
+    if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(nyq::g_chain_stamps), sizeof z) != hipSuccess) return 1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(nyq::g_chain_stamps), z, sizeof z) != hipSuccess) return 1;
+    return 0;
+}
 // diagnostic build only (tools/placement_trace.py): the post-filter pipeline's per-workgroup placement trace
 extern "C" int nyq_debug_pipe_wg(void *out, size_t bytes) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(nyq::g_pipe_wg), bytes < sizeof(nyq::g_pipe_wg) ? bytes : sizeof(nyq::g_pipe_wg)) == hipSuccess ? 0 : 1;

@@ -257,11 +257,15 @@ extern "C" int emu_fuse_synth(const float *freq, const unsigned char *transient,
     using namespace nyq::fx;
     std::vector<float> r0(kN, 0.f), r1(kN, 0.f);
     float *const reg[2] = {r0.data(), r1.data()};
-    std::vector<XfConst> K(kWave);
+    std::vector<XfRot> K(kWave);
+    std::vector<XfTw> W(kWave);
+    std::vector<XfWin> Wn(kWave);
     std::vector<XfShortConst> S(kWave);
     std::vector<f4> tail[2] = {std::vector<f4>(kWave, f4{0, 0, 0, 0}), std::vector<f4>(kWave, f4{0, 0, 0, 0})};
     for (int l = 0; l < kWave; l++) {
-        xf_init(K[l], l, trig, window);
+        xf_init_rot(K[l], l, trig);
+        xf_init_tw(W[l], l);
+        xf_init_win(Wn[l], l, window);
         xf_short_init(S[l], l, trig);
         for (int c = 0; c < 2; c++)
             if (state && tail_lane(l)) tail[c][l] = *reinterpret_cast<const f4 *>(state + tail_offset(l, c));
@@ -272,7 +276,7 @@ extern "C" int emu_fuse_synth(const float *freq, const unsigned char *transient,
         for (int l = 0; l < kWave; l++) xf_load<0>(R[l], l, frame);
         if (!(transient && transient[f])) {
             for (int r = 0; r < 2; r++)
-                for (int l = 0; l < kWave; l++) xf_long_s0(R[l], K[l], l, r, reg[r]);
+                for (int l = 0; l < kWave; l++) xf_long_s0(R[l], K[l], W[l], l, r, reg[r]);
             {
                 cpx u[kWave][16];
                 for (int l = 0; l < kWave; l++) xf_long_s2_load(l, reg, u[l]);
@@ -286,7 +290,7 @@ extern "C" int emu_fuse_synth(const float *freq, const unsigned char *transient,
             for (int r = 0; r < 2; r++) {
                 std::vector<XfOut> O(kWave);
                 for (int l = 0; l < kWave; l++) xf_long_s4_load(K[l], l, reg[r], O[l]);
-                for (int l = 0; l < kWave; l++) xf_long_s4_store(K[l], l, reg[r], O[l], tail[r][l]);
+                for (int l = 0; l < kWave; l++) xf_long_s4_store(Wn[l], l, reg[r], O[l], tail[r][l]);
             }
         } else {
             for (int l = 0; l < kWave; l++) xf_short_t0(R[l], l, reg);
@@ -309,7 +313,7 @@ extern "C" int emu_fuse_synth(const float *freq, const unsigned char *transient,
                 for (int h = 1; h >= 0; h--) {
                     std::vector<XfMirror> M(kWave);
                     for (int l = 0; l < kWave; l++) xf_short_t5_load(l, c, h, reg, tail[c][l], M[l]);
-                    for (int l = 0; l < kWave; l++) xf_short_t5_store(K[l], l, c, h, reg, M[l]);
+                    for (int l = 0; l < kWave; l++) xf_short_t5_store(Wn[l], l, c, h, reg, M[l]);
                 }
             for (int c = 0; c < 2; c++)
                 for (int l = 0; l < kWave; l++)

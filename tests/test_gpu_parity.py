@@ -214,6 +214,48 @@ def test_dropin_shims_vs_reference_strided_fixture(ref_tables):
     lib.cleanupCudaBuffers()
 
 
+def test_dropin_b8c2_is_eight_rows_and_the_handler_may_call_back(ref_tables, oracle):
+    """processMDCTCudaB8C2 (cuda/mdct_cuda.hpp:96-98: declared with eight row pointers, never called by the reference): eight
+    clt_mdct_backward rows per call, equal to the oracle's.  And the error handler runs with no library lock held: a handler
+    that calls cleanupCudaBuffers() and another operator (what an integrator would do on a failure) returns."""
+    import libnyquist_amd as nyq
+    lib = nyq.load()
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    trig = np.ascontiguousarray(ref_tables["trig"])
+    win = np.ascontiguousarray(ref_tables["window"])
+    rng = np.random.default_rng(88)
+    sine1 = np.float32(2) * np.float32(3.141592653) * np.float32(.125) / np.float32(960)
+    x = (rng.standard_normal((8, 480)) * 30).astype(np.float32)
+    mem = np.zeros((8, 480 + 60), np.float32)
+    mem[:, :60] = (rng.standard_normal((8, 60)) * 30).astype(np.float32)
+    want_f, want_t = oracle.imdct_batch(1, x, mem[:, :60].copy())
+    fp8 = C.c_void_p * 8
+    lib.processMDCTCudaB8C2(fp8(*[x[r].ctypes.data for r in range(8)]), fp8(*[mem[r].ctypes.data for r in range(8)]), P(trig), 960, 1, 1,
+                            sine1, 120, P(win))
+    assert rel_rms(mem, np.concatenate([want_f, want_t], axis=1)) <= 1e-6
+    seen = []
+    HANDLER = C.CFUNCTYPE(None, C.c_char_p, C.c_char_p)
+
+    def on_error(who, what):
+        seen.append((who, what))
+        lib.cleanupCudaBuffers()                                   # would deadlock if the shim's mutex were still held
+        m2 = np.zeros(480 + 60, np.float32)
+        lib.processMDCTCuda(P(x[0]), P(m2), P(trig), 960, 1, 1, sine1, 120, P(win))
+        seen.append(rel_rms(m2[:480], want_f[0] * 0 + oracle.imdct_batch(1, x[:1], None)[0][0]))
+
+    cb = HANDLER(on_error)
+    lib.nyq_shim_set_error_handler.argtypes = [HANDLER]
+    lib.nyq_shim_set_error_handler(cb)
+    try:
+        before = mem.copy()
+        lib.processMDCTCuda(P(x[0]), P(mem[0]), P(trig), 1000, 1, 1, sine1, 120, P(win))   # N does not belong to the mode
+        assert seen and seen[0][0] == b"processMDCTCuda" and np.array_equal(mem, before)
+        assert seen[1] <= 1e-6
+    finally:
+        lib.nyq_shim_set_error_handler(C.cast(None, HANDLER))
+    lib.cleanupCudaBuffers()
+
+
 def test_dropin_shims_tables_by_content_and_threads(ref_tables, oracle):
     """The reference-named entry points keep process-wide state (one context, the uploaded tables).  (1) Tables are
     identified by CONTENT: a caller that refills the SAME buffers with another window gets results for the new window

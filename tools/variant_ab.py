@@ -84,7 +84,10 @@ def run(ns, nf, cases):
                "post": lambda c: c.celt_post_dev(3, pcm.data_ptr(), pitch.data_ptr(), gain.data_ptr(), tap.data_ptr(), 0, 0, 0, 0, out.data_ptr(), ns, nf, ch),
                "chain": lambda c: c.celt_chain_dev(3, freq.data_ptr(), trans.data_ptr(), pitch.data_ptr(), gain.data_ptr(), tap.data_ptr(), 0, 0, 0, 0, 0,
                                                    out.data_ptr(), pcm.data_ptr(), work.data_ptr(), ns, nf, ch)}
+        only = os.environ.get("VAB_OPS")           # e.g. VAB_OPS=chain,post
         for opname, op in ops.items():
+            if only and opname not in only.split(","):
+                continue
             times = [[] for _ in ctxs]
             outs = []
             for rnd in range(12):
