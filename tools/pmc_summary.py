@@ -3,7 +3,7 @@
 
 Usage: tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <rows> <out.json>
 
-Emits one record per kernel of interest -- the headline kernel `imdct_rows_kernel<32>` (what bench.py's
+Emits one record per kernel of interest -- the one-launch frames -> PCM kernel `celt_chain_kernel` (round 4), the headline kernel `imdct_rows_kernel<32>` (what bench.py's
 `roofline.traffic` quotes), and the two stages of the frames -> PCM chain, `synth_frames_kernel<32, 3>` (key `synth_long_kernel<32>`, its name before round 3's single launch) and the post-filter
 kernel (`celt_post_pipe_kernel<3>`, or `celt_post_kernel<3,...>` when the round-1 form ran) -- each with its algorithmic
 bytes and the ratio to them, plus the sha of the kernel sources the passes were taken with: bench.py replays the
@@ -51,7 +51,9 @@ def main():
             "synth_long_kernel<32>": record(fetch_csv, write_csv, "synth_frames_kernelILi32ELi3", 7680 * chain_units) or
             record(fetch_csv, write_csv, "synth_frames_kernel<32, 3", 7680 * chain_units),
             "post_filter_kernel": record(fetch_csv, write_csv, "celt_post_pipe_kernel", 7680 * chain_units) or
-            record(fetch_csv, write_csv, "celt_post_kernel", 7680 * chain_units)}
+            record(fetch_csv, write_csv, "celt_post_kernel", 7680 * chain_units),
+            # round 4: freq[] -> interleaved PCM in ONE launch (3840 B in + 3840 B out per channel-frame)
+            "celt_chain_kernel": record(fetch_csv, write_csv, "celt_chain_kernel", 7680 * chain_units)}
     head_rec = recs["imdct_rows_kernel<32>"]
     d = {"rows": rows, "kernel": "imdct_rows_kernel<32>", "csrc_sha16": csrc_digest(), "git_head": head,
          "measured_on": datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%dT%H:%MZ"),
