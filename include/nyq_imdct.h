@@ -188,6 +188,36 @@ int nyq_celt_chain_dev(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned
                        float *d_deemph, float *d_out, float *d_pcm, float *d_work,
                        size_t nstreams, size_t nframes, int channels);
 
+/* ---- the samples straight into the FILE's layout ----
+ * What opus_multistream_decode_native does with every elementary stream's PCM (opus_copy_channel_out_float,
+ * opus_multistream_decoder.c:305-331, call sites :237-290), what opusfile does with the stream's ends (skip pre_skip
+ * samples, stop at the last granule position) and the header gain (OPUS_SET_GAIN, opus_decoder_clean.c:700-712) --
+ * done by the kernels' own store phase instead of a per-sample pass on the host: a stream with a destination record
+ * writes sample ts of its channel k to  base[(ts - first) * cstride + coff[k]]  (times gain) for first <= ts < last and
+ * nowhere else.  `base` is device memory (nyq_device_alloc); records are per elementary stream (mono or stereo). */
+typedef struct nyq_out_desc {
+    float *base;            /* device: where stream sample `first`, destination channel slot 0 goes; NULL = dense output */
+    long long first, last;  /* stream samples [first, last) are written (pre-skip / end trim), the rest is dropped */
+    long long t0;           /* stream sample index of the call's first sample (a time slice of a longer stream) */
+    int cstride;            /* floats from one sample to the next in the destination = the file's channel count */
+    int coff[2];            /* destination channel slot of the stream's channel 0 / 1; -1 = not written */
+    float gain;             /* multiplied in; 1 = none */
+} nyq_out_desc;
+/* nyq_celt_chain_dev with per-stream destinations: d_desc [nstreams] (device memory) or NULL; channels 1 or 2.  d_out
+ * (the dense output) may be NULL when every record has a base. */
+int nyq_celt_chain_mapped_dev(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned char *d_transient,
+                              const int *d_pf_pitch, const float *d_pf_gain, const int *d_pf_tapset,
+                              const float *d_pf_state_in, float *d_pf_state_out, float *d_overlap, float *d_hist,
+                              float *d_deemph, float *d_out, const nyq_out_desc *d_desc, float *d_pcm, float *d_work,
+                              size_t nstreams, size_t nframes, int channels);
+/* device memory for such destinations (on the context's device; synchronous calls) */
+void *nyq_device_alloc(nyq_ctx *ctx, size_t bytes);              /* NULL on failure */
+void nyq_device_free(nyq_ctx *ctx, void *d_p);
+int nyq_device_zero(nyq_ctx *ctx, void *d_p, size_t bytes);      /* silent channels (mapping 255) stay zero */
+int nyq_device_download(nyq_ctx *ctx, void *host_dst, const void *d_src, size_t bytes);
+/* destination channel src_slot repeated in dst_slot (a mapping may name one decoded channel twice) */
+int nyq_device_dup_channel(nyq_ctx *ctx, float *d_base, int cstride, int src_slot, int dst_slot, size_t nsamples);
+
 /* libvorbis' mdct_backward (third_party/libvorbis/src/mdct.c:397-491) on `batch` rows: n/2 coefficients
  * in, n samples out per row, n a power of two in 64..8192 (every Vorbis block size).
  * d_in [batch][n/2], d_out [batch][n].  out[i] = sum_k in[k] cos(2 pi/n (i + 1/2 + n/4)(k + 1/2)):
@@ -238,6 +268,14 @@ int nyq_celt_frames_to_pcm_window(nyq_ctx *ctx, int LM, const float *freq, const
                                   const int *pf_pitch, const float *pf_gain, const int *pf_tapset,
                                   float *out, float *state, size_t nstreams, size_t nframes, int channels,
                                   size_t frames_per_stream);
+
+/* nyq_celt_frames_to_pcm_window with per-stream destinations: desc [nstreams] (HOST array; its `base` pointers are
+ * device memory) or NULL.  Streams with a destination are written there by the kernels and are not downloaded into
+ * `out`; when every stream has one, `out` may be NULL. */
+int nyq_celt_frames_to_pcm_mapped(nyq_ctx *ctx, int LM, const float *freq, const unsigned char *transient,
+                                  const int *pf_pitch, const float *pf_gain, const int *pf_tapset,
+                                  float *out, const nyq_out_desc *desc, float *state, size_t nstreams, size_t nframes,
+                                  int channels, size_t frames_per_stream);
 
 /* ---- the reference's operator boundary, kept verbatim ------------------- */
 /* cuda/mdct_cuda.hpp:89-91 (impl mdct_cuda.cu:314-392).  Host pointers, caller-owned.

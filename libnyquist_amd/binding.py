@@ -28,6 +28,8 @@ EXPORTS = [
     "nyq_ifft_batch_dev", "nyq_imdct_batch_dev", "nyq_imdct_chain_dev",
     "nyq_celt_synth_work_floats", "nyq_celt_synth_dev", "nyq_celt_synth", "nyq_celt_post_dev",
     "nyq_celt_chain_fused_supported", "nyq_celt_chain_dev", "nyq_device_copy_forms", "nyq_device_copy_form_name", "nyq_device_copy_dev",
+    "nyq_celt_chain_mapped_dev", "nyq_device_alloc", "nyq_device_free", "nyq_device_zero", "nyq_device_download", "nyq_device_dup_channel",
+    "nyq_celt_frames_to_pcm_mapped",
     "nyq_celt_frames_to_pcm", "nyq_celt_frames_to_pcm_window", "nyq_celt_state_floats", "nyq_vorbis_imdct_batch_dev", "nyq_vorbis_imdct_batch",
     "nyq_ifft_batch", "nyq_imdct_batch", "nyq_imdct_chain", "nyq_host_alloc", "nyq_host_free",
     "processMDCTCuda", "processMDCTCudaB1C2", "processMDCTCudaB8C2", "cleanupCudaBuffers", "printCudaVersion", "nyq_shim_set_error_handler",
@@ -136,6 +138,15 @@ def load(path=None):
     L.nyq_celt_post_round_chains.argtypes = [vp]
     L.nyq_celt_post_round_chains.restype = sz
     L.nyq_celt_chain_fused_supported.argtypes = [i, i]
+    L.nyq_celt_chain_mapped_dev.argtypes = [vp, i] + [vp] * 14 + [sz, sz, i]
+    L.nyq_device_alloc.argtypes = [vp, sz]
+    L.nyq_device_alloc.restype = vp
+    L.nyq_device_free.argtypes = [vp, vp]
+    L.nyq_device_free.restype = None
+    L.nyq_device_zero.argtypes = [vp, vp, sz]
+    L.nyq_device_download.argtypes = [vp, vp, vp, sz]
+    L.nyq_device_dup_channel.argtypes = [vp, vp, i, i, i, sz]
+    L.nyq_celt_frames_to_pcm_mapped.argtypes = [vp, i] + [vp] * 8 + [sz, sz, i, sz]
     L.nyq_device_copy_forms.restype = i
     L.nyq_device_copy_form_name.argtypes = [i]
     L.nyq_device_copy_form_name.restype = C.c_char_p

@@ -68,6 +68,7 @@ struct ChainArgs {
     // freq / transient, and pf_* / out, may be WINDOWS into longer per-stream arrays: consecutive streams are `fstride` /
     // `pstride` frames apart (0 = dense: nframes)
     long fstride, pstride;
+    const OutDesc *desc;             // [nstreams] or null: per-stream destinations in a file's interleaved layout (OutDesc)
     __host__ __device__ long fs() const { return fstride ? fstride : nframes; }
     __host__ __device__ long ps() const { return pstride ? pstride : nframes; }
 };
@@ -134,9 +135,10 @@ __device__ __forceinline__ float lane_value(float v, int l) {   // v of lane l (
 // LDS straight to global memory: lane l of block b owns samples 2 (l + 64 b), + 1 of both channels = float4 l + 64 b of
 // the interleaved frame.  Per block: two-sample recurrence, one weighted scan over the lanes, carry from the block before.
 // Blocks go two at a time (four scans side by side); only the carry (one multiply-add per block and channel) is serial.
+// Dm.base != null: the samples go through the stream's descriptor (ts0 = stream sample index of the frame's first sample)
 template <int N>
 __device__ __forceinline__ void deemph_store_pair(const float *sL, const float *sR, vf4 *d4, float &memL, float &memR,
-                                                  int lane, const DeConst &D, float pwHalf) {
+                                                  int lane, const DeConst &D, float pwHalf, const OutDesc &Dm, long long ts0) {
     constexpr int NV2 = N / 2;                       // float4 of the interleaved frame
     constexpr int NB = (NV2 + kWave - 1) / kWave;    // blocks of 64
     static_assert(NV2 % kWave == 0 || NV2 % kWave == 32, "the last block is whole or half");
@@ -167,7 +169,17 @@ __device__ __forceinline__ void deemph_store_pair(const float *sL, const float *
             const float cL = kPreemph * dpp_shr1(0.f, e[2 * k]) + D.pw * memL, cR = kPreemph * dpp_shr1(0.f, e[2 * k + 1]) + D.pw * memR;
             const vf4 o = {(x0[2 * k] + cL) * (1.f / 32768.f), (x0[2 * k + 1] + cR) * (1.f / 32768.f),
                            (x1[2 * k] + kPreemph * cL) * (1.f / 32768.f), (x1[2 * k + 1] + kPreemph * cR) * (1.f / 32768.f)};
-            if (on[k]) pipe_st(d4 + v, o);
+            if (on[k]) {
+                if (Dm.base) {
+                    const long long ts = ts0 + 2 * v;
+                    mapped_put(Dm, ts, Dm.coff0, o.x);
+                    mapped_put(Dm, ts, Dm.coff1, o.y);
+                    mapped_put(Dm, ts + 1, Dm.coff0, o.z);
+                    mapped_put(Dm, ts + 1, Dm.coff1, o.w);
+                } else {
+                    pipe_st(d4 + v, o);
+                }
+            }
             const bool half = (b0 + k + 1) * kWave > NV2;     // the last block ends at lane 31
             const float pe = half ? pwHalf : D.pwEnd;
             memL = kPreemph * lane_value(e[2 * k], half ? 31 : 63) + pe * memL;
@@ -399,6 +411,7 @@ __global__ __launch_bounds__(kWave *kChainWaves, NYQ_CHAIN_MINWAVES) void celt_c
         deemph_init_lanes<2>(D, pwHalf, lane);
         for (long s = blockIdx.x; s < A.nstreams; s += gridDim.x) {
             const long u0 = 2 * s;
+            const OutDesc Dm = load_desc(A.desc, s);
             float memL = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, A.deemph ? A.deemph[u0] : 0.f)));
             float memR = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, A.deemph ? A.deemph[u0 + 1] : 0.f)));
             int pT = 0, pS = 0;
@@ -450,7 +463,8 @@ __global__ __launch_bounds__(kWave *kChainWaves, NYQ_CHAIN_MINWAVES) void celt_c
                 if (f >= 1 && nfr < 0)
 #endif
                     deemph_store_pair<N>(bufs[0][cb] + R0 - N, bufs[1][cb] + R0 - N,
-                                         reinterpret_cast<vf4 *>(A.out + (s * pst * N + (f - 1) * N) * 2), memL, memR, opaque(lane), D, pwHalf);
+                                         reinterpret_cast<vf4 *>(A.out + (s * pst * N + (f - 1) * N) * 2), memL, memR, opaque(lane), D, pwHalf,
+                                         Dm, Dm.t0 + (f - 1) * (long long)N);
                 if (f == nfr) {
                     // state for the next call: the last 1088 outputs (1040 in cur's history region, the 48 before them in nxt's)
 #pragma unroll

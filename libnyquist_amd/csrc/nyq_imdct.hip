@@ -6,7 +6,9 @@
 // algorithmic 7680 B of SURVEY.md section 8(d); tables (2.4 KB) stay in L2.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -549,7 +551,7 @@ static int launch_post_pipe(nyq_ctx *ctx, const PostArgs &A) {
 
 static int post_core(nyq_ctx *ctx, int LM, const float *d_pcm, const int *d_pf_pitch, const float *d_pf_gain,
                      const int *d_pf_tapset, const float *d_pf_state_in, float *d_pf_state_out, float *d_hist, float *d_deemph,
-                     float *d_out, size_t nstreams, size_t nframes, int channels, size_t pstride) {
+                     float *d_out, size_t nstreams, size_t nframes, int channels, size_t pstride, const OutDesc *d_desc = nullptr) {
     PostArgs A;
     A.pcm = d_pcm;
     A.pf_pitch = d_pf_pitch;
@@ -564,6 +566,7 @@ static int post_core(nyq_ctx *ctx, int LM, const float *d_pcm, const int *d_pf_p
     A.nframes = (long)nframes;
     A.channels = channels;
     A.pstride = (long)pstride;                      // 0: pf_* / out are dense
+    A.desc = d_desc;                                // per-stream destinations in a file's interleaved layout, or null
     // The workgroup pipeline (a chain's wave issues only the recursion) is the product's one form.  The
     // round-1 forms -- one wave per channel, or per stereo pair, doing everything -- exist in the A/B build only and are
     // chosen per context: nyq_ctx_set_option(ctx, NYQ_OPT_POST_FORM, ...).
@@ -627,8 +630,9 @@ static int chain_core(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned 
                       const int *d_pf_pitch, const float *d_pf_gain, const int *d_pf_tapset,
                       const float *d_pf_state_in, float *d_pf_state_out, float *d_overlap, float *d_hist,
                       float *d_deemph, float *d_out, float *d_pcm, float *d_work, size_t nstreams,
-                      size_t nframes, int channels, size_t fstride) {
+                      size_t nframes, int channels, size_t fstride, const OutDesc *d_desc = nullptr) {
     if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_celt_chain_dev: ctx is NULL");
+    if (d_desc && channels > 2) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_chain_mapped_dev: output descriptors serve mono and stereo streams");
     if (LM < 0 || LM > 3) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_chain_dev: LM must be 0..3");
     if (channels < 1 || channels > 255) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_chain_dev: channels must be 1..255");
     if (nstreams == 0 || nframes == 0) return NYQ_OK;
@@ -657,6 +661,7 @@ static int chain_core(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned 
         A.nframes = (long)nframes;
         A.fstride = (long)fstride;
         A.pstride = (long)fstride;
+        A.desc = d_desc;
         if (ctx->res_chain == 0) {
             int per_cu = 0;
             hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, celt_chain_kernel, kWave * kChainWaves, 0);
@@ -673,7 +678,7 @@ static int chain_core(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned 
     // Round 2's fused kernel (A/B build only) is correct (tests/test_gpu_chain.py) and measured 3x SLOWER than the two launches
     // (6.1 ms vs 1.9 ms for 1024 x 256 stereo frames, profiles/r02_*): one IMDCT wave per four chains cannot keep up with
     // the comb waves, and the LDS that would hold more IMDCT slices is what keeps every chain resident.
-    if (ctx->opt_chain_fused == NYQ_CHAIN_FUSED_R2 && nyq_celt_chain_fused_supported(LM, channels) && fstride == 0) {
+    if (ctx->opt_chain_fused == NYQ_CHAIN_FUSED_R2 && nyq_celt_chain_fused_supported(LM, channels) && fstride == 0 && !d_desc) {
         FusedR2Args A;
         A.freq = d_freq;
         A.transient = d_transient;
@@ -716,11 +721,11 @@ static int chain_core(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned 
     size_t W = ctx->opt_chain_window > 0 ? (size_t)ctx->opt_chain_window : default_chain_window(nstreams, nframes, channels, LM);
     const size_t chainlen = LM == 3 ? Geo<32>::CHAIN_FRAMES : LM == 2 ? Geo<16>::CHAIN_FRAMES : LM == 1 ? Geo<8>::CHAIN_FRAMES : Geo<4>::CHAIN_FRAMES;
     W = (W + chainlen - 1) / chainlen * chainlen;   // windows start where the in-wave carry chains start: bit-identical to one window
-    if (W >= nframes || nframes - W < 20 || fstride != 0) {   // (the temporaries below need 20 frames' worth of d_work beyond a window's own)
+    if (W >= nframes || nframes - W < 20 || fstride != 0 || d_desc) {   // (the temporaries below need 20 frames' worth of d_work beyond a window's own)
         int rc = synth_core(ctx, LM, d_freq, d_transient, d_pcm, d_overlap, d_overlap, d_work, nstreams, nframes, channels, fstride);
         if (rc != NYQ_OK) return rc;
         return post_core(ctx, LM, d_pcm, d_pf_pitch, d_pf_gain, d_pf_tapset, d_pf_state_in, d_pf_state_out, d_hist, d_deemph,
-                         d_out, nstreams, nframes, channels, fstride);
+                         d_out, nstreams, nframes, channels, fstride, d_desc);
     }
     // temporaries behind the window's own share of d_work (nsc * (W + 1) * 60 floats of nsc * (nframes + 1) * 60):
     // overlap [nsc][60], hist [nsc][1088], deemph [nsc], post-filter state ping / pong [nstreams][6] -- 1150 floats per
@@ -787,6 +792,67 @@ extern "C" int nyq_celt_chain_dev(nyq_ctx *ctx, int LM, const float *d_freq, con
                                   size_t nframes, int channels) {
     return chain_core(ctx, LM, d_freq, d_transient, d_pf_pitch, d_pf_gain, d_pf_tapset, d_pf_state_in, d_pf_state_out, d_overlap,
                       d_hist, d_deemph, d_out, d_pcm, d_work, nstreams, nframes, channels, 0);
+}
+
+// ---- row f3: the samples straight into the FILE's interleaved layout (opus_multistream_decoder.c:305-331) -------------
+static_assert(sizeof(nyq_out_desc) == sizeof(OutDesc) && offsetof(nyq_out_desc, base) == offsetof(OutDesc, base) &&
+                  offsetof(nyq_out_desc, first) == offsetof(OutDesc, first) && offsetof(nyq_out_desc, last) == offsetof(OutDesc, last) &&
+                  offsetof(nyq_out_desc, t0) == offsetof(OutDesc, t0) && offsetof(nyq_out_desc, cstride) == offsetof(OutDesc, cstride) &&
+                  offsetof(nyq_out_desc, coff) == offsetof(OutDesc, coff0) && offsetof(nyq_out_desc, gain) == offsetof(OutDesc, gain),
+              "nyq_out_desc (C ABI) and nyq::OutDesc (kernels) are one layout");
+
+extern "C" int nyq_celt_chain_mapped_dev(nyq_ctx *ctx, int LM, const float *d_freq, const unsigned char *d_transient,
+                                         const int *d_pf_pitch, const float *d_pf_gain, const int *d_pf_tapset,
+                                         const float *d_pf_state_in, float *d_pf_state_out, float *d_overlap, float *d_hist,
+                                         float *d_deemph, float *d_out, const nyq_out_desc *d_desc, float *d_pcm, float *d_work,
+                                         size_t nstreams, size_t nframes, int channels) {
+    if (ctx && !d_out && !d_desc) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_chain_mapped_dev: neither d_out nor d_desc");
+    // (d_out may be null when every stream has a destination: the kernels never touch it then; chain_core wants a non-null
+    // pointer for its argument check only)
+    float *out = d_out ? d_out : reinterpret_cast<float *>(const_cast<nyq_out_desc *>(d_desc));
+    return chain_core(ctx, LM, d_freq, d_transient, d_pf_pitch, d_pf_gain, d_pf_tapset, d_pf_state_in, d_pf_state_out, d_overlap,
+                      d_hist, d_deemph, out, d_pcm, d_work, nstreams, nframes, channels, 0, reinterpret_cast<const OutDesc *>(d_desc));
+}
+
+extern "C" void *nyq_device_alloc(nyq_ctx *ctx, size_t bytes) {
+    void *p = nullptr;
+    if (!ctx || bytes == 0 || hipSetDevice(ctx->device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    return p;
+}
+extern "C" void nyq_device_free(nyq_ctx *ctx, void *p) {
+    if (ctx && p) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipFree(p);
+    }
+}
+extern "C" int nyq_device_zero(nyq_ctx *ctx, void *d_p, size_t bytes) {
+    if (!ctx || !d_p) return fail(ctx, NYQ_ERR_INVALID, "nyq_device_zero: NULL argument");
+    NYQ_HIP(ctx, hipSetDevice(ctx->device));
+    NYQ_HIP(ctx, hipMemsetAsync(d_p, 0, bytes, ctx->stream));
+    NYQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NYQ_OK;
+}
+extern "C" int nyq_device_download(nyq_ctx *ctx, void *host_dst, const void *d_src, size_t bytes) {
+    if (!ctx || !host_dst || !d_src) return fail(ctx, NYQ_ERR_INVALID, "nyq_device_download: NULL argument");
+    NYQ_HIP(ctx, hipSetDevice(ctx->device));
+    NYQ_HIP(ctx, hipMemcpyAsync(host_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    NYQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NYQ_OK;
+}
+// one destination channel repeated in another (a channel mapping may name one decoded channel twice)
+__global__ void dup_channel_kernel(float *base, int cstride, int src, int dst, long n) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) base[t * cstride + dst] = base[t * cstride + src];
+}
+extern "C" int nyq_device_dup_channel(nyq_ctx *ctx, float *d_base, int cstride, int src_slot, int dst_slot, size_t nsamples) {
+    if (!ctx || !d_base || cstride < 1 || src_slot < 0 || dst_slot < 0 || src_slot >= cstride || dst_slot >= cstride)
+        return fail(ctx, NYQ_ERR_INVALID, "nyq_device_dup_channel: bad argument");
+    if (nsamples == 0 || src_slot == dst_slot) return NYQ_OK;
+    NYQ_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(dup_channel_kernel, dim3((unsigned)std::min<size_t>((nsamples + 255) / 256, 4096)), dim3(256), 0, ctx->stream, d_base,
+                       cstride, src_slot, dst_slot, (long)nsamples);
+    NYQ_HIP(ctx, hipGetLastError());
+    NYQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NYQ_OK;
 }
 
 // ---- Vorbis inverse MDCT ---------------------------------------------------------------------
@@ -1055,15 +1121,21 @@ static hipError_t copy_rows(void *dst, size_t dpitch, const void *src, size_t sp
     return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, kind, st);
 }
 
+// desc: per-stream destinations (HOST array of nstreams records whose `base` are DEVICE pointers) or null.  A stream with a
+// destination is written there by the kernels and is not downloaded; when EVERY stream has one, `out` may be null.
 static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const unsigned char *transient,
                               const int *pf_pitch, const float *pf_gain, const int *pf_tapset, float *out,
-                              float *state, size_t nstreams, size_t nframes, int channels, size_t hstride) {
+                              float *state, size_t nstreams, size_t nframes, int channels, size_t hstride,
+                              const nyq_out_desc *desc = nullptr) {
     if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm: ctx is NULL");
     if (LM < 0 || LM > 3) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm: LM must be 0..3");
     if (channels < 1 || channels > 255) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm: channels must be 1..255");
     if (nstreams == 0 || nframes == 0) return NYQ_OK;
-    if (!freq || !pf_pitch || !pf_gain || !pf_tapset || !out)
+    bool all_mapped = desc != nullptr;
+    for (size_t k = 0; desc && k < nstreams; k++) all_mapped = all_mapped && desc[k].base != nullptr;
+    if (!freq || !pf_pitch || !pf_gain || !pf_tapset || (!out && !all_mapped))
         return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm: NULL buffer");
+    if (desc && channels > 2) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm_mapped: output descriptors serve mono and stereo streams");
     NYQ_HIP(ctx, hipSetDevice(ctx->device));
     const size_t N = (size_t)120 << LM, nsc = nstreams * (size_t)channels, nfr = nstreams * nframes;
     const size_t n_x = round16f(nsc * nframes * N), n_w = round16f(nyq_celt_synth_work_floats(nstreams, nframes, channels)),
@@ -1071,13 +1143,15 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
     // state on the device: overlap, hist, deemph, pf in, pf out (each 16-byte aligned)
     const size_t n_ov = round16f(nsc * NYQ_HALF_OV), n_hi = round16f(nsc * kPostHist), n_de = round16f(nsc),
                  n_pf = round16f(nstreams * 6);
-    int rc = need_scratch(ctx, (3 * n_x + n_w + 3 * n_p + n_t + n_ov + n_hi + n_de + 2 * n_pf) * sizeof(float));
+    const size_t n_ds = desc ? round16f(nstreams * sizeof(nyq_out_desc) / sizeof(float)) : 0;
+    int rc = need_scratch(ctx, (3 * n_x + n_w + 3 * n_p + n_t + n_ov + n_hi + n_de + 2 * n_pf + n_ds) * sizeof(float));
     if (rc != NYQ_OK) return rc;
     float *d_x = ctx->d_scratch, *d_pcm = d_x + n_x, *d_out = d_pcm + n_x, *d_w = d_out + n_x, *d_pg = d_w + n_w;
     int *d_pp = reinterpret_cast<int *>(d_pg + n_p), *d_pt = d_pp + n_p;
     unsigned char *d_t = reinterpret_cast<unsigned char *>(d_pt + n_p);
     float *d_ov = reinterpret_cast<float *>(d_pt + n_p) + n_t, *d_hi = d_ov + n_ov, *d_de = d_hi + n_hi,
           *d_pfi = d_de + n_de, *d_pfo = d_pfi + n_pf;
+    nyq_out_desc *d_ds = desc ? reinterpret_cast<nyq_out_desc *>(d_pfo + n_pf) : nullptr;
     float *h_ov = state, *h_hi = state ? h_ov + nsc * NYQ_HALF_OV : nullptr, *h_de = state ? h_hi + nsc * kPostHist : nullptr,
           *h_pf = state ? h_de + nsc : nullptr;
     // pieces of whole streams: upload of piece k+1, kernels of piece k, download of piece k-1 at the same time
@@ -1117,6 +1191,7 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
         NYQ_HIP(ctx, copy_rows(d_pg + fo, nframes * 4, pf_gain + hf, hstride * 4, nframes * 4, cnt, hipMemcpyHostToDevice, hs));
         NYQ_HIP(ctx, copy_rows(d_pp + fo, nframes * 4, pf_pitch + hf, hstride * 4, nframes * 4, cnt, hipMemcpyHostToDevice, hs));
         NYQ_HIP(ctx, copy_rows(d_pt + fo, nframes * 4, pf_tapset + hf, hstride * 4, nframes * 4, cnt, hipMemcpyHostToDevice, hs));
+        if (desc) NYQ_HIP(ctx, hipMemcpyAsync(d_ds + s0, desc + s0, cnt * sizeof(nyq_out_desc), hipMemcpyHostToDevice, hs));
         if (state) {
             NYQ_HIP(ctx, hipMemcpyAsync(d_ov + co * NYQ_HALF_OV, h_ov + co * NYQ_HALF_OV, cn * NYQ_HALF_OV * sizeof(float), hipMemcpyHostToDevice, hs));
             NYQ_HIP(ctx, hipMemcpyAsync(d_hi + co * kPostHist, h_hi + co * kPostHist, cn * kPostHist * sizeof(float), hipMemcpyHostToDevice, hs));
@@ -1126,10 +1201,11 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
         NYQ_HIP(ctx, hipEventRecord(up, hs));
         NYQ_HIP(ctx, hipStreamWaitEvent(ctx->stream, up, 0));
         // (one launch for 20 ms stereo frames, synthesis + post-filter through d_pcm otherwise)
-        rc = nyq_celt_chain_dev(ctx, LM, d_x + xo, transient ? d_t + fo : nullptr, d_pp + fo, d_pg + fo, d_pt + fo,
-                                state ? d_pfi + s0 * 6 : nullptr, state ? d_pfo + s0 * 6 : nullptr,
-                                state ? d_ov + co * NYQ_HALF_OV : nullptr, state ? d_hi + co * kPostHist : nullptr,
-                                state ? d_de + co : nullptr, d_out + xo, d_pcm + xo, d_w + s0 * work_per_stream, cnt, nframes, channels);
+        rc = chain_core(ctx, LM, d_x + xo, transient ? d_t + fo : nullptr, d_pp + fo, d_pg + fo, d_pt + fo,
+                        state ? d_pfi + s0 * 6 : nullptr, state ? d_pfo + s0 * 6 : nullptr,
+                        state ? d_ov + co * NYQ_HALF_OV : nullptr, state ? d_hi + co * kPostHist : nullptr,
+                        state ? d_de + co : nullptr, d_out + xo, d_pcm + xo, d_w + s0 * work_per_stream, cnt, nframes, channels, 0,
+                        reinterpret_cast<const OutDesc *>(desc ? d_ds + s0 : nullptr));
         if (rc != NYQ_OK) {
             (void)hipStreamSynchronize(hs);
             (void)hipStreamSynchronize(ctx->stream);
@@ -1138,7 +1214,7 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
         }
         NYQ_HIP(ctx, hipEventRecord(done, ctx->stream));
         NYQ_HIP(ctx, hipStreamWaitEvent(ds, done, 0));
-        NYQ_HIP(ctx, copy_rows(out + hx, xp, d_out + xo, xw, xw, cnt, hipMemcpyDeviceToHost, ds));
+        if (!all_mapped) NYQ_HIP(ctx, copy_rows(out + hx, xp, d_out + xo, xw, xw, cnt, hipMemcpyDeviceToHost, ds));
         if (state) {
             NYQ_HIP(ctx, hipMemcpyAsync(h_ov + co * NYQ_HALF_OV, d_ov + co * NYQ_HALF_OV, cn * NYQ_HALF_OV * sizeof(float), hipMemcpyDeviceToHost, ds));
             NYQ_HIP(ctx, hipMemcpyAsync(h_hi + co * kPostHist, d_hi + co * kPostHist, cn * kPostHist * sizeof(float), hipMemcpyDeviceToHost, ds));
@@ -1155,6 +1231,16 @@ extern "C" int nyq_celt_frames_to_pcm(nyq_ctx *ctx, int LM, const float *freq, c
                                       const int *pf_pitch, const float *pf_gain, const int *pf_tapset, float *out,
                                       float *state, size_t nstreams, size_t nframes, int channels) {
     return frames_to_pcm_core(ctx, LM, freq, transient, pf_pitch, pf_gain, pf_tapset, out, state, nstreams, nframes, channels, nframes);
+}
+
+extern "C" int nyq_celt_frames_to_pcm_mapped(nyq_ctx *ctx, int LM, const float *freq, const unsigned char *transient,
+                                             const int *pf_pitch, const float *pf_gain, const int *pf_tapset, float *out,
+                                             const nyq_out_desc *desc, float *state, size_t nstreams, size_t nframes, int channels,
+                                             size_t frames_per_stream) {
+    if (ctx && frames_per_stream < nframes)
+        return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm_mapped: frames_per_stream is smaller than nframes");
+    return frames_to_pcm_core(ctx, LM, freq, transient, pf_pitch, pf_gain, pf_tapset, out, state, nstreams, nframes, channels,
+                              frames_per_stream, desc);
 }
 
 extern "C" int nyq_celt_frames_to_pcm_window(nyq_ctx *ctx, int LM, const float *freq, const unsigned char *transient,

@@ -15,6 +15,33 @@ constexpr int kCombMinPeriod = 15;      // celt.h:188
 constexpr int kCombMaxPeriod = 1024;    // celt.h:187 (keeps every tap inside the buffer whatever the caller passes)
 constexpr float kPreemph = 0.85000610f; // mode->preemph[0], static_modes_float.h:581
 
+// Where an elementary stream's samples go when they do not go to the dense [stream][sample][channel] output: straight into
+// the interleaved layout of the FILE the stream belongs to (row f3 of SURVEY.md section 8: opus_copy_channel_out_float,
+// opus_multistream_decoder.c:305-331, with the pre-skip / end trim of opusfile and the header gain of
+// opus_decoder_clean.c:700-712 applied on the way).  Same layout as nyq_out_desc of include/nyq_imdct.h.
+struct OutDesc {
+    float *base;             // device memory: stream sample `first` of destination channel slot 0
+    long long first, last;   // stream samples [first, last) are written, the rest is dropped (trimmed)
+    long long t0;            // stream sample index of the call's first sample
+    int cstride;             // floats from one sample to the next in the destination (the file's channel count)
+    int coff0, coff1;        // destination slot of the stream's channel 0 / 1; -1 = not written
+    float gain;              // multiplied in (1 = none)
+};
+__device__ __forceinline__ void mapped_put(const OutDesc &D, long long ts, int coff, float v) {
+    if (coff >= 0 && ts >= D.first && ts < D.last) D.base[(ts - D.first) * D.cstride + coff] = v * D.gain;
+}
+// the descriptor of stream s into wave-uniform registers (base == null: this stream goes to the dense output)
+__device__ __forceinline__ OutDesc load_desc(const OutDesc *desc, long s) {
+    OutDesc D;
+    D.base = nullptr;
+    D.first = D.last = D.t0 = 0;
+    D.cstride = 0;
+    D.coff0 = D.coff1 = -1;
+    D.gain = 1.f;
+    if (desc) D = desc[s];
+    return D;
+}
+
 struct PostArgs {
     const float *pcm;        // [nstreams*channels][nframes*N]  IMDCT output (read only)
     const int *pf_pitch;     // [nstreams][nframes]
@@ -30,6 +57,7 @@ struct PostArgs {
     // pf_* and out may be WINDOWS into longer per-stream arrays: consecutive streams are `pstride` frames apart
     // (0 = dense: nframes).  pcm and the states are always dense.
     long pstride;
+    const OutDesc *desc;     // [nstreams] or null: per-stream destinations (channels <= 2), see OutDesc
     __host__ __device__ long ps() const { return pstride ? pstride : nframes; }
 };
 

@@ -660,6 +660,9 @@ __global__ __launch_bounds__(kWave *kPipeWaves, NYQ_PIPE_MINWAVES) void celt_pos
             int cU[kPipeUnits];
             const vf4 *src[kPipeUnits];
             float mem[kPipeUnits];
+            // mapped output (row f3): the descriptor of each unit's stream (PAIR: one stream); null base = dense output
+            const OutDesc D0 = load_desc(A.desc, (PAIR || u0 < nunits) ? u0 / A.channels : 0);
+            const OutDesc D1 = PAIR ? D0 : load_desc(A.desc, u0 + 1 < nunits ? (u0 + 1) / A.channels : 0);
             // the prefetched frame (+ its parameters): frame f+1 lands from these registers in iteration f, right after
             // that frame f+2 is fetched into them -- the loads have a whole frame time to arrive, and the wait for them
             // sits in front of this iteration's stores (vmcnt counts loads and stores in issue order)
@@ -818,7 +821,20 @@ __global__ __launch_bounds__(kWave *kPipeWaves, NYQ_PIPE_MINWAVES) void celt_pos
                     if (f + 1 < nfr) land(f + 1, nb, QH * h, QH * (h + 1));   // (waits for the prefetched loads)
                     if (f >= 1) {
                         const long t0 = (f - 1) * N;           // first sample of the frame
-                        if (pairOut) {
+                        if (pairOut && D0.base) {
+                            // into the file's interleaved layout: float4 v = samples 2v, 2v+1 of both channels
+#pragma unroll
+                            for (int q = 0; q < 2 * QH; q++) {
+                                const int v = lh + (2 * QH * h + q) * kWave;
+                                if (v < 2 * NV) {
+                                    const long long ts = D0.t0 + t0 + 2 * v;
+                                    mapped_put(D0, ts, D0.coff0, sv[q].x);
+                                    mapped_put(D0, ts, D0.coff1, sv[q].y);
+                                    mapped_put(D0, ts + 1, D0.coff0, sv[q].z);
+                                    mapped_put(D0, ts + 1, D0.coff1, sv[q].w);
+                                }
+                            }
+                        } else if (pairOut) {
                             vf4 *d4 = reinterpret_cast<vf4 *>(A.out + (sU[0] * pst * N + t0) * 2);
 #pragma unroll
                             for (int q = 0; q < 2 * QH; q++) {
@@ -829,11 +845,22 @@ __global__ __launch_bounds__(kWave *kPipeWaves, NYQ_PIPE_MINWAVES) void celt_pos
 #pragma unroll
                             for (int k = 0; k < kPipeUnits; k++) {
                                 if (!live[k]) continue;
+                                const OutDesc &Dk = k ? D1 : D0;
                                 vf4 *d4 = reinterpret_cast<vf4 *>(A.out + sU[k] * pst * N + t0);
 #pragma unroll
                                 for (int q = 0; q < QH; q++) {
                                     const int v = lh + (QH * h + q) * kWave;
-                                    if (v < NV) pipe_st(d4 + v, sv[k * QH + q]);
+                                    if (v >= NV) continue;
+                                    const vf4 w = sv[k * QH + q];
+                                    if (Dk.base) {
+                                        const long long ts = Dk.t0 + t0 + 4 * v;
+                                        mapped_put(Dk, ts, Dk.coff0, w.x);
+                                        mapped_put(Dk, ts + 1, Dk.coff0, w.y);
+                                        mapped_put(Dk, ts + 2, Dk.coff0, w.z);
+                                        mapped_put(Dk, ts + 3, Dk.coff0, w.w);
+                                    } else {
+                                        pipe_st(d4 + v, w);
+                                    }
                                 }
                             }
                         }

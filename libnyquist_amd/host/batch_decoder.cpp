@@ -171,6 +171,7 @@ void entropyDecode(FileJob &job, OnSlice &&onSlice) {
 
 // streams of one shape (channels, frame size of the first segment), padded to the longest
 struct Group {
+    bool mapped = false;                // its streams write through output records into their files' device buffers
     int ch = 0, LM = 0, dev = 0;        // dev: index into the decoder's device list
     size_t N = 0, ns = 0, maxF = 0;
     std::vector<size_t> ids;            // flattened stream indices, slot order
@@ -301,18 +302,20 @@ class SubBatch {
 public:
     // ctxs: ndev * feedersPerDev contexts, device d's at [d * feedersPerDev, ...); arena(dev, bytes) = that device's staging memory
     SubBatch(std::vector<FileJob> &jobs, std::vector<DecodedStream> &out, const std::vector<size_t> &members, void *const *ctxs,
-             int ndev, int feedersPerDev, int threads, const std::function<void *(int, size_t)> &arena)
+             int ndev, int feedersPerDev, int threads, const std::function<void *(int, size_t)> &arena,
+             const std::function<void *(int, size_t)> &devArena)
         : jobs_(jobs), out_(out), members_(members), ctxs_(ctxs), ndev_(ndev), feedersPerDev_(feedersPerDev),
-          nfeeders_(ndev * feedersPerDev), threads_(threads), arena_(arena), firstSub_(jobs.size(), 0), finished_(jobs.size(), 0),
-          streamed_(jobs.size(), 0), window_(jobs.size()), subsLeft_(jobs.size()), ready_((size_t)ndev),
-          gpuBusy_((size_t)(ndev * feedersPerDev), 0.0) {}
+          nfeeders_(ndev * feedersPerDev), threads_(threads), arena_(arena), devArena_(devArena), firstSub_(jobs.size(), 0),
+          finished_(jobs.size(), 0), streamed_(jobs.size(), 0), window_(jobs.size()), subsLeft_(jobs.size()), fileDev_(jobs.size(), 0),
+          devOut_(jobs.size(), nullptr), ready_((size_t)ndev), gpuBusy_((size_t)(ndev * feedersPerDev), 0.0) {}
 
     // returns when every file of the sub-batch is decoded (or has its error set); throws if the GPU failed
     void run() {
         const auto tb = std::chrono::steady_clock::now();
         flatten();
-        layout();
         planOutput();
+        layout();
+        placeOutput();
         std::chrono::steady_clock::time_point t1;
         {
             // The feeders are joined whichever way this block is left.  If anything throws in here (a feeder that cannot
@@ -353,7 +356,8 @@ public:
         // the file in a piece that ended after the file's other streams)
         parallelFor(members_.size(), threads_, [&](size_t mi) {
             const size_t i = members_[mi];
-            if (jobs_[i].error.empty() && !finished_[i]) finishFile(i);
+            // (the feeders are gone: context k of the file's device, by worker index, under that context's mutex)
+            if (jobs_[i].error.empty() && !finished_[i]) finishFile(i, fileDev_[i] * feedersPerDev_ + (int)(mi % (size_t)feedersPerDev_));
         });
         cpuSeconds = std::chrono::duration<double>(t1 - tb).count();
         tailSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
@@ -389,11 +393,14 @@ private:
         const size_t n = sfp_.size();
         // Elementary stream number s of a (channels, frame size) class goes to device s mod G:
         // a group -- one set of staging buffers, one shape of GPU calls -- belongs to ONE device.
+        // The streams of a file whose samples are mapped on the device (several streams, a permuted mapping, a header gain)
+        // all go to ONE device -- the file's interleaved buffer lives there -- and form groups of their own.
         std::map<std::pair<int, int>, size_t> seenOfClass;
-        std::map<std::tuple<int, int, int>, size_t> groupOf;
+        std::map<std::tuple<int, int, int, int>, size_t> groupOf;
         for (size_t i = 0; i < n; i++) {
-            const int dev = (int)(seenOfClass[{sf(i).channels, sf(i).plan[0].LM}]++ % (size_t)ndev_);
-            const std::tuple<int, int, int> key{sf(i).channels, sf(i).plan[0].LM, dev};
+            const bool mapped = !streamed_[fileOf_[i]];
+            const int dev = mapped ? fileDev_[fileOf_[i]] : (int)(seenOfClass[{sf(i).channels, sf(i).plan[0].LM}]++ % (size_t)ndev_);
+            const std::tuple<int, int, int, int> key{sf(i).channels, sf(i).plan[0].LM, dev, mapped ? 1 : 0};
             auto it = groupOf.find(key);
             if (it == groupOf.end()) {
                 it = groupOf.emplace(key, groups_.size()).first;
@@ -402,6 +409,7 @@ private:
                 groups_.back().LM = std::get<1>(key);
                 groups_.back().N = (size_t)120 << std::get<1>(key);
                 groups_.back().dev = dev;
+                groups_.back().mapped = mapped;
             }
             Group &g = groups_[it->second];
             sf(i).group = it->second;
@@ -413,7 +421,7 @@ private:
         for (Group &g : groups_) {
             g.ns = g.ids.size();
             const size_t x = g.ns * g.maxF * g.ch * g.N * sizeof(float), q = g.ns * g.maxF;
-            bytes[(size_t)g.dev] += 2 * align256(x) + 3 * align256(q * 4) + align256(q);
+            bytes[(size_t)g.dev] += (g.mapped ? 1 : 2) * align256(x) + 3 * align256(q * 4) + align256(q);   // (mapped: no dense output)
         }
         std::vector<char *> bases((size_t)ndev_, nullptr);
         for (int d = 0; d < ndev_; d++)
@@ -423,7 +431,8 @@ private:
             char *&base = bases[(size_t)g.dev];
             const size_t x = g.ns * g.maxF * g.ch * g.N * sizeof(float), q = g.ns * g.maxF;
             g.freq = (float *)base; base += align256(x);
-            g.out = (float *)base; base += align256(x);
+            g.out = nullptr;
+            if (!g.mapped) { g.out = (float *)base; base += align256(x); }
             g.pg = (float *)base; base += align256(q * 4);
             g.pp = (int *)base; base += align256(q * 4);
             g.pt = (int *)base; base += align256(q * 4);
@@ -487,7 +496,60 @@ private:
             window_[i] = {head.preSkip, head.preSkip + total};
             streamed_[i] = ch <= 2 && job.subs.size() == 1 && job.subs[0].channels == ch && head.outputGainQ8 == 0 &&
                            head.mapping[0] == 0 && (ch == 1 || head.mapping[1] == 1);
+            if (!streamed_[i]) fileDev_[i] = (int)(nmapped_++ % (size_t)ndev_);
         }
+    }
+
+    // Device memory for the interleaved output of every mapped file (opus_multistream_decoder.c:305-331 on the device): one
+    // region per device, the files of that device side by side; zeroed when a file has silent channels (mapping 255)
+    void placeOutput() {
+        std::vector<size_t> bytes((size_t)ndev_, 0);
+        for (size_t i : members_) {
+            if (!jobs_[i].error.empty() || streamed_[i]) continue;
+            const size_t b = align256((size_t)(window_[i].second - window_[i].first) * (size_t)jobs_[i].f.head.channels * sizeof(float)) + 256;
+            bytes[(size_t)fileDev_[i]] += b;
+        }
+        std::vector<char *> base((size_t)ndev_, nullptr);
+        for (int d = 0; d < ndev_; d++)
+            if (bytes[(size_t)d]) base[(size_t)d] = (char *)devArena_(d, bytes[(size_t)d]);
+        for (size_t i : members_) {
+            if (!jobs_[i].error.empty() || streamed_[i]) continue;
+            const OpusHead &head = jobs_[i].f.head;
+            const size_t b = align256((size_t)(window_[i].second - window_[i].first) * (size_t)head.channels * sizeof(float)) + 256;
+            devOut_[i] = (float *)base[(size_t)fileDev_[i]];
+            base[(size_t)fileDev_[i]] += b;
+            bool silent = false;
+            for (int c = 0; c < head.channels; c++) silent = silent || head.mapping[c] == 255;
+            if (silent && nyq_device_zero((nyq_ctx *)ctxs_[(size_t)fileDev_[i] * (size_t)feedersPerDev_], devOut_[i], b) != NYQ_OK)
+                throw std::runtime_error("libnyq_imdct: cannot clear a file's output buffer");
+        }
+    }
+
+    // The output record of elementary stream `flat` for a call whose first sample is stream sample t0: which of the file's
+    // channel slots its one or two channels go to (the FIRST output channel that names them; further ones are copied on the
+    // device when the file is finished), the file's sample window and the header gain.
+    nyq_out_desc recordOf(size_t flat, int64_t t0) const {
+        const size_t i = fileOf_[flat];
+        const OpusHead &head = jobs_[i].f.head;
+        const int sub = (int)(flat - firstSub_[i]);
+        nyq_out_desc d;
+        d.base = devOut_[i];
+        d.first = window_[i].first;
+        d.last = window_[i].second;
+        d.t0 = t0;
+        d.cstride = head.channels;
+        d.coff[0] = d.coff[1] = -1;
+        d.gain = head.outputGainQ8 == 0 ? 1.f   // OPUS_SET_GAIN, opus_decoder_clean.c:700-712
+                                        : (float)std::exp(0.6931471805599453094 * (6.48814081e-4 * head.outputGainQ8));
+        for (int c = head.channels - 1; c >= 0; c--) {           // (descending: the lowest output channel wins)
+            const int idx = head.mapping[c];
+            if (idx == 255) continue;
+            int s2, sc;
+            if (idx < 2 * head.coupledCount) { s2 = idx / 2; sc = idx & 1; }
+            else { s2 = idx - head.coupledCount; sc = 0; }
+            if (s2 == sub) d.coff[sc] = c;
+        }
+        return d;
     }
 
     // pass 1 for one file (a decoding thread)
@@ -555,10 +617,20 @@ private:
             bool released = false, ok = false;
             const auto c0 = std::chrono::steady_clock::now();
             try {
-                if (nyq_celt_frames_to_pcm_window(ctx, g.LM, g.freq + so * g.ch * g.N, g.tr + so, g.pp + so, g.pg + so, g.pt + so,
-                                                  g.out + so * g.ch * g.N, p.state.empty() ? nullptr : p.state.data(), p.k1 - p.k0, len,
-                                                  g.ch, g.maxF) != NYQ_OK)
-                    throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(ctx));
+                int rc;
+                if (g.mapped) {
+                    // every stream of the piece writes its samples of this slice straight into its file's interleaved
+                    // device buffer: channel slot, pre-skip / end trim and header gain are in the record
+                    std::vector<nyq_out_desc> desc(p.k1 - p.k0);
+                    for (size_t k = p.k0; k < p.k1; k++) desc[k - p.k0] = recordOf(g.ids[k], (int64_t)(f0 * g.N));
+                    rc = nyq_celt_frames_to_pcm_mapped(ctx, g.LM, g.freq + so * g.ch * g.N, g.tr + so, g.pp + so, g.pg + so, g.pt + so, nullptr,
+                                                       desc.data(), p.state.empty() ? nullptr : p.state.data(), p.k1 - p.k0, len, g.ch, g.maxF);
+                } else {
+                    rc = nyq_celt_frames_to_pcm_window(ctx, g.LM, g.freq + so * g.ch * g.N, g.tr + so, g.pp + so, g.pg + so, g.pt + so,
+                                                       g.out + so * g.ch * g.N, p.state.empty() ? nullptr : p.state.data(), p.k1 - p.k0, len,
+                                                       g.ch, g.maxF);
+                }
+                if (rc != NYQ_OK) throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(ctx));
                 // the GPU part of the slice is done: the piece's next slice may start (its kernels only need the
                 // state, which is back on the host) while this thread copies samples out
                 if (!last) {
@@ -601,7 +673,7 @@ private:
                 }
                 finishFiles = last && ok && gpuError_.empty();   // (after a GPU failure run() throws: no file is finished)
             }
-            if (finishFiles) finishFilesOf(p);
+            if (finishFiles) finishFilesOf(p, which);
             std::lock_guard<std::mutex> lk(mu_);
             if (!released) {
                 p.nextSlice++;
@@ -618,6 +690,7 @@ private:
     // hand the slice's samples to the files that take them verbatim (slices of a piece arrive here in order)
     void handOver(const Piece &p, size_t f0, size_t len) {
         const Group &g = groups_[p.group];
+        if (g.mapped) return;                                   // (its samples are in the files' device buffers)
         for (size_t k = p.k0; k < p.k1; k++) {
             const size_t i = fileOf_[g.ids[k]];
             if (!streamed_[i]) continue;
@@ -656,7 +729,7 @@ private:
 
     // pass 3 right away for every file all of whose streams are through (and that has no later segment): what is left
     // of it overlaps the entropy stage of the files still being decoded
-    void finishFilesOf(const Piece &p) {
+    void finishFilesOf(const Piece &p, int which) {
         const Group &g = groups_[p.group];
         for (size_t k = p.k0; k < p.k1; k++) {
             const size_t i = fileOf_[g.ids[k]];
@@ -665,7 +738,7 @@ private:
             for (const auto &sub : jobs_[i].subs) simple = simple && sub.plan.size() == 1;
             if (!simple) continue;
             try {
-                finishFile(i);
+                finishFile(i, which);
             } catch (const std::exception &e) {
                 std::lock_guard<std::mutex> lk(mu_);
                 if (gpuError_.empty()) gpuError_ = e.what();
@@ -682,19 +755,22 @@ private:
         for (size_t r = 1;; r++) {
             // (device, channels, frame size, frame count): a stream's later segments run on the device that holds its
             // group -- no stream's data ever visits another device
-            std::map<std::tuple<int, int, int, long>, std::vector<size_t>> shapes;
+            std::map<std::tuple<int, int, int, long, int>, std::vector<size_t>> shapes;
             for (size_t i = 0; i < n; i++)
                 if (sf(i).later.size() >= r && !stateOf_[i].empty())   // (no state: the file failed in pass 1)
-                    shapes[std::make_tuple(groups_[sf(i).group].dev, sf(i).channels, sf(i).later[r - 1].LM, sf(i).later[r - 1].nframes)]
+                    shapes[std::make_tuple(groups_[sf(i).group].dev, sf(i).channels, sf(i).later[r - 1].LM, sf(i).later[r - 1].nframes,
+                                           groups_[sf(i).group].mapped ? 1 : 0)]
                         .push_back(i);
             if (shapes.empty()) break;
             for (const auto &kv : shapes) {
                 nyq_ctx *ctx = (nyq_ctx *)ctxs_[(size_t)std::get<0>(kv.first) * (size_t)feedersPerDev_];
                 const int ch = std::get<1>(kv.first), LM = std::get<2>(kv.first);
                 const size_t nf = (size_t)std::get<3>(kv.first), N = (size_t)120 << LM;
+                const bool mapped = std::get<4>(kv.first) != 0;
                 const std::vector<size_t> &ids = kv.second;
                 const size_t ns = ids.size(), per = nf * ch * N;
-                std::vector<float> freq(ns * per), pcm(ns * per), pg(ns * nf), state(nyq_celt_state_floats(ns, ch));
+                std::vector<float> freq(ns * per), pcm(mapped ? 0 : ns * per), pg(ns * nf), state(nyq_celt_state_floats(ns, ch));
+                std::vector<nyq_out_desc> desc(mapped ? ns : 0);
                 std::vector<int> pp(ns * nf), pt(ns * nf);
                 std::vector<uint8_t> tr(ns * nf);
                 for (size_t k = 0; k < ns; k++) {
@@ -705,13 +781,21 @@ private:
                     std::memcpy(&pt[k * nf], sg.pfTapset.data(), nf * sizeof(int));
                     std::memcpy(&pg[k * nf], sg.pfGain.data(), nf * sizeof(float));
                     stateIntoBatch(state.data(), ns, ch, k, stateOf_[ids[k]].data());
+                    if (mapped) {                                   // samples decoded before this segment: where it starts in the stream
+                        const StreamFrames &st = sf(ids[k]);
+                        int64_t t0 = (int64_t)st.plan[0].nframes * (int64_t)((size_t)120 << st.plan[0].LM);
+                        for (size_t q = 0; q + 1 < r; q++) t0 += (int64_t)st.later[q].nframes * (int64_t)((size_t)120 << st.later[q].LM);
+                        desc[k] = recordOf(ids[k], t0);
+                    }
                 }
-                if (nyq_celt_frames_to_pcm(ctx, LM, freq.data(), tr.data(), pp.data(), pg.data(), pt.data(), pcm.data(), state.data(),
-                                           ns, nf, ch) != NYQ_OK)
-                    throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(ctx));
+                const int rc = mapped ? nyq_celt_frames_to_pcm_mapped(ctx, LM, freq.data(), tr.data(), pp.data(), pg.data(), pt.data(), nullptr,
+                                                                     desc.data(), state.data(), ns, nf, ch, nf)
+                                      : nyq_celt_frames_to_pcm(ctx, LM, freq.data(), tr.data(), pp.data(), pg.data(), pt.data(), pcm.data(),
+                                                               state.data(), ns, nf, ch);
+                if (rc != NYQ_OK) throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(ctx));
                 for (size_t k = 0; k < ns; k++) {
                     const size_t i = ids[k];
-                    laterPcm_[i].insert(laterPcm_[i].end(), &pcm[k * per], &pcm[k * per] + per);
+                    if (!mapped) laterPcm_[i].insert(laterPcm_[i].end(), &pcm[k * per], &pcm[k * per] + per);
                     stateOfStream(state.data(), ns, ch, k, stateOf_[i].data());
                     frames += (long)nf;
                 }
@@ -719,9 +803,13 @@ private:
         }
     }
 
-    // pass 3 for one file: channel mapping (opus_multistream_decoder.c:305-331), then trimming (opusfile: skip
-    // pre_skip samples, stop at the last page's granule position) and the header gain
-    void finishFile(size_t i) {
+    // pass 3 for one file.  A file that is one identity-mapped stream at unit gain has received its first segment slice by
+    // slice (handOver); what its later segments add is appended here, a contiguous range.  Every other file -- several
+    // elementary streams, a permuted or partly silent mapping, a header gain -- was written by the kernels themselves into
+    // its interleaved layout in device memory (channel mapping opus_multistream_decoder.c:305-331, pre-skip / end trim,
+    // OPUS_SET_GAIN opus_decoder_clean.c:700-712: recordOf): output channels that repeat a decoded channel are copied on
+    // the device, then ONE download.  No per-sample work on the host.
+    void finishFile(size_t i, int which) {
         finished_[i] = 1;
         const FileJob &job = jobs_[i];
         const OpusHead &head = job.f.head;
@@ -745,31 +833,20 @@ private:
             return;
         }
         d.pcm.resize((size_t)total * ch);
-        const float gain = head.outputGainQ8 == 0 ? 1.f   // OPUS_SET_GAIN, opus_decoder_clean.c:700-712
-                                                   : (float)std::exp(0.6931471805599453094 * (6.48814081e-4 * head.outputGainQ8));
+        if (total == 0) return;
+        nyq_ctx *ctx = (nyq_ctx *)ctxs_[(size_t)which];
+        std::lock_guard<std::mutex> lk(ctxMu_[(size_t)which]);
+        // an output channel that names a decoded channel another (lower) output channel already carries
+        std::vector<int> firstOf(256, -1);
         for (int c = 0; c < ch; c++) {
             const int idx = head.mapping[c];
-            float *dst = d.pcm.data() + c;
-            if (idx == 255) {                              // silent channel
-                for (int64_t t = 0; t < total; t++) dst[t * ch] = 0.f;
-                continue;
-            }
-            int sub, sc;
-            if (idx < 2 * head.coupledCount) { sub = idx / 2; sc = idx & 1; }
-            else { sub = idx - head.coupledCount; sc = 0; }
-            const size_t flat = firstSub_[i] + (size_t)sub;
-            const StreamFrames &s = sf(flat);
-            const Group &g = groups_[s.group];
-            const int sch = s.channels;
-            // samples [0, n0) come from the group output, the rest from the later segments
-            const int64_t n0 = (int64_t)s.plan[0].nframes * (int64_t)g.N;
-            const float *src0 = g.out + s.slot * g.maxF * g.N * sch;
-            const float *src1 = laterPcm_[flat].data();
-            for (int64_t t = a; t < b; t++) {
-                const float v = t < n0 ? src0[t * sch + sc] : src1[(t - n0) * sch + sc];
-                dst[(t - a) * ch] = gain == 1.f ? v : v * gain;
-            }
+            if (idx == 255) continue;
+            if (firstOf[(size_t)idx] < 0) firstOf[(size_t)idx] = c;
+            else if (nyq_device_dup_channel(ctx, devOut_[i], ch, firstOf[(size_t)idx], c, (size_t)total) != NYQ_OK)
+                throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(ctx));
         }
+        if (nyq_device_download(ctx, d.pcm.data(), devOut_[i], (size_t)total * (size_t)ch * sizeof(float)) != NYQ_OK)
+            throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(ctx));
     }
 
     std::vector<FileJob> &jobs_;
@@ -778,6 +855,7 @@ private:
     void *const *ctxs_;
     const int ndev_, feedersPerDev_, nfeeders_, threads_;
     const std::function<void *(int, size_t)> &arena_;
+    const std::function<void *(int, size_t)> &devArena_;
 
     std::vector<StreamFrames *> sfp_;                  // flattened elementary streams
     std::vector<size_t> firstSub_, fileOf_;            // file -> first flat index; flat index -> file
@@ -789,6 +867,10 @@ private:
     std::vector<char> finished_, streamed_;            // per file: pass 3 done; samples handed over slice by slice
     std::vector<std::pair<int64_t, int64_t>> window_;  // per file: [first, last) sample after trimming
     std::vector<std::atomic<int>> subsLeft_;           // per file: elementary streams still on their way through the GPU
+    std::vector<int> fileDev_;                         // per mapped file: the device (index into the decoder's list) of all its streams
+    std::vector<float *> devOut_;                      // per mapped file: its interleaved output in that device's memory
+    size_t nmapped_ = 0;
+    std::vector<std::mutex> ctxMu_{(size_t)nfeeders_}; // per context: finishFile's device calls (a feeder owns its context otherwise)
 
     std::mutex mu_;                                    // scheduler: ready queue, Piece::{nextSlice, inFlight, appendTurn}
     std::condition_variable cv_, cvAppend_;
@@ -814,6 +896,7 @@ BatchOpusDecoder::BatchOpusDecoder(const std::vector<int> &devices) : devices_(d
         if (d < 0 || d >= ndev)
             throw std::runtime_error("BatchOpusDecoder: device " + std::to_string(d) + " does not exist (" + std::to_string(ndev) + " visible)");
     arenas_.resize(devices_.size());
+    devArenas_.resize(devices_.size());
     for (size_t d = 0; d < devices_.size(); d++)
         for (int k = 0; k < kFeeders; k++) {
             nyq_ctx *c = nullptr;
@@ -829,6 +912,8 @@ BatchOpusDecoder::BatchOpusDecoder(const std::vector<int> &devices) : devices_(d
 BatchOpusDecoder::~BatchOpusDecoder() {
     for (Arena &a : arenas_)
         if (a.p) (a.pinned ? nyq_host_free(a.p) : std::free(a.p));
+    for (size_t d = 0; d < devArenas_.size(); d++)
+        if (devArenas_[d].p) nyq_device_free((nyq_ctx *)ctx_[d * kFeeders], devArenas_[d].p);
     for (size_t k = ctx_.size(); k-- > 0;) nyq_ctx_destroy((nyq_ctx *)ctx_[k]);
 }
 
@@ -837,6 +922,11 @@ void BatchOpusDecoder::trim(size_t keepBytes) {
         if (a.p && a.bytes > keepBytes) {
             a.pinned ? nyq_host_free(a.p) : std::free(a.p);
             a = Arena();
+        }
+    for (size_t d = 0; d < devArenas_.size(); d++)
+        if (devArenas_[d].p && devArenas_[d].bytes > keepBytes) {
+            nyq_device_free((nyq_ctx *)ctx_[d * kFeeders], devArenas_[d].p);
+            devArenas_[d] = Arena();
         }
     // pooled sample buffers, ascending by capacity (decodeImpl hands them out from the back: the largest first); keep
     // the largest ones that fit the same bound
@@ -857,6 +947,21 @@ void *BatchOpusDecoder::arena(int dev, size_t bytes) {
     a.pinned = a.p != nullptr;
     if (!a.p) a.p = std::aligned_alloc(4096, (want + 4095) & ~(size_t)4095);
     if (!a.p) throw std::bad_alloc();
+    a.bytes = want;
+    return a.p;
+}
+
+// device memory of one device for the mapped files' interleaved output, kept from call to call (grow only: a hipFree is a
+// device-wide synchronisation, never on the decode path)
+void *BatchOpusDecoder::deviceArena(int dev, size_t bytes) {
+    Arena &a = devArenas_[(size_t)dev];
+    if (bytes <= a.bytes) return a.p;
+    nyq_ctx *c = (nyq_ctx *)ctx_[(size_t)dev * kFeeders];
+    if (a.p) nyq_device_free(c, a.p);
+    a = Arena();
+    const size_t want = bytes + bytes / 8;
+    a.p = nyq_device_alloc(c, want);
+    if (!a.p) throw std::runtime_error("libnyq_imdct: cannot allocate device memory for the files' output");
     a.bytes = want;
     return a.p;
 }
@@ -929,6 +1034,7 @@ void BatchOpusDecoder::decodeImpl(const std::vector<const std::vector<uint8_t> *
     double cpuSecs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), tailSecs = 0, busySecs = 0;
     long totalFrames = 0;
     const std::function<void *(int, size_t)> arenaFn = [this](int dev, size_t bytes) { return arena(dev, bytes); };
+    const std::function<void *(int, size_t)> devArenaFn = [this](int dev, size_t bytes) { return deviceArena(dev, bytes); };
     auto settle = [&](size_t i) {
         if (!jobs[i].error.empty()) {
             out[i].error = jobs[i].error;
@@ -943,7 +1049,7 @@ void BatchOpusDecoder::decodeImpl(const std::vector<const std::vector<uint8_t> *
                     pool_.pop_back();
                     out[i].pcm.clear();
                 }
-        SubBatch sb(jobs, out, members, ctx_.data(), (int)devices_.size(), kFeeders, threads, arenaFn);
+        SubBatch sb(jobs, out, members, ctx_.data(), (int)devices_.size(), kFeeders, threads, arenaFn, devArenaFn);
         sb.run();
         cpuSecs += sb.cpuSeconds;
         tailSecs += sb.tailSeconds;

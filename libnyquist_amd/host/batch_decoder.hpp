@@ -6,7 +6,10 @@
 //           threads (one GPU context each: pieces upload, compute and download side by side -- the post-filter
 //           of a piece with few long streams is a handful of sequential waves, so several must be in flight) runs
 //           nyq_celt_frames_to_pcm = inverse MDCTs + TDAC chaining + post-filter + de-emphasis + interleave
-//   pass 3 (CPU threads): channel mapping, pre-skip / end trimming (RFC 7845 section 4), header gain.
+//   pass 3: channel mapping, pre-skip / end trimming (RFC 7845 section 4), header gain -- on the DEVICE (round 4): every
+//           elementary stream of a file that needs them writes through an output record (nyq_out_desc) straight into the
+//           file's interleaved layout in device memory, one download per file; files that are one identity-mapped stream at
+//           unit gain take their samples from the dense output slice by slice.  No per-sample work on the host.
 // Replaces the per-packet loop of src/OpusDecoder.cpp:95-122 (op_read_float).
 #pragma once
 #include <cstdint>
@@ -71,6 +74,7 @@ private:
     void decodeImpl(const std::vector<const std::vector<uint8_t> *> &files, std::vector<DecodedStream> &out, const StreamSink *sink,
                     BatchStats *stats, int threads);
     void *arena(int dev, size_t bytes);
+    void *deviceArena(int dev, size_t bytes);   // device memory of one device for the files' interleaved output (grow only)
     static constexpr int kFeeders = 6;        // GPU contexts / feeder threads PER DEVICE: pieces in flight at once
     struct Arena {                            // page-locked staging memory of one device's groups, kept between calls
         void *p = nullptr;
@@ -81,6 +85,7 @@ private:
     size_t stagingBudget_ = (size_t)6 << 30;
     std::vector<void *> ctx_;                 // nyq_ctx*, device d's feeders at [d * kFeeders, (d + 1) * kFeeders)
     std::vector<Arena> arenas_;
+    std::vector<Arena> devArenas_;            // per device: device memory (Arena::pinned unused)
     std::vector<std::vector<float>> pool_;    // sample buffers of the sink form, capacity kept
 };
 

@@ -57,9 +57,20 @@ size_t nyq_celt_state_floats(size_t nstreams, int channels) {
     return nsc * (60 + 1088 + 1) + nstreams * 6;
 }
 
-int nyq_celt_frames_to_pcm_window(nyq_ctx *ctx, int LM, const float *freq, const unsigned char *transient, const int *pf_pitch,
-                                  const float *pf_gain, const int *pf_tapset, float *out, float *state, size_t nstreams,
-                                  size_t nframes, int channels, size_t frames_per_stream) {
+// "device memory" of the stand-in is host memory
+void *nyq_device_alloc(nyq_ctx *, size_t bytes) { return std::malloc(bytes ? bytes : 1); }
+void nyq_device_free(nyq_ctx *, void *p) { std::free(p); }
+int nyq_device_zero(nyq_ctx *, void *p, size_t bytes) { std::memset(p, 0, bytes); return NYQ_OK; }
+int nyq_device_download(nyq_ctx *, void *dst, const void *src, size_t bytes) { std::memcpy(dst, src, bytes); return NYQ_OK; }
+int nyq_device_dup_channel(nyq_ctx *, float *base, int cstride, int src, int dst, size_t n) {
+    for (size_t t = 0; t < n; t++) base[t * cstride + dst] = base[t * cstride + src];
+    return NYQ_OK;
+}
+
+// desc != null: stream s with desc[s].base writes through its record (as the real kernels' store phase does)
+int nyq_celt_frames_to_pcm_mapped(nyq_ctx *ctx, int LM, const float *freq, const unsigned char *transient, const int *pf_pitch,
+                                  const float *pf_gain, const int *pf_tapset, float *out, const nyq_out_desc *desc, float *state,
+                                  size_t nstreams, size_t nframes, int channels, size_t frames_per_stream) {
     const size_t N = (size_t)120 << LM, nsc = nstreams * channels;
     g_calls[ctx->device]++;
     const long ncall = ++g_allCalls, every = g_failCallEvery.load();
@@ -75,8 +86,17 @@ int nyq_celt_frames_to_pcm_window(nyq_ctx *ctx, int LM, const float *freq, const
                 for (size_t k = 0; k < N; k += 7) v += x[k];
                 acc = 0.5f * acc + v + (transient ? (float)transient[hf] : 0.f) + (float)pf_pitch[hf] * 1e-3f + pf_gain[hf] +
                       (float)pf_tapset[hf];
-                float *o = out + (hf * N) * channels + c;
-                for (size_t k = 0; k < N; k++) o[k * channels] = acc + (float)k * 1e-6f;
+                if (desc && desc[s].base) {
+                    const nyq_out_desc &D = desc[s];
+                    if (c < 2 && D.coff[c] >= 0)
+                        for (size_t k = 0; k < N; k++) {
+                            const long long ts = D.t0 + (long long)(f * N + k);
+                            if (ts >= D.first && ts < D.last) D.base[(ts - D.first) * D.cstride + D.coff[c]] = (acc + (float)k * 1e-6f) * D.gain;
+                        }
+                } else {
+                    float *o = out + (hf * N) * channels + c;
+                    for (size_t k = 0; k < N; k++) o[k * channels] = acc + (float)k * 1e-6f;
+                }
             }
             if (state) state[(s * channels + c) * 60] = acc;
         }
@@ -87,6 +107,13 @@ int nyq_celt_frames_to_pcm_window(nyq_ctx *ctx, int LM, const float *freq, const
     }
     std::this_thread::sleep_for(std::chrono::microseconds(200 + 20 * (nstreams * nframes) / 64));   // a GPU takes a while
     return NYQ_OK;
+}
+
+int nyq_celt_frames_to_pcm_window(nyq_ctx *ctx, int LM, const float *freq, const unsigned char *transient, const int *pf_pitch,
+                                  const float *pf_gain, const int *pf_tapset, float *out, float *state, size_t nstreams,
+                                  size_t nframes, int channels, size_t frames_per_stream) {
+    return nyq_celt_frames_to_pcm_mapped(ctx, LM, freq, transient, pf_pitch, pf_gain, pf_tapset, out, nullptr, state, nstreams, nframes,
+                                         channels, frames_per_stream);
 }
 
 int nyq_celt_frames_to_pcm(nyq_ctx *c, int LM, const float *freq, const unsigned char *transient, const int *pf_pitch,

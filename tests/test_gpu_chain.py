@@ -217,3 +217,69 @@ def test_windowed_chain_is_bit_identical_to_one_window(ctx, ctx_ab, oracle, lm, 
             ctx.set_option(nyq.binding.OPT_CHAIN_FUSED, ONE_LAUNCH)
         outs.append(d_out.cpu().numpy())
     assert np.array_equal(outs[0], outs[1])
+
+
+class _OutDesc(__import__("ctypes").Structure):
+    import ctypes as _C
+    _fields_ = [("base", _C.c_void_p), ("first", _C.c_longlong), ("last", _C.c_longlong), ("t0", _C.c_longlong), ("cstride", _C.c_int),
+                ("coff", _C.c_int * 2), ("gain", _C.c_float)]
+
+
+@pytest.mark.parametrize("lm,ch,form", [(3, 2, ONE_LAUNCH), (3, 2, TWO_KERNELS), (2, 2, ONE_LAUNCH), (3, 1, ONE_LAUNCH), (0, 1, ONE_LAUNCH)])
+def test_mapped_output_equals_the_dense_output_rearranged(ctx, oracle, lm, ch, form):
+    """Row f3: with an output record per elementary stream (nyq_out_desc) the kernels' store phase writes sample ts of
+    channel k to base[(ts - first) * cstride + coff[k]] * gain for first <= ts < last and nowhere else -- the channel mapping
+    of opus_multistream_decoder.c:305-331, the pre-skip / end trim and the header gain without a pass on the host.  Checked
+    bit for bit against the dense output of the same call, for the one-launch kernel and the post-filter pipeline (stereo
+    and mono instances), with a stream that has no record (dense), a channel that is not written (-1) and a time-slice
+    offset t0."""
+    import ctypes as C
+    import libnyquist_amd as nyq
+    import torch
+    ctx.set_tables(*oracle.tables()[:2])
+    rng = np.random.default_rng(900 + 10 * lm + ch)
+    ns, nf, n = 5, 9, 120 << lm
+    freq, tr, pitch, gain, taps, pst, ov, hist, dm = _case(rng, ns, nf, 0.2, ch=ch, lm=lm)
+    dense = _run_chain(ctx, lm, freq, tr, pitch, gain, taps, pst, ov, hist, dm, ch, form=form)[0]      # [ns][nf*n][ch]
+    dev = torch.device("cuda", 0)
+    T = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dt)).to(dev)
+    cstride, total = 5, nf * n
+    files = torch.full((ns, total + 64, cstride), -7.0, device=dev)
+    desc = (_OutDesc * ns)()
+    want = np.full((ns, total + 64, cstride), -7.0, np.float32)
+    for s in range(ns):
+        t0 = 1000 * s                                            # the call is a slice that starts at stream sample t0
+        first, last = t0 + 37 + s, t0 + total - 11 * s           # (first not a multiple of 2 or 4: unaligned windows)
+        g = np.float32(1.0 if s == 0 else 0.5 + 0.1 * s)
+        c0, c1 = (3, 1) if s % 2 == 0 else (0, -1)               # (odd streams: the second channel is dropped)
+        if s == 3:
+            desc[s].base = None                                  # no record: this stream goes to the dense output
+            continue
+        desc[s].base = files[s].data_ptr()
+        desc[s].first, desc[s].last, desc[s].t0, desc[s].cstride, desc[s].gain = first, last, t0, cstride, float(g)
+        desc[s].coff[0], desc[s].coff[1] = c0, (c1 if ch == 2 else -1)
+        w = dense[s, first - t0:last - t0]
+        want[s, :last - first, c0] = w[:, 0] * g
+        if ch == 2 and c1 >= 0:
+            want[s, :last - first, c1] = w[:, 1] * g
+    d_desc = torch.from_numpy(np.frombuffer(bytes(desc), np.uint8).copy()).to(dev)
+    d_freq, d_tr = T(freq, np.float32), T(tr, np.uint8)
+    d_pp, d_pg, d_pt = T(pitch, np.int32), T(gain, np.float32), T(taps, np.int32)
+    d_si = T(pst, np.float32)
+    d_so = torch.zeros_like(d_si)
+    d_ov, d_h, d_m = T(ov, np.float32), T(hist, np.float32), T(dm, np.float32)
+    d_out = torch.full((ns, nf * n, ch), 3.0, device=dev)
+    d_pcm = torch.empty((ns * ch, nf * n), device=dev)
+    d_work = torch.empty(ctx.celt_synth_work_floats(ns, nf, ch), device=dev)
+    torch.cuda.synchronize(dev)
+    V = lambda t: C.c_void_p(t.data_ptr())
+    ctx.set_option(nyq.binding.OPT_CHAIN_FUSED, form)
+    try:
+        ctx._ck(ctx.lib.nyq_celt_chain_mapped_dev(ctx.h, lm, V(d_freq), V(d_tr), V(d_pp), V(d_pg), V(d_pt), V(d_si), V(d_so), V(d_ov), V(d_h),
+                                                  V(d_m), V(d_out), V(d_desc), V(d_pcm), V(d_work), ns, nf, ch))
+        ctx.synchronize()
+    finally:
+        ctx.set_option(nyq.binding.OPT_CHAIN_FUSED, ONE_LAUNCH)
+    got = files.cpu().numpy()
+    assert np.array_equal(got, want)
+    assert np.array_equal(d_out[3].cpu().numpy(), dense[3])      # the stream without a record, dense as ever
