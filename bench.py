@@ -110,7 +110,7 @@ def cpu_share():
     return n
 
 
-def opus_file_decode_leg(count=256, fname="short.opus", n=421930, threads=None, device=0):
+def opus_file_decode_leg(count=256, fname="short.opus", n=421930, threads=None, device=0, channels=2):
     """File-level decode of `count` copies of tests/golden/<fname> (short.opus: 220 stereo 20 ms CELT frames + one
     closing 2.5 ms frame, 123 kbit/s; sb-reverie.opus: 11184 frames = 224 s, BASELINE config 4's file) as ONE
     batch through libnyquist_host (CPU entropy stage in
@@ -120,27 +120,31 @@ def opus_file_decode_leg(count=256, fname="short.opus", n=421930, threads=None, 
     threads = threads or cpu_share()
     raw = open(os.path.join(ROOT, "tests", "golden", fname), "rb").read()
     H = ctypes.CDLL(os.path.join(ROOT, "libnyquist_amd", "libnyquist_host.so"))
-    H.nyqh_batch_decode_timed.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
-                                    ctypes.c_long, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")]
-    H.nyqh_batch_decode_timed.restype = ctypes.c_long
+    H.nyqh_batch_decode_stats8.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_long, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")]
+    H.nyqh_batch_decode_stats8.restype = ctypes.c_long
     H.nyqh_set_devices.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int]
     H.nyqh_set_devices.restype = None
     H.nyqh_set_devices((ctypes.c_int * 1)(device), 1)      # this rank's GPU (an explicit call: the environment is not touched)
     first = np.zeros(n, np.float32)
-    stats = np.zeros(6, np.float64)
-    H.nyqh_batch_decode_timed(raw, len(raw), count, threads, first.ctypes.data_as(ctypes.c_void_p), None, n, stats)   # contexts, pinned staging, pooled buffers
+    stats = np.zeros(8, np.float64)
+    H.nyqh_batch_decode_stats8(raw, len(raw), count, threads, first.ctypes.data_as(ctypes.c_void_p), None, n, stats)   # contexts, pinned staging, pooled buffers
     t0 = time.perf_counter()
-    got = H.nyqh_batch_decode_timed(raw, len(raw), count, threads, first.ctypes.data_as(ctypes.c_void_p), None, n, stats)
+    got = H.nyqh_batch_decode_stats8(raw, len(raw), count, threads, first.ctypes.data_as(ctypes.c_void_p), None, n, stats)
     wall = time.perf_counter() - t0          # a clock AROUND the call; every result is consumed and released inside it
     if got != n:
         raise RuntimeError(f"nyqh_batch_decode returned {got}")
-    cpu_s, tail_s, frames, thr, wall_inside, ndev = stats
-    leg = {"file": fname, "files": count, "frames": int(frames), "host_threads": int(thr), "devices": int(ndev),
+    cpu_s, tail_s, frames, thr, wall_inside, ndev, gpu_call_s, feeders = stats
+    leg = {"file": fname, "files": count, "channels": channels, "frames": int(frames), "host_threads": int(thr), "devices": int(ndev),
+           # how busy the GPU side was kept: time the feeder threads spent inside GPU calls (uploads, kernels, downloads),
+           # summed, over wall x feeder threads -- the rest of the wall clock the GPU waited for the host's entropy stage
+           "gpu_feeder_threads": int(feeders), "gpu_call_seconds_summed_over_feeders": float(gpu_call_s),
+           "gpu_busy_fraction": float(gpu_call_s / (wall * feeders)) if feeders else None,
            "seconds": wall, "wall_seconds": wall, "wall_seconds_measured_inside_the_library": float(wall_inside),
            "files_per_sec": count / wall, "frames_per_sec": frames / wall,
            "breakdown_cpu_entropy_stage_s": cpu_s, "breakdown_not_hidden_gpu_and_trim_s": tail_s,
            "wall_over_stage_sum": wall / (cpu_s + tail_s),
-           "x_realtime": count * (n / 2 / 48000.0) / wall, "checksum_file0": float(first.astype(np.float64).sum())}
+           "x_realtime": count * (n / channels / 48000.0) / wall, "checksum_file0": float(first.astype(np.float64).sum())}
     rp = os.path.join(ROOT, "oracle", "_ref", "libref_decode.so")
     if os.path.exists(rp):
         R = ctypes.CDLL(rp)
@@ -210,6 +214,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the pinned host-buffer (PCIe) measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--threads-per-rank", type=int, default=0,
+                    help="host threads of each rank's file-decode leg (default: this process's usable cores / world size)")
     ap.add_argument("--preroll-ms", type=float, default=40.0,
                     help="GPU time each leg's operator runs untimed before its warm-up, to measure at steady clocks (0 = none)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -514,19 +520,34 @@ def main():
     file_leg = None
     if not args.no_host_leg:
         try:
-            thr = max(1, cpu_share() // world)
+            thr = args.threads_per_rank if args.threads_per_rank > 0 else max(1, cpu_share() // world)
             file_leg = opus_file_decode_leg(256 if world == 1 else 128, threads=thr, device=local_rank)
             if world == 1:
                 # BASELINE config 4's file (224 s per stream): the GPU walks it in time slices behind the entropy stage
-                file_leg["long_streams"] = opus_file_decode_leg(32, "sb-reverie.opus", 21472602, device=local_rank)
+                file_leg["long_streams"] = opus_file_decode_leg(32, "sb-reverie.opus", 21472602, threads=thr, device=local_rank)
+                # BASELINE config 5's shape: 7.1 surround (8 channels in 5 elementary streams, 3 coupled; the corpus file made
+                # with the reference's surround encoder stands in for Rachel8ch.opus, which the reference mount lacks): channel
+                # mapping, trim and gain happen in the kernels' store phase, one download per file (row f3)
+                file_leg["surround_7_1"] = opus_file_decode_leg(128, os.path.join("corpus", "surround71_20ms_320k.opus"), 384000, threads=thr,
+                                                                device=local_rank, channels=8)
         except Exception as e:
             file_leg = {"error": repr(e)} if file_leg is None else dict(file_leg, long_streams_error=repr(e))
         if world > 1:                        # (every rank takes part, whatever happened above)
-            tt = torch.tensor([file_leg.get("wall_seconds", float("inf"))], device=red_dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tt = torch.tensor([file_leg.get("wall_seconds", float("inf")), file_leg.get("gpu_busy_fraction") or 0.0,
+                               float(file_leg.get("host_threads", 0))], device=red_dev, dtype=torch.float64)
+            every = [torch.zeros_like(tt) for _ in range(world)]
+            dist.all_gather(every, tt)
+            walls = [float(e[0].item()) for e in every]
             if "files" in file_leg:
-                file_leg["whole_job"] = {"n_gpus": world, "files": world * file_leg["files"], "slowest_rank_wall_seconds": float(tt.item()),
-                                         "files_per_sec": world * file_leg["files"] / float(tt.item())}
+                # The file-level leg is bound by the host's bit-serial entropy stage: every rank decodes
+                # with ITS share of the node's cores, so files/s follows the host threads, not the GPU count -- the per-rank
+                # GPU-busy fractions say how much of each GPU the host could feed.
+                file_leg["whole_job"] = {"n_gpus": world, "files": world * file_leg["files"], "slowest_rank_wall_seconds": max(walls),
+                                         "files_per_sec": world * file_leg["files"] / max(walls),
+                                         "per_rank_wall_seconds": walls,
+                                         "per_rank_gpu_busy_fraction": [float(e[1].item()) for e in every],
+                                         "per_rank_host_threads": [int(e[2].item()) for e in every],
+                                         "host_threads_total": int(sum(e[2].item() for e in every))}
 
     my_kern_avg_ms = sum(kern_ms) / len(kern_ms)
     kern_avg_ms_cold = sum(kern_ms_cold) / len(kern_ms_cold)

@@ -63,6 +63,7 @@ public:
     void decode(const std::vector<const std::vector<uint8_t> *> &files, const StreamSink &sink, BatchStats *stats = nullptr,
                 int threads = 0);
     int deviceCount() const { return (int)devices_.size(); }
+    static constexpr int kFeedersPerDevice = 6;   // GPU contexts / feeder threads per device: pieces in flight at once
     // page-locked staging memory a sub-batch may use (default 6 GiB, or NYQ_BATCH_BYTES as it stood at construction)
     void setStagingBudget(size_t bytes) { if (bytes) stagingBudget_ = bytes; }
 
@@ -75,7 +76,7 @@ private:
                     BatchStats *stats, int threads);
     void *arena(int dev, size_t bytes);
     void *deviceArena(int dev, size_t bytes);   // device memory of one device for the files' interleaved output (grow only)
-    static constexpr int kFeeders = 6;        // GPU contexts / feeder threads PER DEVICE: pieces in flight at once
+    static constexpr int kFeeders = kFeedersPerDevice;
     struct Arena {                            // page-locked staging memory of one device's groups, kept between calls
         void *p = nullptr;
         size_t bytes = 0;

@@ -176,9 +176,11 @@ static nyq_host::BatchOpusDecoder &capiDecoder() {               // call with g_
 // `count` copies of one file decoded as ONE batch (config 4 shape: many concurrent streams).  The results go through
 // the sink form (every stream is looked at once and its buffer returns to the pool: what the reference's loop does
 // with each AudioData), the first and the last decoded stream are copied out for checking.
-// stats6 = {cpu_s, not_hidden_s, frames, threads, wall_s, devices}: wall_s is the whole call measured in here.
-long nyqh_batch_decode_timed(const unsigned char *file, long size, long count, int threads, float *first, float *last,
-                             long capacity, double *stats) {
+// stats8 = {cpu_s, not_hidden_s, frames, threads, wall_s, devices, gpu_call_s, feeders}: wall_s is the whole call measured in
+// here; gpu_call_s = time the feeder threads spent inside GPU calls (uploads, kernels, downloads), summed over the
+// `feeders` feeder threads of all devices -- gpu_call_s / (wall_s * feeders) is how busy the GPU side was kept.
+static long batch_decode_stats(const unsigned char *file, long size, long count, int threads, float *first, float *last,
+                               long capacity, double *stats, int nstats) {
     try {
         const auto t0 = std::chrono::steady_clock::now();
         std::lock_guard<std::mutex> lk(g_capi_mu);
@@ -201,11 +203,23 @@ long nyqh_batch_decode_timed(const unsigned char *file, long size, long count, i
         stats[0] = st.cpuSeconds; stats[1] = st.gpuSeconds; stats[2] = (double)st.frames; stats[3] = st.threads;
         stats[4] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         stats[5] = (double)dec.deviceCount();
+        if (nstats >= 8) {
+            stats[6] = st.gpuBusySeconds;
+            stats[7] = (double)(dec.deviceCount() * nyq_host::BatchOpusDecoder::kFeedersPerDevice);
+        }
         return nsamp;
     } catch (const std::exception &e) {
         g_capi_err = e.what();
         return -1;
     }
+}
+long nyqh_batch_decode_timed(const unsigned char *file, long size, long count, int threads, float *first, float *last,
+                             long capacity, double *stats6) {
+    return batch_decode_stats(file, size, count, threads, first, last, capacity, stats6, 6);
+}
+long nyqh_batch_decode_stats8(const unsigned char *file, long size, long count, int threads, float *first, float *last,
+                              long capacity, double *stats8) {
+    return batch_decode_stats(file, size, count, threads, first, last, capacity, stats8, 8);
 }
 
 // the same with the original four-element stats = {cpu_s, not_hidden_s, frames, threads}
