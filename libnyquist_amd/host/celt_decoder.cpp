@@ -1,6 +1,18 @@
-// celt_decoder.cpp -- see celt_decoder.hpp.  Decoder-only restatement, float build semantics
-// (MULT16_16 = *, SHR/SHL = identity, Q15ONE = 1.0f, NORM_SCALING = 1.0f).  Reference line numbers
-// refer to third_party/opus/celt/ of the reference tree.
+// celt_decoder.cpp -- see celt_decoder.hpp.  The CPU stage of the batched decode path: one CELT frame's bitstream in,
+// freq[] and the GPU stages' scalars out (RFC 6716 section 4.3; float build semantics of the reference).
+//
+// Organisation (this decoder's own, built for the batch pipeline -- the bitstream semantics are the specification's):
+//   * AllocConst -- everything of the bit allocation that depends only on (frame size, channels) is tabulated once:
+//     band widths, the eleven allocation rows already scaled to 1/8 bits, thresholds, trim slopes, caps;
+//   * BitPlan    -- the frame's bit allocation from those tables (rows bisection, interpolation, band skipping,
+//     PVQ / fine-energy split), no per-band recomputation of mode arithmetic;
+//   * BandShaper -- a band's shape in TWO phases: the split tree is walked with an explicit stack (no recursion) reading
+//     angles and pulse vectors into a flat list of leaves (integers only), then the leaves are turned into
+//     coefficients by the vector kernels of celt_synth.hpp (spreading rotations of sibling leaves run in lockstep);
+//     the fold source is prepared lazily, only when some leaf of the band actually folds;
+//   * pulse vectors are unranked on 32-bit rows of the U(n, k) table;
+//   * all working memory lives in the decoder object (no heap traffic per frame).
+// Reference line numbers (third_party/opus/celt/) mark the clauses of the reference a block answers to.
 #include "celt_decoder.hpp"
 
 #include <algorithm>
@@ -8,12 +20,14 @@
 #include <cstring>
 #include <vector>
 
+#include "celt_synth.hpp"
+
 namespace nyq_host {
 
 // ---- entropy-coded side information: constants of the Opus specification ----------------------
 namespace {
 
-// Laplace parameters of the coarse energy, {P(0), decay} in Q8 per band, [LM][intra] (quant_bands.c:77-138)
+// Laplace parameters of the coarse energy, {P(0), decay} in Q8 per band, [LM][intra] (RFC 6716 4.3.2.1; quant_bands.c:77-138)
 const uint8_t kEnergyModel[4][2][42] = {
     {{72, 127, 65, 129, 66, 128, 65, 128, 64, 128, 62, 128, 64, 128, 64, 128, 92, 78, 92, 79, 92, 78, 90, 79, 116, 41, 115, 40, 114, 40, 132, 26, 132, 26, 145, 17, 161, 12, 176, 10, 177, 11},
      {24, 179, 48, 138, 54, 135, 54, 132, 53, 134, 56, 133, 55, 132, 55, 132, 61, 114, 70, 96, 74, 88, 75, 88, 87, 74, 89, 66, 91, 67, 100, 59, 108, 50, 120, 40, 122, 37, 97, 43, 78, 50}},
@@ -23,34 +37,33 @@ const uint8_t kEnergyModel[4][2][42] = {
      {21, 178, 59, 110, 71, 86, 75, 85, 84, 83, 91, 66, 88, 73, 87, 72, 92, 75, 98, 72, 105, 58, 107, 54, 115, 52, 114, 55, 112, 56, 129, 51, 132, 40, 150, 33, 140, 29, 98, 35, 77, 42}},
     {{42, 121, 96, 66, 108, 43, 111, 40, 117, 44, 123, 32, 120, 36, 119, 33, 127, 33, 134, 34, 139, 21, 147, 23, 152, 20, 158, 25, 154, 26, 166, 21, 173, 16, 184, 13, 184, 10, 150, 13, 139, 15},
      {22, 178, 63, 114, 74, 82, 84, 83, 92, 82, 103, 62, 96, 72, 96, 67, 101, 73, 107, 72, 113, 55, 118, 52, 125, 52, 118, 52, 117, 55, 135, 49, 137, 39, 157, 32, 145, 29, 97, 33, 77, 40}}};
-const uint8_t kSmallEnergyIcdf[3] = {2, 1, 0};                                   // quant_bands.c:140
-const float kPredCoef[4] = {29440 / 32768.f, 26112 / 32768.f, 21248 / 32768.f, 16384 / 32768.f};   // :67
-const float kBetaCoef[4] = {30147 / 32768.f, 22282 / 32768.f, 12124 / 32768.f, 6554 / 32768.f};    // :68
-const float kBetaIntra = 4915 / 32768.f;                                         // :69
-const int8_t kTfSelect[4][8] = {{0, -1, 0, -1, 0, -1, 0, -1},                    // celt.c:174-179
-                                {0, -1, 0, -2, 1, 0, 1, -1},
-                                {0, -2, 0, -3, 2, 0, 1, -1},
-                                {0, -2, 0, -3, 3, 0, 1, -1}};
-const uint8_t kTrimIcdf[11] = {126, 124, 119, 109, 87, 41, 19, 9, 4, 2, 0};      // celt.h:145
-const uint8_t kSpreadIcdf[4] = {25, 23, 2, 0};                                   // celt.h:147
-const uint8_t kTapsetIcdf[3] = {2, 1, 0};                                        // celt.h:149
-const uint8_t kLog2Frac[24] = {0, 8, 13, 16, 19, 21, 23, 24, 26, 27, 28, 29, 30, 31, 32, 32, 33, 34, 34, 35, 36, 36, 37, 37};   // rate.c:42-48
+const uint8_t kSmallEnergyIcdf[3] = {2, 1, 0};
+const float kPredCoef[4] = {29440 / 32768.f, 26112 / 32768.f, 21248 / 32768.f, 16384 / 32768.f};
+const float kBetaCoef[4] = {30147 / 32768.f, 22282 / 32768.f, 12124 / 32768.f, 6554 / 32768.f};
+const float kBetaIntra = 4915 / 32768.f;
+const int8_t kTfSelect[4][8] = {{0, -1, 0, -1, 0, -1, 0, -1}, {0, -1, 0, -2, 1, 0, 1, -1}, {0, -2, 0, -3, 2, 0, 1, -1}, {0, -2, 0, -3, 3, 0, 1, -1}};
+const uint8_t kTrimIcdf[11] = {126, 124, 119, 109, 87, 41, 19, 9, 4, 2, 0};
+const uint8_t kSpreadIcdf[4] = {25, 23, 2, 0};
+const uint8_t kTapsetIcdf[3] = {2, 1, 0};
+const uint8_t kLog2Frac[24] = {0, 8, 13, 16, 19, 21, 23, 24, 26, 27, 28, 29, 30, 31, 32, 32, 33, 34, 34, 35, 36, 36, 37, 37};
 constexpr int kSpreadNone = 0, kSpreadNormal = 2, kSpreadAggressive = 3;
+constexpr int kOneBit = 1 << kBitRes;                       // one bit in the allocator's 1/8-bit units
 
-inline float exp2f_ref(float x) { return (float)std::exp(0.6931471805599453094 * (double)x); }   // mathops.h celt_exp2 (float)
-inline uint32_t lcg(uint32_t s) { return 1664525u * s + 1013904223u; }                           // bands.c:61-64
-inline int fracMul16(int a, int b) { return (16384 + (int32_t)(int16_t)a * (int16_t)b) >> 15; } // mathops.h:42
+inline float exp2Ref(float x) { return (float)std::exp(0.6931471805599453094 * (double)x); }   // celt_exp2, float build
+inline uint32_t lcg(uint32_t s) { return 1664525u * s + 1013904223u; }
+inline int fracMul16(int a, int b) { return (16384 + (int32_t)(int16_t)a * (int16_t)b) >> 15; }
 
 }  // namespace
 
 int laplaceDecode(RangeDecoder &dec, unsigned fs, int decay) {
+    // RFC 6716 4.3.2.1 (laplace.c:92-134): geometric tails around a centre of probability fs, a flat floor of 1/32768
     int val = 0;
     unsigned fl = 0;
     const unsigned fm = dec.decodeBin(15);
     if (fm >= fs) {
         val++;
         fl = fs;
-        fs = ((32768u - 32u - fs) * (uint32_t)(16384 - decay) >> 15) + 1;     // ec_laplace_get_freq1 + MINP
+        fs = ((32768u - 32u - fs) * (uint32_t)(16384 - decay) >> 15) + 1;
         while (fs > 1 && fm >= fl + 2 * fs) {
             fs *= 2;
             fl += fs;
@@ -58,7 +71,7 @@ int laplaceDecode(RangeDecoder &dec, unsigned fs, int decay) {
             fs += 1;
             val++;
         }
-        if (fs <= 1) {                                                          // the flat tail
+        if (fs <= 1) {
             const int di = (int)(fm - fl) >> 1;
             val += di;
             fl += 2 * di;
@@ -72,909 +85,871 @@ int laplaceDecode(RangeDecoder &dec, unsigned fs, int decay) {
 
 namespace {
 
-// ---- band energies (quant_bands.c:427-540) -----------------------------------------------------
-void unquantCoarse(const CeltMode &m, int start, int end, float *oldE, int intra, RangeDecoder &dec, int C, int LM) {
-    (void)m;
-    const uint8_t *model = kEnergyModel[LM][intra];
-    float prev[2] = {0.f, 0.f};
-    const float coef = intra ? 0.f : kPredCoef[LM];
-    const float beta = intra ? kBetaIntra : kBetaCoef[LM];
-    const int32_t budget = (int32_t)dec.storageBytes() * 8;
-    for (int i = start; i < end; i++)
-        for (int c = 0; c < C; c++) {
-            int qi;
-            const int32_t tell = dec.tell();
-            if (budget - tell >= 15) {
-                const int pi = 2 * std::min(i, 20);
-                qi = laplaceDecode(dec, model[pi] << 7, model[pi + 1] << 6);
-            } else if (budget - tell >= 2) {
-                qi = dec.icdf(kSmallEnergyIcdf, 2);
-                qi = (qi >> 1) ^ -(qi & 1);
-            } else if (budget - tell >= 1) {
-                qi = -dec.bitLogp(1);
+// ---- what of the allocation depends on (LM, C) alone ------------------------------------------------------------------
+struct AllocConst {
+    int16_t width[kBands];                  // bins of the band in a 2.5 ms block
+    int16_t bins[kBands];                   // ... in this frame size
+    int16_t first[kBands + 1];              // first bin of the band in this frame size
+    int16_t floorBits[kBands];              // below this a band gets nothing (or the bare minimum)
+    int32_t trimUnit[kBands];               // trim offset = trimUnit * (trim - 5 - LM) * (end - 1 - band) >> 6
+    int16_t row[kAllocVectors][kBands];     // the static allocation rows in 1/8 bits for this (LM, C)
+    int16_t cap[kBands];
+    int16_t pulseCap[kBands];               // logN + 8 LM
+    int16_t boostQuantum[kBands];           // what one dynalloc boost step adds
+    int minBits;                            // C << 3
+};
+
+const AllocConst &allocConst(int LM, int C) {
+    static const AllocConst *tab = [] {
+        static AllocConst t[4][2];
+        const CeltMode &m = mode48k();
+        for (int lm = 0; lm < 4; lm++)
+            for (int c = 1; c <= 2; c++) {
+                AllocConst &a = t[lm][c - 1];
+                int caps[kBands];
+                m.initCaps(caps, lm, c);
+                a.minBits = c << kBitRes;
+                for (int j = 0; j < kBands; j++) {
+                    const int w = m.eBands[j + 1] - m.eBands[j];
+                    a.width[j] = (int16_t)w;
+                    a.bins[j] = (int16_t)(w << lm);
+                    a.first[j] = (int16_t)(m.eBands[j] << lm);
+                    a.floorBits[j] = (int16_t)std::max(c << kBitRes, (3 * w << lm << kBitRes) >> 4);
+                    a.trimUnit[j] = c * w * (1 << (lm + kBitRes));
+                    for (int r = 0; r < kAllocVectors; r++) a.row[r][j] = (int16_t)(c * w * m.alloc[r * kBands + j] << lm >> 2);
+                    a.cap[j] = (int16_t)caps[j];
+                    a.pulseCap[j] = (int16_t)(m.logN[j] + lm * kOneBit);
+                    const int width = c * w << lm;
+                    a.boostQuantum[j] = (int16_t)std::min(width << kBitRes, std::max(6 << kBitRes, width));
+                }
+                a.first[kBands] = (int16_t)(m.eBands[kBands] << lm);
+            }
+        return &t[0][0];
+    }();
+    return tab[LM * 2 + (C - 1)];
+}
+
+// ---- the frame's bit allocation (RFC 6716 4.3.3; rate.c:247-638) --------------------------------------------------------
+struct BitPlan {
+    int shape[kBands];          // 1/8 bits for the band's PVQ shape
+    int fine[kBands];           // whole bits per channel of fine energy
+    int finePrio[kBands];       // which bands get the left-over bits first
+    int codedBands = 0;
+    int intensity = 0;          // first band coded with intensity stereo
+    int dualStereo = 0;
+    int32_t balance = 0;        // bits carried into the band loop
+};
+
+struct Allocator {
+    const AllocConst &K;
+    const CeltMode &m;
+    const int start, end, C, LM;
+    RangeDecoder &rc;
+
+    // the bits band j would get from `raw` (a row value, already trimmed and boosted), scanning from the top band down:
+    // once a band reaches its floor every lower band is taken whole; a band under its floor gets the minimum or nothing
+    template <class RawFn>
+    int32_t demand(RawFn raw) const {
+        int32_t sum = 0;
+        bool reached = false;
+        for (int j = end; j-- > start;) {
+            const int v = raw(j);
+            if (v >= K.floorBits[j] || reached) {
+                reached = true;
+                sum += std::min<int>(v, K.cap[j]);
+            } else if (v >= K.minBits) {
+                sum += K.minBits;
+            }
+        }
+        return sum;
+    }
+
+    void run(const int *boost, int trim, int32_t total, BitPlan &P) const {
+        total = std::max<int32_t>(total, 0);
+        // reservations: the skip flag, the intensity parameter, the dual-stereo flag
+        const int skipRsv = total >= kOneBit ? kOneBit : 0;
+        total -= skipRsv;
+        int intensityRsv = 0, dualRsv = 0;
+        if (C == 2) {
+            intensityRsv = kLog2Frac[end - start];
+            if (intensityRsv > total) {
+                intensityRsv = 0;
             } else {
-                qi = -1;
-            }
-            const float q = (float)qi;
-            float &e = oldE[i + c * kBands];
-            e = std::max(-9.f, e);
-            const float tmp = coef * e + prev[c] + q;
-            e = tmp;
-            prev[c] = prev[c] + q - beta * q;
-        }
-}
-
-void unquantFine(int start, int end, float *oldE, const int *fineQuant, RangeDecoder &dec, int C) {
-    for (int i = start; i < end; i++) {
-        if (fineQuant[i] <= 0) continue;
-        for (int c = 0; c < C; c++) {
-            const int q2 = (int)dec.bits(fineQuant[i]);
-            const float offset = (q2 + .5f) * (1 << (14 - fineQuant[i])) * (1.f / 16384) - .5f;
-            oldE[i + c * kBands] += offset;
-        }
-    }
-}
-
-void unquantFinalise(int start, int end, float *oldE, const int *fineQuant, const int *finePriority, int bitsLeft,
-                     RangeDecoder &dec, int C) {
-    for (int prio = 0; prio < 2; prio++)
-        for (int i = start; i < end && bitsLeft >= C; i++) {
-            if (fineQuant[i] >= kMaxFineBits || finePriority[i] != prio) continue;
-            for (int c = 0; c < C; c++) {
-                const int q2 = (int)dec.bits(1);
-                const float offset = (q2 - .5f) * (1 << (14 - fineQuant[i] - 1)) * (1.f / 16384);
-                oldE[i + c * kBands] += offset;
-                bitsLeft--;
+                total -= intensityRsv;
+                dualRsv = total >= kOneBit ? kOneBit : 0;
+                total -= dualRsv;
             }
         }
-}
-
-// ---- time-frequency resolution flags (celt_decoder_clean.c:314-351) ------------------------------
-void tfDecode(int start, int end, int isTransient, int *tfRes, int LM, RangeDecoder &dec) {
-    uint32_t budget = dec.storageBytes() * 8;
-    uint32_t tell = (uint32_t)dec.tell();
-    int logp = isTransient ? 2 : 4;
-    const int tfSelectRsv = LM > 0 && tell + logp + 1 <= budget;
-    budget -= tfSelectRsv;
-    int tfChanged = 0, curr = 0;
-    for (int i = start; i < end; i++) {
-        if (tell + logp <= budget) {
-            curr ^= dec.bitLogp(logp);
-            tell = (uint32_t)dec.tell();
-            tfChanged |= curr;
+        int trimOff[kBands];
+        for (int j = start; j < end; j++) {
+            trimOff[j] = K.trimUnit[j] * (trim - 5 - LM) * (end - j - 1) >> 6;
+            if (K.bins[j] == 1) trimOff[j] -= K.minBits;
         }
-        tfRes[i] = curr;
-        logp = isTransient ? 4 : 5;
-    }
-    int tfSelect = 0;
-    if (tfSelectRsv && kTfSelect[LM][4 * isTransient + 0 + tfChanged] != kTfSelect[LM][4 * isTransient + 2 + tfChanged])
-        tfSelect = dec.bitLogp(1);
-    for (int i = start; i < end; i++) tfRes[i] = kTfSelect[LM][4 * isTransient + 2 * tfSelect + tfRes[i]];
-}
-
-// ---- bit allocation (rate.c:247-638) ----------------------------------------------------------
-int interpBits2Pulses(const CeltMode &m, int start, int end, int skipStart, const int *bits1, const int *bits2,
-                      const int *thresh, const int *cap, int32_t total, int32_t *balanceOut, int skipRsv, int *intensity,
-                      int intensityRsv, int *dualStereo, int dualStereoRsv, int *bits, int *ebits, int *finePriority,
-                      int C, int LM, RangeDecoder &ec) {
-    const int allocFloor = C << kBitRes;
-    const int stereo = C > 1;
-    const int logM = LM << kBitRes;
-    int lo = 0, hi = 1 << 6;
-    for (int i = 0; i < 6; i++) {                                   // ALLOC_STEPS
-        const int mid = (lo + hi) >> 1;
+        auto rowBits = [&](int r, int j) {
+            int v = K.row[r][j];
+            if (v > 0) v = std::max(0, v + trimOff[j]);
+            return v;
+        };
+        // the two neighbouring rows of the static table between which the budget falls
+        int lo = 1, hi = kAllocVectors - 1;
+        do {
+            const int mid = (lo + hi) >> 1;
+            if (demand([&](int j) { return rowBits(mid, j) + boost[j]; }) > total) hi = mid - 1;
+            else lo = mid + 1;
+        } while (lo <= hi);
+        hi = lo--;
+        int base[kBands], span[kBands];
+        int skipStart = start;
+        for (int j = start; j < end; j++) {
+            int b1 = rowBits(lo, j);
+            int b2 = hi >= kAllocVectors ? K.cap[j] : rowBits(hi, j);
+            if (lo > 0) b1 += boost[j];
+            b2 += boost[j];
+            if (boost[j] > 0) skipStart = j;
+            base[j] = b1;
+            span[j] = std::max(0, b2 - b1);
+        }
+        // six bisection steps on the interpolation weight between the two rows
+        int wlo = 0, whi = 1 << 6;
+        for (int step = 0; step < 6; step++) {
+            const int mid = (wlo + whi) >> 1;
+            if (demand([&](int j) { return base[j] + (int)(mid * (int32_t)span[j] >> 6); }) > total) whi = mid;
+            else wlo = mid;
+        }
+        int *bits = P.shape;
         int32_t psum = 0;
-        int done = 0;
-        for (int j = end; j-- > start;) {
-            const int tmp = bits1[j] + (int)(mid * (int32_t)bits2[j] >> 6);
-            if (tmp >= thresh[j] || done) {
-                done = 1;
-                psum += std::min(tmp, cap[j]);
-            } else if (tmp >= allocFloor) {
-                psum += allocFloor;
+        {
+            bool reached = false;
+            for (int j = end; j-- > start;) {
+                int v = base[j] + (wlo * span[j] >> 6);
+                if (v < K.floorBits[j] && !reached) v = v >= K.minBits ? K.minBits : 0;
+                else reached = true;
+                v = std::min<int>(v, K.cap[j]);
+                bits[j] = v;
+                psum += v;
             }
         }
-        if (psum > total) hi = mid;
-        else lo = mid;
-    }
-    int32_t psum = 0;
-    int done = 0;
-    for (int j = end; j-- > start;) {
-        int tmp = bits1[j] + (lo * bits2[j] >> 6);
-        if (tmp < thresh[j] && !done) tmp = tmp >= allocFloor ? allocFloor : 0;
-        else done = 1;
-        tmp = std::min(tmp, cap[j]);
-        bits[j] = tmp;
-        psum += tmp;
-    }
-    int codedBands;
-    for (codedBands = end;; codedBands--) {                          // band skipping, from the top
-        const int j = codedBands - 1;
-        if (j <= skipStart) {
-            total += skipRsv;
-            break;
+        // band skipping from the top: a band that could be coded carries a flag saying whether it is
+        int coded = end;
+        for (;; coded--) {
+            const int j = coded - 1;
+            if (j <= skipStart) {
+                total += skipRsv;
+                break;
+            }
+            int32_t left = total - psum;
+            const int span0 = m.eBands[coded] - m.eBands[start];
+            const int32_t perBin = left / span0;
+            left -= span0 * perBin;
+            const int rem = std::max((int)left - (m.eBands[j] - m.eBands[start]), 0);
+            int bandBits = (int)(bits[j] + perBin * K.width[j] + rem);
+            if (bandBits >= std::max<int>(K.floorBits[j], K.minBits + kOneBit)) {
+                if (rc.bitLogp(1)) break;
+                psum += kOneBit;
+                bandBits -= kOneBit;
+            }
+            psum -= bits[j] + intensityRsv;
+            if (intensityRsv > 0) intensityRsv = kLog2Frac[j - start];
+            psum += intensityRsv;
+            if (bandBits >= K.minBits) {
+                psum += K.minBits;
+                bits[j] = K.minBits;
+            } else {
+                bits[j] = 0;
+            }
         }
-        int32_t left = total - psum;
-        const int32_t percoeff = left / (m.eBands[codedBands] - m.eBands[start]);
-        left -= (m.eBands[codedBands] - m.eBands[start]) * percoeff;
-        const int rem = std::max((int)left - (m.eBands[j] - m.eBands[start]), 0);
-        const int bandWidth = m.eBands[codedBands] - m.eBands[j];
-        int bandBits = (int)(bits[j] + percoeff * bandWidth + rem);
-        if (bandBits >= std::max(thresh[j], allocFloor + (1 << kBitRes))) {
-            if (ec.bitLogp(1)) break;
-            psum += 1 << kBitRes;
-            bandBits -= 1 << kBitRes;
+        P.codedBands = coded;
+        P.intensity = intensityRsv > 0 ? start + (int)rc.uint(coded + 1 - start) : 0;
+        if (P.intensity <= start) {
+            total += dualRsv;
+            dualRsv = 0;
         }
-        psum -= bits[j] + intensityRsv;
-        if (intensityRsv > 0) intensityRsv = kLog2Frac[j - start];
-        psum += intensityRsv;
-        if (bandBits >= allocFloor) {
-            psum += allocFloor;
-            bits[j] = allocFloor;
-        } else {
+        P.dualStereo = dualRsv > 0 ? rc.bitLogp(1) : 0;
+        // what is left goes to the coded bands in proportion to their width
+        {
+            int32_t left = total - psum;
+            const int span0 = m.eBands[coded] - m.eBands[start];
+            const int32_t perBin = left / span0;
+            left -= span0 * perBin;
+            for (int j = start; j < coded; j++) bits[j] += (int)perBin * K.width[j];
+            for (int j = start; j < coded; j++) {
+                const int t = (int)std::min<int32_t>(left, K.width[j]);
+                bits[j] += t;
+                left -= t;
+            }
+        }
+        // every band's bits between its shape and the fine energy of its channels
+        const int stereo = C > 1;
+        int32_t carry = 0;
+        int j = start;
+        for (; j < coded; j++) {
+            const int N = K.bins[j];
+            const int32_t have = (int32_t)bits[j] + carry;
+            int32_t excess;
+            if (N > 1) {
+                excess = std::max<int32_t>(have - K.cap[j], 0);
+                bits[j] = (int)(have - excess);
+                const int den = C * N + ((C == 2 && N > 2 && !P.dualStereo && j < P.intensity) ? 1 : 0);
+                const int nLogN = den * K.pulseCap[j];
+                int offset = (nLogN >> 1) - den * kFineOffset;
+                if (N == 2) offset += den << kBitRes >> 2;
+                if (bits[j] + offset < den * 2 << kBitRes) offset += nLogN >> 2;
+                else if (bits[j] + offset < den * 3 << kBitRes) offset += nLogN >> 3;
+                int e = std::max(0, (bits[j] + offset + (den << (kBitRes - 1))) / (den << kBitRes));
+                if (C * e > (bits[j] >> kBitRes)) e = bits[j] >> stereo >> kBitRes;
+                e = std::min(e, kMaxFineBits);
+                P.fine[j] = e;
+                P.finePrio[j] = e * (den << kBitRes) >= bits[j] + offset;
+                bits[j] -= C * e << kBitRes;
+            } else {
+                excess = std::max<int32_t>(0, have - (C << kBitRes));
+                bits[j] = (int)(have - excess);
+                P.fine[j] = 0;
+                P.finePrio[j] = 1;
+            }
+            if (excess > 0) {
+                const int extra = (int)std::min<int32_t>(excess >> (stereo + kBitRes), kMaxFineBits - P.fine[j]);
+                P.fine[j] += extra;
+                const int extraBits = extra * C << kBitRes;
+                P.finePrio[j] = extraBits >= excess - carry;
+                excess -= extraBits;
+            }
+            carry = excess;
+        }
+        P.balance = carry;
+        for (; j < end; j++) {                                    // skipped bands keep fine energy only
+            P.fine[j] = bits[j] >> stereo >> kBitRes;
             bits[j] = 0;
+            P.finePrio[j] = P.fine[j] < 1;
         }
     }
-    if (intensityRsv > 0) *intensity = start + (int)ec.uint(codedBands + 1 - start);
-    else *intensity = 0;
-    if (*intensity <= start) {
-        total += dualStereoRsv;
-        dualStereoRsv = 0;
-    }
-    if (dualStereoRsv > 0) *dualStereo = ec.bitLogp(1);
-    else *dualStereo = 0;
+};
 
-    int32_t left = total - psum;
-    const int32_t percoeff = left / (m.eBands[codedBands] - m.eBands[start]);
-    left -= (m.eBands[codedBands] - m.eBands[start]) * percoeff;
-    for (int j = start; j < codedBands; j++) bits[j] += (int)percoeff * (m.eBands[j + 1] - m.eBands[j]);
-    for (int j = start; j < codedBands; j++) {
-        const int tmp = (int)std::min<int32_t>(left, m.eBands[j + 1] - m.eBands[j]);
-        bits[j] += tmp;
-        left -= tmp;
-    }
-    int32_t balance = 0;
-    int j;
-    for (j = start; j < codedBands; j++) {                            // split PVQ bits / fine energy bits
-        const int N0 = m.eBands[j + 1] - m.eBands[j];
-        const int N = N0 << LM;
-        const int32_t bit = (int32_t)bits[j] + balance;
-        int32_t excess;
-        if (N > 1) {
-            excess = std::max<int32_t>(bit - cap[j], 0);
-            bits[j] = (int)(bit - excess);
-            const int den = C * N + ((C == 2 && N > 2 && !*dualStereo && j < *intensity) ? 1 : 0);
-            const int NClogN = den * (m.logN[j] + logM);
-            int offset = (NClogN >> 1) - den * kFineOffset;
-            if (N == 2) offset += den << kBitRes >> 2;
-            if (bits[j] + offset < den * 2 << kBitRes) offset += NClogN >> 2;
-            else if (bits[j] + offset < den * 3 << kBitRes) offset += NClogN >> 3;
-            ebits[j] = std::max(0, (bits[j] + offset + (den << (kBitRes - 1))) / (den << kBitRes));
-            if (C * ebits[j] > (bits[j] >> kBitRes)) ebits[j] = bits[j] >> stereo >> kBitRes;
-            ebits[j] = std::min(ebits[j], kMaxFineBits);
-            finePriority[j] = ebits[j] * (den << kBitRes) >= bits[j] + offset;
-            bits[j] -= C * ebits[j] << kBitRes;
-        } else {
-            excess = std::max<int32_t>(0, bit - (C << kBitRes));
-            bits[j] = (int)(bit - excess);
-            ebits[j] = 0;
-            finePriority[j] = 1;
-        }
-        if (excess > 0) {
-            const int extraFine = (int)std::min<int32_t>(excess >> (stereo + kBitRes), kMaxFineBits - ebits[j]);
-            ebits[j] += extraFine;
-            const int extraBits = extraFine * C << kBitRes;
-            finePriority[j] = extraBits >= excess - balance;
-            excess -= extraBits;
-        }
-        balance = excess;
-    }
-    *balanceOut = balance;
-    for (; j < end; j++) {                                            // skipped bands: fine energy only
-        ebits[j] = bits[j] >> stereo >> kBitRes;
-        bits[j] = 0;
-        finePriority[j] = ebits[j] < 1;
-    }
-    return codedBands;
-}
-
-int computeAllocation(const CeltMode &m, int start, int end, const int *offsets, const int *cap, int allocTrim,
-                      int *intensity, int *dualStereo, int32_t total, int32_t *balance, int *pulses, int *ebits,
-                      int *finePriority, int C, int LM, RangeDecoder &ec) {
-    total = std::max<int32_t>(total, 0);
-    int skipStart = start;
-    const int skipRsv = total >= 1 << kBitRes ? 1 << kBitRes : 0;
-    total -= skipRsv;
-    int intensityRsv = 0, dualStereoRsv = 0;
-    if (C == 2) {
-        intensityRsv = kLog2Frac[end - start];
-        if (intensityRsv > total) {
-            intensityRsv = 0;
-        } else {
-            total -= intensityRsv;
-            dualStereoRsv = total >= 1 << kBitRes ? 1 << kBitRes : 0;
-            total -= dualStereoRsv;
-        }
-    }
-    int bits1[kBands], bits2[kBands], thresh[kBands], trimOffset[kBands];
-    for (int j = start; j < end; j++) {
-        const int w = m.eBands[j + 1] - m.eBands[j];
-        thresh[j] = std::max(C << kBitRes, (3 * w << LM << kBitRes) >> 4);
-        trimOffset[j] = C * w * (allocTrim - 5 - LM) * (end - j - 1) * (1 << (LM + kBitRes)) >> 6;
-        if ((w << LM) == 1) trimOffset[j] -= C << kBitRes;
-    }
-    int lo = 1, hi = kAllocVectors - 1;
-    do {
-        int done = 0, psum = 0;
-        const int mid = (lo + hi) >> 1;
-        for (int j = end; j-- > start;) {
-            const int N = m.eBands[j + 1] - m.eBands[j];
-            int bitsj = C * N * m.alloc[mid * kBands + j] << LM >> 2;
-            if (bitsj > 0) bitsj = std::max(0, bitsj + trimOffset[j]);
-            bitsj += offsets[j];
-            if (bitsj >= thresh[j] || done) {
-                done = 1;
-                psum += std::min(bitsj, cap[j]);
-            } else if (bitsj >= C << kBitRes) {
-                psum += C << kBitRes;
-            }
-        }
-        if (psum > total) hi = mid - 1;
-        else lo = mid + 1;
-    } while (lo <= hi);
-    hi = lo--;
-    for (int j = start; j < end; j++) {
-        const int N = m.eBands[j + 1] - m.eBands[j];
-        int bits1j = C * N * m.alloc[lo * kBands + j] << LM >> 2;
-        int bits2j = hi >= kAllocVectors ? cap[j] : C * N * m.alloc[hi * kBands + j] << LM >> 2;
-        if (bits1j > 0) bits1j = std::max(0, bits1j + trimOffset[j]);
-        if (bits2j > 0) bits2j = std::max(0, bits2j + trimOffset[j]);
-        if (lo > 0) bits1j += offsets[j];
-        bits2j += offsets[j];
-        if (offsets[j] > 0) skipStart = j;
-        bits2j = std::max(0, bits2j - bits1j);
-        bits1[j] = bits1j;
-        bits2[j] = bits2j;
-    }
-    return interpBits2Pulses(m, start, end, skipStart, bits1, bits2, thresh, cap, total, balance, skipRsv, intensity,
-                             intensityRsv, dualStereo, dualStereoRsv, pulses, ebits, finePriority, C, LM, ec);
-}
-
-// ---- PVQ shape decoding (cwrs.c:469-540, vq.c) ----------------------------------------------------
-void decodePulseVector(int n, int k, uint32_t idx, int *y) {             // cwrsi
-    // U is symmetric, so every lookup of a step reads row n of the table: contiguous in k
-    const uint64_t *T = pvqTable();
-    uint64_t i = idx;
+// ---- pulse vectors (RFC 6716 4.3.4.2; cwrs.c) -----------------------------------------------------------------------------
+// Codeword `idx` of the k-pulse codebook in n dimensions -> y[0 .. n).  U(n, k) counts the vectors whose first coordinate is
+// not negative ... the index space of one coordinate is [ positive values | zero | negative values ] in terms of row n of U:
+// idx >= U(n, k + 1) means "negative" (and that many codewords are skipped), then the largest k' with U(n, k') <= idx is
+// what is left for the remaining coordinates.  32-bit rows (pvqTable32: clamped entries are never reached by a valid index).
+// Returns |y|^2 (what the gain normalisation needs, so that no second pass over y computes it).
+int32_t unrankPulses(int n, int k, uint32_t idx, int16_t *y) {
+    // U is symmetric, so U(n, k) is read as T[k][n]: while the pulse count stands still the two values a step needs --
+    // U(n, k) and U(n, k + 1) -- come from two rows walked along n (sequential reads); a row changes only where a pulse is
+    // found.  (Measured on the pulse vectors of a real stream, tools/scripts/pvq_unrank_bench.cpp: a branch-free lattice walk
+    // and one with both possible next cells loaded ahead are 10-25 % SLOWER than this loop -- its branches predict well.)
+    const uint32_t *T = pvqTable32();
+    constexpr long D = kPvqTableDim;
+    const uint32_t *here = T + (size_t)k * D;
+    int32_t yy = 0;
     while (n > 2) {
-        const uint64_t *row = T + (size_t)n * kPvqTableDim;
-        uint64_t p, q;
-        int s, k0;
-        if (k >= n) {                                                    // many pulses
-            p = row[k + 1];
-            s = -(i >= p);
-            i -= p & (uint64_t)(int64_t)s;
-            k0 = k;
-            q = row[n];
-            if (q > i) {
-                k = n;
-                do p = row[--k];
-                while (p > i);
-            } else {
-                for (p = row[k]; p > i; p = row[k]) k--;
+        uint32_t a = here[D + n];
+        const int neg = idx >= a;
+        if (neg) idx -= a;
+        a = here[n];
+        if (a <= idx) {                                         // no pulse at this coordinate
+            idx -= a;
+            *y++ = 0;
+        } else {
+            int kk = k;
+            const uint32_t *p = here + n;                       // p[-j * D] = U(n, k - j)
+            if (kk > n && T[(size_t)n * D + n] > idx) {         // (many pulses: skip what cannot match)
+                kk = n;
+                p = T + (size_t)n * D + n;
             }
-            i -= p;
-            *y++ = (k0 - k + s) ^ s;
-        } else {                                                         // many dimensions
-            p = row[k];
-            q = row[k + 1];
-            if (p <= i && i < q) {
-                i -= p;
-                *y++ = 0;
-            } else {
-                s = -(i >= q);
-                i -= q & (uint64_t)(int64_t)s;
-                k0 = k;
-                do p = row[--k];
-                while (p > i);
-                i -= p;
-                *y++ = (k0 - k + s) ^ s;
-            }
+            do {
+                kk--;
+                p -= D;
+            } while (*p > idx);
+            idx -= *p;
+            const int v = k - kk;
+            *y++ = (int16_t)(neg ? -v : v);
+            yy += v * v;
+            k = kk;
+            here = T + (size_t)k * D;
         }
         n--;
     }
-    uint64_t p = 2 * (uint64_t)k + 1;                                    // n == 2
-    int s = -(i >= p);
-    i -= p & (uint64_t)(int64_t)s;
-    int k0 = k;
-    k = (int)((i + 1) >> 1);
-    if (k) i -= 2 * (uint64_t)k - 1;
-    *y++ = (k0 - k + s) ^ s;
-    s = -(int)i;                                                         // n == 1
-    *y = (k + s) ^ s;
-}
-
-void expRotation1(float *X, int len, int stride, float c, float s) {       // vq.c:40-63
-    float *p = X;
-    for (int i = 0; i < len - stride; i++) {
-        const float x1 = p[0], x2 = p[stride];
-        p[stride] = c * x2 + s * x1;
-        *p++ = c * x1 - s * x2;
+    {                                                           // two coordinates left: closed forms
+        const uint32_t a = 2 * (uint32_t)k + 1;
+        const int neg = idx >= a;
+        if (neg) idx -= a;
+        const int kk = (int)((idx + 1) >> 1);
+        if (kk) idx -= 2 * (uint32_t)kk - 1;
+        const int v = k - kk;
+        *y++ = (int16_t)(neg ? -v : v);
+        *y = (int16_t)(idx ? -kk : kk);
+        yy += v * v + kk * kk;
     }
-    p = &X[len - 2 * stride - 1];
-    for (int i = len - 2 * stride - 1; i >= 0; i--) {
-        const float x1 = p[0], x2 = p[stride];
-        p[stride] = c * x2 + s * x1;
-        *p-- = c * x1 - s * x2;
+    return yy;
+}
+
+// bits -> pseudo-pulse count of a (band, size) cache (rate.h bits2pulses: a six-step bisection and a rounding rule) as a direct
+// table per cache, filled from that very function: the band loop asks this for every leaf of every frame
+struct PulseLut {
+    std::vector<uint8_t> q[(kMaxLM + 2) * kBands];
+    PulseLut() {
+        const CeltMode &m = mode48k();
+        for (int l = -1; l <= kMaxLM; l++)
+            for (int j = 0; j < kBands; j++) {
+                if (m.cacheIndex[(size_t)((l + 1) * kBands + j)] < 0) continue;   // (a band too narrow to be split to this size)
+                const uint8_t *cache = m.cacheFor(j, l);
+                const int top = cache[cache[0]] + 3;             // beyond the costliest entry the answer no longer changes
+                std::vector<uint8_t> &t = q[(l + 1) * kBands + j];
+                t.resize((size_t)top + 1);
+                for (int b = 0; b <= top; b++) t[(size_t)b] = (uint8_t)m.bits2pulses(j, l, b);
+            }
     }
-}
-
-void expRotation(float *X, int len, int dir, int stride, int K, int spread) {   // vq.c:65-111
-    static const int factorOf[3] = {15, 10, 5};
-    if (2 * K >= len || spread == kSpreadNone) return;
-    const int factor = factorOf[spread - 1];
-    // (c, s) depend on (len, K, spread) only, and a stream keeps hitting the same few hundred triples frame
-    // after frame: a small per-thread direct-mapped memo replaces the two libm cos() calls (a fifth of the
-    // whole entropy stage) by a lookup, with the very same values
-    struct Memo { uint32_t key; float c, s; };
-    static thread_local Memo memo[1024];
-    const uint32_t key = ((uint32_t)len << 12) | ((uint32_t)K << 2) | (uint32_t)spread;   // len <= 176, K <= 128: never 0
-    Memo &mm = memo[(key * 2654435761u) >> 22];
-    if (mm.key != key) {
-        const float gain = (float)(1.0f * len) / (float)(len + factor * K);
-        const float theta = .5f * (gain * gain);
-        // celt_cos_norm (mathops.h): float argument, C library cos() in double, rounded once
-        mm.c = (float)std::cos((double)((.5f * 3.141592653f) * theta));
-        mm.s = (float)std::cos((double)((.5f * 3.141592653f) * (1.0f - theta)));
-        mm.key = key;
+    int operator()(int band, int lm, int bits) const {
+        const std::vector<uint8_t> &t = q[(lm + 1) * kBands + band];
+        return t[(size_t)std::min<int>(std::max(bits, 0), (int)t.size() - 1)];
     }
-    const float c = mm.c, s = mm.s;
-    int stride2 = 0;
-    if (len >= 8 * stride) {
-        stride2 = 1;
-        while ((stride2 * stride2 + stride2) * stride + (stride >> 2) < len) stride2++;
-    }
-    len /= stride;
-    for (int i = 0; i < stride; i++) {
-        if (dir < 0) {
-            if (stride2) expRotation1(X + i * len, len, stride2, s, c);
-            expRotation1(X + i * len, len, 1, c, s);
-        } else {
-            expRotation1(X + i * len, len, 1, c, -s);
-            if (stride2) expRotation1(X + i * len, len, stride2, s, -c);
-        }
-    }
+};
+const PulseLut &pulseLut() {
+    static const PulseLut lut;
+    return lut;
 }
 
-void renormalise(float *X, int N, float gain) {                            // vq.c:354-382
-    float E = 1e-15f;
-    for (int i = 0; i < N; i++) E += X[i] * X[i];
-    const float g = (1.f / (float)std::sqrt(E)) * gain;
-    for (int i = 0; i < N; i++) X[i] = g * X[i];
-}
-
-unsigned algUnquant(float *X, int N, int K, int spread, int B, RangeDecoder &dec, float gain) {   // vq.c:327-352
-    int iy[176];
-    decodePulseVector(N, K, dec.uint((uint32_t)pvqV(N, K)), iy);
-    float Ryy = 0;
-    for (int i = 0; i < N; i++) Ryy += (float)iy[i] * (float)iy[i];
-    const float g = (1.f / (float)std::sqrt(Ryy)) * gain;                   // normalise_residual
-    for (int i = 0; i < N; i++) X[i] = g * iy[i];
-    expRotation(X, N, -1, B, K, spread);
-    if (B <= 1) return 1;                                                   // extract_collapse_mask
-    const int N0 = N / B;
-    unsigned mask = 0;
-    for (int i = 0; i < B; i++)
-        for (int j = 0; j < N0; j++) mask |= (unsigned)(iy[i * N0 + j] != 0) << i;
-    return mask;
-}
-
-// ---- band shapes: splits, folding, stereo (bands.c:541-1518, decoder side) -------------------------
-const int kOrdery[] = {1, 0, 3, 0, 2, 1, 7, 0, 4, 3, 6, 1, 5, 2, 15, 0, 8, 7, 12, 3, 11, 4, 14, 1, 9, 6, 13, 2, 10, 5};
-
-void deinterleaveHadamard(float *X, int N0, int stride, int hadamard) {
-    float tmp[176];
-    const int N = N0 * stride;
-    if (hadamard) {
-        const int *ordery = kOrdery + stride - 2;
-        for (int i = 0; i < stride; i++)
-            for (int j = 0; j < N0; j++) tmp[ordery[i] * N0 + j] = X[j * stride + i];
-    } else {
-        for (int i = 0; i < stride; i++)
-            for (int j = 0; j < N0; j++) tmp[i * N0 + j] = X[j * stride + i];
-    }
-    std::memcpy(X, tmp, sizeof(float) * N);
-}
-
-void interleaveHadamard(float *X, int N0, int stride, int hadamard) {
-    float tmp[176];
-    const int N = N0 * stride;
-    if (hadamard) {
-        const int *ordery = kOrdery + stride - 2;
-        for (int i = 0; i < stride; i++)
-            for (int j = 0; j < N0; j++) tmp[j * stride + i] = X[ordery[i] * N0 + j];
-    } else {
-        for (int i = 0; i < stride; i++)
-            for (int j = 0; j < N0; j++) tmp[j * stride + i] = X[i * N0 + j];
-    }
-    std::memcpy(X, tmp, sizeof(float) * N);
-}
-
-void haar1(float *X, int N0, int stride) {
-    N0 >>= 1;
-    for (int i = 0; i < stride; i++)
-        for (int j = 0; j < N0; j++) {
-            const float t1 = .70710678f * X[stride * 2 * j + i];
-            const float t2 = .70710678f * X[stride * (2 * j + 1) + i];
-            X[stride * 2 * j + i] = t1 + t2;
-            X[stride * (2 * j + 1) + i] = t1 - t2;
-        }
-}
-
-int bitexactCos(int x) {                                                    // bands.c:68-78
-    const int32_t tmp = (4096 + (int32_t)x * x) >> 13;
-    int x2 = (int16_t)tmp;
+// ---- angles between two halves of a band (RFC 6716 4.3.4.3; bands.c:661-832) ---------------------------------------------------
+int bitexactCos(int x) {
+    const int32_t t = (4096 + (int32_t)x * x) >> 13;
+    int x2 = (int16_t)t;
     x2 = (32767 - x2) + fracMul16(x2, (-7651 + fracMul16(x2, (8277 + fracMul16(-626, x2)))));
     return 1 + x2;
 }
-
-int bitexactLog2tan(int isin, int icos) {                                   // bands.c:80-92
+int bitexactLog2tan(int isin, int icos) {
     const int lc = ilog((uint32_t)icos), ls = ilog((uint32_t)isin);
     icos <<= 15 - lc;
     isin <<= 15 - ls;
-    return (ls - lc) * (1 << 11) + fracMul16(isin, fracMul16(isin, -2597) + 7932) -
-           fracMul16(icos, fracMul16(icos, -2597) + 7932);
+    return (ls - lc) * (1 << 11) + fracMul16(isin, fracMul16(isin, -2597) + 7932) - fracMul16(icos, fracMul16(icos, -2597) + 7932);
 }
-
-int computeQn(int N, int b, int offset, int pulseCap, int stereo) {         // bands.c:614-636
+int angleResolution(int N, int b, int offset, int pulseCap, bool stereo) {
     static const int16_t exp2Table8[8] = {16384, 17866, 19483, 21247, 23170, 25267, 27554, 30048};
     int N2 = 2 * N - 1;
     if (stereo && N == 2) N2--;
     int qb = std::min(b - pulseCap - (4 << kBitRes), (b + N2 * offset) / N2);
     qb = std::min(8 << kBitRes, qb);
-    int qn;
-    if (qb < (1 << kBitRes >> 1)) {
-        qn = 1;
-    } else {
-        qn = exp2Table8[qb & 0x7] >> (14 - (qb >> kBitRes));
-        qn = (qn + 1) >> 1 << 1;
-    }
-    return qn;
+    if (qb < (1 << kBitRes >> 1)) return 1;
+    const int qn = exp2Table8[qb & 0x7] >> (14 - (qb >> kBitRes));
+    return (qn + 1) >> 1 << 1;
 }
 
-struct BandState {
-    const CeltMode *m;
-    RangeDecoder *ec;
-    int band, intensity, spread, tfChange;
-    int32_t remainingBits;
-    uint32_t seed;
-};
+const int kHadamardOrder[] = {1, 0, 3, 0, 2, 1, 7, 0, 4, 3, 6, 1, 5, 2, 15, 0, 8, 7, 12, 3, 11, 4, 14, 1, 9, 6, 13, 2, 10, 5};
 
-struct Split {
-    int inv, imid, iside, delta, itheta, qalloc;
-};
+}  // namespace
 
-void computeTheta(BandState &ctx, Split &sp, int N, int *b, int B, int B0, int LM, int stereo, int *fill) {   // bands.c:661-832
-    const CeltMode &m = *ctx.m;
-    RangeDecoder &ec = *ctx.ec;
-    const int i = ctx.band;
-    int itheta = 0, inv = 0;
-    const int pulseCap = m.logN[i] + LM * (1 << kBitRes);
-    const int offset = (pulseCap >> 1) - (stereo && N == 2 ? kQThetaOffsetTwoPhase : kQThetaOffset);
-    int qn = computeQn(N, *b, offset, pulseCap, stereo);
-    if (stereo && i >= ctx.intensity) qn = 1;
-    const int32_t tell = (int32_t)ec.tellFrac();
-    if (qn != 1) {
-        if (stereo && N > 2) {                                              // step pdf
-            const int p0 = 3, x0 = qn / 2, ft = p0 * (x0 + 1) + x0;
-            const int fs = (int)ec.decode(ft);
-            int x;
-            if (fs < (x0 + 1) * p0) x = fs / p0;
-            else x = x0 + 1 + (fs - (x0 + 1) * p0);
-            ec.update(x <= x0 ? p0 * x : (x - 1 - x0) + (x0 + 1) * p0, x <= x0 ? p0 * (x + 1) : (x - x0) + (x0 + 1) * p0, ft);
-            itheta = x;
-        } else if (B0 > 1 || stereo) {                                      // uniform pdf
-            itheta = (int)ec.uint(qn + 1);
-        } else {                                                            // triangular pdf
-            const int ft = ((qn >> 1) + 1) * ((qn >> 1) + 1);
-            const int fm = (int)ec.decode(ft);
-            int fs, fl;
-            if (fm < ((qn >> 1) * ((qn >> 1) + 1) >> 1)) {
-                itheta = (int)(isqrt32(8 * (uint32_t)fm + 1) - 1) >> 1;
-                fs = itheta + 1;
-                fl = itheta * (itheta + 1) >> 1;
-            } else {
-                itheta = (int)(2 * (qn + 1) - isqrt32(8 * (uint32_t)(ft - fm - 1) + 1)) >> 1;
-                fs = qn + 1 - itheta;
-                fl = ft - ((qn + 1 - itheta) * (qn + 2 - itheta) >> 1);
+// ---- a frame's band shapes ---------------------------------------------------------------------------------------------------------
+// One object per decode() call: the range decoder, the allocation and the running state of the band loop (bits left, the
+// noise generator) plus views of the decoder's scratch memory.
+struct CeltDecoder::BandShaper {
+    const CeltMode &m;
+    const AllocConst &K;
+    RangeDecoder &rc;
+    Scratch &S;
+    const int LM, C, N;              // N: bins per channel
+    const int spread, intensity;
+    int32_t remaining = 0;           // bits the current band may still spend (1/8 bits)
+    uint32_t seed = 0;
+    int band = 0, tfChange = 0;
+
+    // ---- phase 1: symbols ------------------------------------------------------------------------------------------
+    struct Angle {
+        int inv, imid, iside, delta, itheta, qalloc;
+    };
+    Angle readAngle(int n, int &b, int B, int B0, int lm, bool stereo, int &fill) {
+        const int pulseCap = m.logN[band] + lm * kOneBit;
+        const int offset = (pulseCap >> 1) - (stereo && n == 2 ? kQThetaOffsetTwoPhase : kQThetaOffset);
+        int qn = angleResolution(n, b, offset, pulseCap, stereo);
+        if (stereo && band >= intensity) qn = 1;
+        const int32_t before = (int32_t)rc.tellFrac();
+        int itheta = 0, inv = 0;
+        if (qn != 1) {
+            if (stereo && n > 2) {                                        // a step density: the low angles three times as likely
+                const int p0 = 3, x0 = qn / 2, ft = p0 * (x0 + 1) + x0;
+                const int fs = (int)rc.decode(ft);
+                const int x = fs < (x0 + 1) * p0 ? fs / p0 : x0 + 1 + (fs - (x0 + 1) * p0);
+                rc.update(x <= x0 ? p0 * x : (x - 1 - x0) + (x0 + 1) * p0, x <= x0 ? p0 * (x + 1) : (x - x0) + (x0 + 1) * p0, ft);
+                itheta = x;
+            } else if (B0 > 1 || stereo) {                                // uniform
+                itheta = (int)rc.uint(qn + 1);
+            } else {                                                      // triangular
+                const int h = qn >> 1, ft = (h + 1) * (h + 1);
+                const int fm = (int)rc.decode(ft);
+                int fs, fl;
+                if (fm < (h * (h + 1) >> 1)) {
+                    itheta = (int)(isqrt32(8 * (uint32_t)fm + 1) - 1) >> 1;
+                    fs = itheta + 1;
+                    fl = itheta * (itheta + 1) >> 1;
+                } else {
+                    itheta = (int)(2 * (qn + 1) - isqrt32(8 * (uint32_t)(ft - fm - 1) + 1)) >> 1;
+                    fs = qn + 1 - itheta;
+                    fl = ft - ((qn + 1 - itheta) * (qn + 2 - itheta) >> 1);
+                }
+                rc.update(fl, fl + fs, ft);
             }
-            ec.update(fl, fl + fs, ft);
+            itheta = (int32_t)itheta * 16384 / qn;
+        } else if (stereo) {
+            inv = (b > 2 << kBitRes && remaining > 2 << kBitRes) ? rc.bitLogp(2) : 0;
         }
-        itheta = (int32_t)itheta * 16384 / qn;
-    } else if (stereo) {
-        if (*b > 2 << kBitRes && ctx.remainingBits > 2 << kBitRes) inv = ec.bitLogp(2);
-        else inv = 0;
-        itheta = 0;
-    }
-    const int qalloc = (int)ec.tellFrac() - tell;
-    *b -= qalloc;
-    int imid, iside, delta;
-    if (itheta == 0) {
-        imid = 32767; iside = 0; *fill &= (1 << B) - 1; delta = -16384;
-    } else if (itheta == 16384) {
-        imid = 0; iside = 32767; *fill &= ((1 << B) - 1) << B; delta = 16384;
-    } else {
-        imid = bitexactCos((int16_t)itheta);
-        iside = bitexactCos((int16_t)(16384 - itheta));
-        delta = fracMul16((N - 1) << 7, bitexactLog2tan(iside, imid));
-    }
-    sp = {inv, imid, iside, delta, itheta, qalloc};
-}
-
-unsigned quantBandN1(BandState &ctx, float *X, float *Y, float *lowbandOut) {     // bands.c:834-872
-    float *x = X;
-    for (int c = 0; c < 1 + (Y != nullptr); c++) {
-        int sign = 0;
-        if (ctx.remainingBits >= 1 << kBitRes) {
-            sign = (int)ctx.ec->bits(1);
-            ctx.remainingBits -= 1 << kBitRes;
-        }
-        x[0] = sign ? -1.f : 1.f;
-        x = Y;
-    }
-    if (lowbandOut) lowbandOut[0] = X[0];
-    return 1;
-}
-
-unsigned quantPartition(BandState &ctx, float *X, int N, int b, int B, float *lowband, int LM, float gain, int fill) {   // bands.c:879-1055
-    const CeltMode &m = *ctx.m;
-    const int i = ctx.band;
-    const int B0 = B;
-    unsigned cm = 0;
-    const uint8_t *cache = m.cacheFor(i, LM);
-    if (LM != -1 && b > cache[cache[0]] + 12 && N > 2) {                     // split the band in two
-        N >>= 1;
-        float *Y = X + N;
-        LM -= 1;
-        if (B == 1) fill = (fill & 1) | (fill << 1);
-        B = (B + 1) >> 1;
-        Split sp;
-        computeTheta(ctx, sp, N, &b, B, B0, LM, 0, &fill);
-        int delta = sp.delta;
-        const int itheta = sp.itheta;
-        const float mid = (1.f / 32768) * sp.imid, side = (1.f / 32768) * sp.iside;
-        if (B0 > 1 && (itheta & 0x3fff)) {
-            if (itheta > 8192) delta -= delta >> (4 - LM);
-            else delta = std::min(0, delta + (N << kBitRes >> (5 - LM)));
-        }
-        int mbits = std::max(0, std::min(b, (b - delta) / 2));
-        int sbits = b - mbits;
-        ctx.remainingBits -= sp.qalloc;
-        float *nextLowband2 = lowband ? lowband + N : nullptr;
-        int32_t rebalance = ctx.remainingBits;
-        if (mbits >= sbits) {
-            cm = quantPartition(ctx, X, N, mbits, B, lowband, LM, gain * mid, fill);
-            rebalance = mbits - (rebalance - ctx.remainingBits);
-            if (rebalance > 3 << kBitRes && itheta != 0) sbits += rebalance - (3 << kBitRes);
-            cm |= quantPartition(ctx, Y, N, sbits, B, nextLowband2, LM, gain * side, fill >> B) << (B0 >> 1);
+        const int qalloc = (int)rc.tellFrac() - before;
+        b -= qalloc;
+        Angle a{inv, 0, 0, 0, itheta, qalloc};
+        if (itheta == 0) {
+            a.imid = 32767; a.iside = 0; a.delta = -16384;
+            fill &= (1 << B) - 1;
+        } else if (itheta == 16384) {
+            a.imid = 0; a.iside = 32767; a.delta = 16384;
+            fill &= ((1 << B) - 1) << B;
         } else {
-            cm = quantPartition(ctx, Y, N, sbits, B, nextLowband2, LM, gain * side, fill >> B) << (B0 >> 1);
-            rebalance = sbits - (rebalance - ctx.remainingBits);
-            if (rebalance > 3 << kBitRes && itheta != 16384) mbits += rebalance - (3 << kBitRes);
-            cm |= quantPartition(ctx, X, N, mbits, B, lowband, LM, gain * mid, fill);
+            a.imid = bitexactCos((int16_t)itheta);
+            a.iside = bitexactCos((int16_t)(16384 - itheta));
+            a.delta = fracMul16((n - 1) << 7, bitexactLog2tan(a.iside, a.imid));
+        }
+        return a;
+    }
+
+    // a leaf of the split tree (Scratch::LeafSlot): off / n = where in the vector and how many bins, k = pulses, blocks =
+    // interleaved short blocks inside it, kind, gain, foldOff = (kFold) offset of its source inside the band's fold source
+    enum LeafKind : uint8_t { kPulses, kZero, kNoise, kFold };
+    using Leaf = Scratch::LeafSlot;
+    struct Node {                    // a pending partition of the split tree
+        int16_t off, n, foldOff;
+        int b, B, lm, fill, shift;
+        float gain;
+        // second halves wait for what the first half really spent: b += max(0, surplus - 3 bits) unless the angle is degenerate
+        bool deferred, mayGrow;
+        int firstBits;
+        int32_t remainingBefore;
+    };
+
+    // Walk the split tree of one vector (quant_partition's recursion, bands.c:879-1055, as an explicit stack) reading every
+    // angle and pulse vector; leaves go to S.leaves[nleaves..], pulses to `pulses` (same offsets as the coefficients).
+    // Returns the collapse mask of the vector.
+    unsigned readTree(int n0, int b0, int B0, bool hasFold, int lm0, float gain0, int fill0, int16_t *pulses, int &nleaves) {
+        Node stack[2 * (kMaxLM + 2)];
+        const PulseLut &lut = pulseLut();
+        const uint32_t *U32 = pvqTable32();
+        int sp = 0;
+        stack[sp++] = Node{0, (int16_t)n0, (int16_t)(hasFold ? 0 : -1), b0, B0, lm0, fill0, 0, gain0, false, false, 0, 0};
+        unsigned cm = 0;
+        while (sp > 0) {
+            Node nd = stack[--sp];
+            if (nd.deferred) {
+                const int32_t surplus = nd.firstBits - (nd.remainingBefore - remaining);
+                if (surplus > 3 << kBitRes && nd.mayGrow) nd.b += surplus - (3 << kBitRes);
+            }
+            const uint8_t *cache = m.cacheFor(band, nd.lm);
+            if (nd.lm != -1 && nd.b > cache[cache[0]] + 12 && nd.n > 2) {
+                // split in two halves and an angle
+                const int half = nd.n >> 1, lm = nd.lm - 1, Bbefore = nd.B;
+                int fill = nd.fill;
+                if (nd.B == 1) fill = (fill & 1) | (fill << 1);
+                const int B = (nd.B + 1) >> 1;
+                int b = nd.b;
+                const Angle a = readAngle(half, b, B, Bbefore, lm, false, fill);
+                const float mid = (1.f / 32768) * a.imid, side = (1.f / 32768) * a.iside;
+                int delta = a.delta;
+                if (Bbefore > 1 && (a.itheta & 0x3fff)) {
+                    if (a.itheta > 8192) delta -= delta >> (4 - lm);
+                    else delta = std::min(0, delta + (half << kBitRes >> (5 - lm)));
+                }
+                const int mbits = std::max(0, std::min(b, (b - delta) / 2)), sbits = b - mbits;
+                remaining -= a.qalloc;
+                Node lo{nd.off, (int16_t)half, nd.foldOff, mbits, B, lm, fill, nd.shift, nd.gain * mid, false, false, 0, 0};
+                Node hi{(int16_t)(nd.off + half), (int16_t)half, (int16_t)(nd.foldOff >= 0 ? nd.foldOff + half : -1), sbits, B, lm, fill >> B,
+                        nd.shift + (Bbefore >> 1), nd.gain * side, false, false, 0, 0};
+                // the half with more bits goes first; the other one is pushed first (popped second) and inherits the surplus
+                Node &first = mbits >= sbits ? lo : hi, &second = mbits >= sbits ? hi : lo;
+                second.deferred = true;
+                second.firstBits = first.b;
+                second.remainingBefore = remaining;
+                second.mayGrow = mbits >= sbits ? a.itheta != 0 : a.itheta != 16384;
+                stack[sp++] = second;
+                stack[sp++] = first;
+                continue;
+            }
+            // a leaf: as many pulses as its bits buy (fewer if the frame runs out)
+            int q = lut(band, nd.lm, nd.b);
+            int cost = q ? cache[q] + 1 : 0;
+            remaining -= cost;
+            while (remaining < 0 && q > 0) {
+                remaining += cost;
+                q--;
+                cost = q ? cache[q] + 1 : 0;
+                remaining -= cost;
+            }
+            Leaf &lf = S.leaves[nleaves++];
+            lf.off = nd.off;
+            lf.n = nd.n;
+            lf.blocks = (uint8_t)nd.B;
+            lf.gain = nd.gain;
+            lf.foldOff = -1;
+            unsigned lcm;
+            if (q != 0) {
+                const int K = CeltMode::pulsesOf(q);
+                lf.kind = kPulses;
+                lf.k = (int16_t)K;
+                int16_t *y = pulses + nd.off;
+                const uint32_t *urow = U32 + (size_t)nd.n * kPvqTableDim + K;          // codebook size V = U(n, K) + U(n, K + 1)
+                lf.yy = unrankPulses(nd.n, K, rc.uint(urow[0] + urow[1]), y);
+                if (nd.B <= 1) {
+                    lcm = 1;
+                } else {                                              // which of the interleaved blocks received a pulse
+                    const int per = nd.n / nd.B;
+                    lcm = 0;
+                    for (int i = 0; i < nd.B; i++) {
+                        int any = 0;
+                        for (int j = 0; j < per; j++) any |= y[i * per + j];
+                        lcm |= (unsigned)(any != 0) << i;
+                    }
+                }
+            } else {
+                const unsigned all = (1u << nd.B) - 1;
+                const int fill = nd.fill & (int)all;
+                lf.k = 0;
+                if (!fill) {
+                    lf.kind = kZero;
+                    lcm = 0;
+                } else if (nd.foldOff < 0) {
+                    lf.kind = kNoise;
+                    lcm = all;
+                } else {
+                    lf.kind = kFold;
+                    lf.foldOff = nd.foldOff;
+                    lcm = (unsigned)fill;
+                }
+            }
+            cm |= lcm << nd.shift;
         }
         return cm;
     }
-    int q = m.bits2pulses(i, LM, b);                                         // no split
-    int currBits = m.pulses2bits(i, LM, q);
-    ctx.remainingBits -= currBits;
-    while (ctx.remainingBits < 0 && q > 0) {
-        ctx.remainingBits += currBits;
-        q--;
-        currBits = m.pulses2bits(i, LM, q);
-        ctx.remainingBits -= currBits;
-    }
-    if (q != 0) return algUnquant(X, N, CeltMode::pulsesOf(q), ctx.spread, B, *ctx.ec, gain);
-    const unsigned cmMask = (unsigned)(1UL << B) - 1;                         // no pulses: fold or noise
-    fill &= (int)cmMask;
-    if (!fill) {
-        for (int j = 0; j < N; j++) X[j] = 0;
-        return 0;
-    }
-    if (lowband == nullptr) {
-        for (int j = 0; j < N; j++) {
-            ctx.seed = lcg(ctx.seed);
-            X[j] = (float)((int32_t)ctx.seed >> 20);
-        }
-        cm = cmMask;
-    } else {
-        for (int j = 0; j < N; j++) {
-            ctx.seed = lcg(ctx.seed);
-            const float tmp = (ctx.seed & 0x8000) ? 1.0f / 256 : -1.0f / 256;
-            X[j] = lowband[j] + tmp;
-        }
-        cm = (unsigned)fill;
-    }
-    renormalise(X, N, gain);
-    return cm;
-}
 
-unsigned quantBand(BandState &ctx, float *X, int N, int b, int B, float *lowband, int LM, float *lowbandOut, float gain,
-                   float *lowbandScratch, int fill) {                        // bands.c:1060-1191
-    const int N0 = N;
-    int N_B = N;
-    int B0 = B;
-    int timeDivide = 0, recombine = 0;
-    const int longBlocks = B0 == 1;
-    int tfChange = ctx.tfChange;
-    N_B /= B;
-    if (N == 1) return quantBandN1(ctx, X, nullptr, lowbandOut);
-    if (tfChange > 0) recombine = tfChange;
-    if (lowbandScratch && lowband && (recombine || ((N_B & 1) == 0 && tfChange < 0) || B0 > 1)) {
-        std::memcpy(lowbandScratch, lowband, sizeof(float) * N);
-        lowband = lowbandScratch;
+    // ---- what phase 1 leaves behind: a flat program for phase 2 (Scratch::vecs, ops, leaves, pulses) ----------------------
+    // Phase 1 reads the WHOLE frame's symbols first (nothing it decides depends on a coefficient's value: fold sources are
+    // named by offset, collapse masks come from the pulse vectors); phase 2 then builds every band in order.  The program is
+    // plain data -- the same records could be executed by a GPU kernel instead of the loops below.
+    using VecRec = Scratch::VecSlot;
+    using Op = Scratch::OpSlot;
+    enum OpKind : uint8_t { kOpVector, kOpSingle, kOpPair2, kOpMerge, kOpNegate, kOpAverage };
+    void emit(OpKind kind, int a, int b, int n, float f0, float f1, int i0) {
+        Op &o = S.ops[S.nops++];
+        o.kind = kind; o.a = (int16_t)a; o.b = (int16_t)b; o.n = (int16_t)n; o.f0 = f0; o.f1 = f1; o.i0 = i0;
     }
-    for (int k = 0; k < recombine; k++) {
+
+    // One vector of one band (quant_band, bands.c:1060-1191), phase 1: the resolution changes' effect on the masks, then the
+    // split tree.  x: offset of the vector in X; fold / out: offsets into the fold memory (or -1), sel: which channel's.
+    unsigned planVector(int x, int n, int b, int B, int fold, int out, int sel, float gain, int fill, bool prepFold) {
+        if (n == 1) return planSingles(x, -1, out, sel);
+        const int Bin = B;
+        int recombine = tfChange > 0 ? tfChange : 0, tf = tfChange, timeDivide = 0, nb = n / B;
         static const uint8_t bitInterleave[16] = {0, 1, 1, 1, 2, 3, 3, 3, 2, 3, 3, 3, 2, 3, 3, 3};
-        if (lowband) haar1(lowband, N >> k, 1 << k);
-        fill = bitInterleave[fill & 0xF] | bitInterleave[fill >> 4] << 2;
+        for (int k = 0; k < recombine; k++) fill = bitInterleave[fill & 0xF] | bitInterleave[fill >> 4] << 2;
+        B >>= recombine;
+        nb <<= recombine;
+        while ((nb & 1) == 0 && tf < 0) {
+            fill |= fill << B;
+            B <<= 1;
+            nb >>= 1;
+            timeDivide++;
+            tf++;
+        }
+        VecRec &v = S.vecs[S.nvecs];
+        v.x = (int16_t)x; v.n = (int16_t)n; v.fold = (int16_t)fold; v.out = (int16_t)out; v.sel = (uint8_t)sel;
+        v.recombine = (uint8_t)recombine; v.timeDivide = (uint8_t)timeDivide; v.Btree = (uint8_t)B; v.Bin = (uint8_t)Bin;
+        v.nbTree = (int16_t)nb; v.prepFold = prepFold;
+        v.leaf0 = (int16_t)S.nleaves;
+        unsigned cm = readTree(n, b, B, fold >= 0, LM, gain, fill, S.pulses + x, S.nleaves);
+        v.leaf1 = (int16_t)S.nleaves;
+        emit(kOpVector, S.nvecs++, 0, 0, 0.f, 0.f, 0);
+        // the masks follow the band back through the resolution changes
+        for (int k = 0; k < timeDivide; k++) {
+            B >>= 1;
+            cm |= cm >> B;
+        }
+        static const uint8_t bitDeinterleave[16] = {0x00, 0x03, 0x0C, 0x0F, 0x30, 0x33, 0x3C, 0x3F, 0xC0, 0xC3, 0xCC, 0xCF, 0xF0, 0xF3, 0xFC, 0xFF};
+        for (int k = 0; k < recombine; k++) cm = bitDeinterleave[cm];
+        B <<= recombine;
+        return cm & ((1u << B) - 1);
     }
-    B >>= recombine;
-    N_B <<= recombine;
-    while ((N_B & 1) == 0 && tfChange < 0) {                                  // more time resolution
-        if (lowband) haar1(lowband, N_B, B);
-        fill |= fill << B;
-        B <<= 1;
-        N_B >>= 1;
-        timeDivide++;
-        tfChange++;
-    }
-    B0 = B;
-    const int N_B0 = N_B;
-    if (B0 > 1 && lowband) deinterleaveHadamard(lowband, N_B >> recombine, B0 << recombine, longBlocks);
-    unsigned cm = quantPartition(ctx, X, N, b, B, lowband, LM, gain, fill);
-    if (B0 > 1) interleaveHadamard(X, N_B >> recombine, B0 << recombine, longBlocks);
-    N_B = N_B0;
-    B = B0;
-    for (int k = 0; k < timeDivide; k++) {
-        B >>= 1;
-        N_B <<= 1;
-        cm |= cm >> B;
-        haar1(X, N_B, B);
-    }
-    for (int k = 0; k < recombine; k++) {
-        static const uint8_t bitDeinterleave[16] = {0x00, 0x03, 0x0C, 0x0F, 0x30, 0x33, 0x3C, 0x3F,
-                                                    0xC0, 0xC3, 0xCC, 0xCF, 0xF0, 0xF3, 0xFC, 0xFF};
-        cm = bitDeinterleave[cm];
-        haar1(X, N0 >> k, 1 << k);
-    }
-    B <<= recombine;
-    if (lowbandOut) {                                                         // scaled copy for later folding
-        const float n = (float)std::sqrt((float)N0);
-        for (int j = 0; j < N0; j++) lowbandOut[j] = n * X[j];
-    }
-    cm &= (1u << B) - 1;
-    return cm;
-}
 
-void stereoMerge(float *X, float *Y, float mid, int N) {                      // bands.c:391-441
-    float xp = 0, side = 0;
-    for (int j = 0; j < N; j++) {
-        xp += Y[j] * X[j];
-        side += Y[j] * Y[j];
-    }
-    xp = mid * xp;
-    const float mid2 = mid;
-    const float El = mid2 * mid2 + side - 2 * xp;
-    const float Er = mid2 * mid2 + side + 2 * xp;
-    if (Er < 6e-4f || El < 6e-4f) {
-        std::memcpy(Y, X, sizeof(float) * N);
-        return;
-    }
-    const float lgain = 1.f / (float)std::sqrt(El), rgain = 1.f / (float)std::sqrt(Er);
-    for (int j = 0; j < N; j++) {
-        const float l = mid * X[j], r = Y[j];
-        X[j] = lgain * (l - r);
-        Y[j] = rgain * (l + r);
-    }
-}
-
-unsigned quantBandStereo(BandState &ctx, float *X, float *Y, int N, int b, int B, float *lowband, int LM, float *lowbandOut,
-                         float *lowbandScratch, int fill) {                   // bands.c:1194-1353
-    if (N == 1) return quantBandN1(ctx, X, Y, lowbandOut);
-    const int origFill = fill;
-    Split sp;
-    computeTheta(ctx, sp, N, &b, B, B, LM, 1, &fill);
-    const int inv = sp.inv, itheta = sp.itheta, delta = sp.delta, qalloc = sp.qalloc;
-    const float mid = (1.f / 32768) * sp.imid, side = (1.f / 32768) * sp.iside;
-    unsigned cm = 0;
-    if (N == 2) {
-        int mbits = b, sbits = 0;
-        if (itheta != 0 && itheta != 16384) sbits = 1 << kBitRes;
-        mbits -= sbits;
-        const int c = itheta > 8192;
-        ctx.remainingBits -= qalloc + sbits;
-        float *x2 = c ? Y : X, *y2 = c ? X : Y;
-        int sign = 0;
-        if (sbits) sign = (int)ctx.ec->bits(1);
-        sign = 1 - 2 * sign;
-        cm = quantBand(ctx, x2, N, mbits, B, lowband, LM, lowbandOut, 1.0f, lowbandScratch, origFill);
-        y2[0] = -sign * x2[1];
-        y2[1] = sign * x2[0];
-        X[0] = mid * X[0];
-        X[1] = mid * X[1];
-        Y[0] = side * Y[0];
-        Y[1] = side * Y[1];
-        float tmp = X[0];
-        X[0] = tmp - Y[0];
-        Y[0] = tmp + Y[0];
-        tmp = X[1];
-        X[1] = tmp - Y[1];
-        Y[1] = tmp + Y[1];
-    } else {
-        int mbits = std::max(0, std::min(b, (b - delta) / 2));
-        int sbits = b - mbits;
-        ctx.remainingBits -= qalloc;
-        int32_t rebalance = ctx.remainingBits;
-        if (mbits >= sbits) {
-            cm = quantBand(ctx, X, N, mbits, B, lowband, LM, lowbandOut, 1.0f, lowbandScratch, fill);
-            rebalance = mbits - (rebalance - ctx.remainingBits);
-            if (rebalance > 3 << kBitRes && itheta != 0) sbits += rebalance - (3 << kBitRes);
-            cm |= quantBand(ctx, Y, N, sbits, B, nullptr, LM, nullptr, side, nullptr, fill >> B);
-        } else {
-            cm = quantBand(ctx, Y, N, sbits, B, nullptr, LM, nullptr, side, nullptr, fill >> B);
-            rebalance = sbits - (rebalance - ctx.remainingBits);
-            if (rebalance > 3 << kBitRes && itheta != 16384) mbits += rebalance - (3 << kBitRes);
-            cm |= quantBand(ctx, X, N, mbits, B, lowband, LM, lowbandOut, 1.0f, lowbandScratch, fill);
-        }
-    }
-    if (N != 2) stereoMerge(X, Y, mid, N);
-    if (inv)
-        for (int j = 0; j < N; j++) Y[j] = -Y[j];
-    return cm;
-}
-
-void quantAllBands(const CeltMode &m, int start, int end, float *X_, float *Y_, uint8_t *collapseMasks, const int *pulses,
-                   int shortBlocks, int spread, int dualStereo, int intensity, const int *tfRes, int32_t totalBits,
-                   int32_t balance, RangeDecoder &ec, int LM, int codedBands, uint32_t *seed) {   // bands.c:1355-1518
-    const int16_t *eBands = m.eBands;
-    const int M = 1 << LM;
-    const int B = shortBlocks ? M : 1;
-    const int C = Y_ ? 2 : 1;
-    const int normOffset = M * eBands[start];
-    std::vector<float> normBuf((size_t)C * (M * eBands[kBands - 1] - normOffset));
-    float *norm = normBuf.data();
-    float *norm2 = norm + M * eBands[kBands - 1] - normOffset;
-    float *lowbandScratch = X_ + M * eBands[kBands - 1];     // the last band doubles as scratch
-    int lowbandOffset = 0;
-    int updateLowband = 1;
-    BandState ctx;
-    ctx.m = &m;
-    ctx.ec = &ec;
-    ctx.intensity = intensity;
-    ctx.seed = *seed;
-    ctx.spread = spread;
-    for (int i = start; i < end; i++) {
-        ctx.band = i;
-        const int last = (i == end - 1);
-        float *X = X_ + M * eBands[i];
-        float *Y = Y_ ? Y_ + M * eBands[i] : nullptr;
-        const int N = M * eBands[i + 1] - M * eBands[i];
-        const int32_t tell = (int32_t)ec.tellFrac();
-        if (i != start) balance -= tell;
-        const int32_t remainingBits = totalBits - tell - 1;
-        ctx.remainingBits = remainingBits;
-        int b;
-        if (i <= codedBands - 1) {
-            const int32_t currBalance = balance / std::min(3, codedBands - i);
-            b = std::max(0, std::min(16383, (int)std::min<int32_t>(remainingBits + 1, pulses[i] + currBalance)));
-        } else {
-            b = 0;
-        }
-        if (M * eBands[i] - N >= M * eBands[start] && (updateLowband || lowbandOffset == 0)) lowbandOffset = i;
-        const int tfChange = tfRes[i];
-        ctx.tfChange = tfChange;
-        if (i >= kBands) {   // i >= m->effEBands never happens for the 48 kHz mode (effEBands == nbEBands)
-            X = norm;
-            if (Y_) Y = norm;
-            lowbandScratch = nullptr;
-        }
-        if (i == end - 1) lowbandScratch = nullptr;
-        int effectiveLowband = -1;
-        unsigned xCm, yCm;
-        if (lowbandOffset != 0 && (spread != kSpreadAggressive || B > 1 || tfChange < 0)) {
-            effectiveLowband = std::max(0, M * eBands[lowbandOffset] - normOffset - N);
-            int foldStart = lowbandOffset;
-            while (M * eBands[--foldStart] > effectiveLowband + normOffset) {}
-            int foldEnd = lowbandOffset - 1;
-            while (M * eBands[++foldEnd] < effectiveLowband + normOffset + N) {}
-            xCm = yCm = 0;
-            int foldI = foldStart;
-            do {
-                xCm |= collapseMasks[foldI * C + 0];
-                yCm |= collapseMasks[foldI * C + C - 1];
-            } while (++foldI < foldEnd);
-        } else {
-            xCm = yCm = (1u << B) - 1;
-        }
-        if (dualStereo && i == intensity) {
-            dualStereo = 0;
-            for (int j = 0; j < M * eBands[i] - normOffset; j++) norm[j] = .5f * (norm[j] + norm2[j]);
-        }
-        float *lowX = effectiveLowband != -1 ? norm + effectiveLowband : nullptr;
-        float *outX = last ? nullptr : norm + M * eBands[i] - normOffset;
-        if (dualStereo) {
-            float *lowY = effectiveLowband != -1 ? norm2 + effectiveLowband : nullptr;
-            float *outY = last ? nullptr : norm2 + M * eBands[i] - normOffset;
-            xCm = quantBand(ctx, X, N, b / 2, B, lowX, LM, outX, 1.0f, lowbandScratch, (int)xCm);
-            yCm = quantBand(ctx, Y, N, b / 2, B, lowY, LM, outY, 1.0f, lowbandScratch, (int)yCm);
-        } else {
-            if (Y) xCm = quantBandStereo(ctx, X, Y, N, b, B, lowX, LM, outX, lowbandScratch, (int)(xCm | yCm));
-            else xCm = quantBand(ctx, X, N, b, B, lowX, LM, outX, 1.0f, lowbandScratch, (int)(xCm | yCm));
-            yCm = xCm;
-        }
-        collapseMasks[i * C + 0] = (uint8_t)xCm;
-        collapseMasks[i * C + C - 1] = (uint8_t)yCm;
-        balance += pulses[i] + tell;
-        updateLowband = b > (N << kBitRes);
-    }
-    *seed = ctx.seed;
-}
-
-void antiCollapse(const CeltMode &m, float *X_, const uint8_t *collapseMasks, int LM, int C, int size, int start, int end,
-                  const float *logE, const float *prev1logE, const float *prev2logE, const int *pulses, uint32_t seed) {   // bands.c:258-351
-    for (int i = start; i < end; i++) {
-        const int N0 = m.eBands[i + 1] - m.eBands[i];
-        const int depth = (1 + pulses[i]) / ((m.eBands[i + 1] - m.eBands[i]) << LM);
-        const float thresh = .5f * exp2f_ref(-.125f * depth);
-        const float sqrt1 = 1.f / (float)std::sqrt((float)(N0 << LM));
-        for (int c = 0; c < C; c++) {
-            float prev1 = prev1logE[c * kBands + i], prev2 = prev2logE[c * kBands + i];
-            if (C == 1) {
-                prev1 = std::max(prev1, prev1logE[kBands + i]);
-                prev2 = std::max(prev2, prev2logE[kBands + i]);
+    // bands of one bin: a sign per channel while bits last (bands.c:834-872)
+    unsigned planSingles(int x, int y, int out, int sel) {
+        for (int c = 0; c < 1 + (y >= 0); c++) {
+            int sign = 0;
+            if (remaining >= kOneBit) {
+                sign = (int)rc.bits(1);
+                remaining -= kOneBit;
             }
-            float Ediff = logE[c * kBands + i] - std::min(prev1, prev2);
-            Ediff = std::max(0.f, Ediff);
-            float r = 2.f * exp2f_ref(-Ediff);
-            if (LM == 3) r *= 1.41421356f;
-            r = std::min(thresh, r);
-            r = r * sqrt1;
-            float *X = X_ + c * size + (m.eBands[i] << LM);
-            int renorm = 0;
-            for (int k = 0; k < 1 << LM; k++) {
-                if (!(collapseMasks[i * C + c] & 1 << k)) {
-                    for (int j = 0; j < N0; j++) {
-                        seed = lcg(seed);
-                        X[(j << LM) + k] = (seed & 0x8000 ? r : -r);
-                    }
-                    renorm = 1;
-                }
-            }
-            if (renorm) renormalise(X, N0 << LM, 1.0f);
+            emit(kOpSingle, c ? y : x, 0, 0, sign ? -1.f : 1.f, 0.f, c == 0 ? (out >= 0 ? out | sel << 16 : -1) : -1);
         }
+        return 1;
     }
-}
 
-void denormalise(const CeltMode &m, const float *X, float *freq, const float *bandLogE, int start, int end, int C, int M) {   // bands.c:192-256
-    const int N = M * kShortMdct;
-    for (int c = 0; c < C; c++) {
-        float *f = freq + c * N;
-        const float *x = X + c * N + M * m.eBands[start];
-        for (int i = 0; i < M * m.eBands[start]; i++) *f++ = 0;
+    // both channels of a band that is coded as mid / side around an angle (quant_band_stereo, bands.c:1194-1353)
+    unsigned planStereo(int x, int y, int n, int b, int B, int fold, int out, int fill) {
+        if (n == 1) return planSingles(x, y, out, 0);
+        const int fill0 = fill;
+        const Angle a = readAngle(n, b, B, B, LM, true, fill);
+        const float mid = (1.f / 32768) * a.imid, side = (1.f / 32768) * a.iside;
+        unsigned cm;
+        if (n == 2) {
+            // two bins: the side is the mid turned by a quarter, its sign one raw bit
+            int mbits = b, sbits = 0;
+            if (a.itheta != 0 && a.itheta != 16384) sbits = kOneBit;
+            mbits -= sbits;
+            const int swap = a.itheta > 8192;
+            remaining -= a.qalloc + sbits;
+            const int sign = 1 - 2 * (sbits ? (int)rc.bits(1) : 0);
+            cm = planVector(swap ? y : x, n, mbits, B, fold, out, 0, 1.0f, fill0, true);
+            emit(kOpPair2, x, y, 0, mid, side, (sign < 0) | swap << 1);
+        } else {
+            int mbits = std::max(0, std::min(b, (b - a.delta) / 2)), sbits = b - mbits;
+            remaining -= a.qalloc;
+            const int32_t before = remaining;
+            if (mbits >= sbits) {
+                cm = planVector(x, n, mbits, B, fold, out, 0, 1.0f, fill, true);
+                const int32_t surplus = mbits - (before - remaining);
+                if (surplus > 3 << kBitRes && a.itheta != 0) sbits += surplus - (3 << kBitRes);
+                cm |= planVector(y, n, sbits, B, -1, -1, 0, side, fill >> B, false);
+            } else {
+                cm = planVector(y, n, sbits, B, -1, -1, 0, side, fill >> B, false);
+                const int32_t surplus = sbits - (before - remaining);
+                if (surplus > 3 << kBitRes && a.itheta != 16384) mbits += surplus - (3 << kBitRes);
+                cm |= planVector(x, n, mbits, B, fold, out, 0, 1.0f, fill, true);
+            }
+            emit(kOpMerge, x, y, n, mid, 0.f, 0);
+        }
+        if (a.inv) emit(kOpNegate, y, 0, n, 0.f, 0.f, 0);
+        return cm;
+    }
+
+    // the band loop (quant_all_bands, bands.c:1355-1518), phase 1
+    void plan(int start, int end, bool stereoFrame, uint8_t *masks, const BitPlan &P, int shortBlocks, const int *tfRes,
+              int32_t totalBits) {
+        const int M = 1 << LM, B = shortBlocks ? M : 1, Cn = stereoFrame ? 2 : 1;
+        const int16_t *edge = K.first;
+        const int normOffset = edge[start];
+        int foldBand = 0;                        // the lowest band whose copy may serve as fold source ("lowband_offset")
+        bool refresh = true;
+        int32_t balance = P.balance;
+        int dual = P.dualStereo;
+        S.nops = S.nvecs = S.nleaves = 0;
         for (int i = start; i < end; i++) {
-            int j = M * m.eBands[i];
-            const int bandEnd = M * m.eBands[i + 1];
-            const float lg = bandLogE[i + c * kBands] + m.eMeans[i];
-            const float g = exp2f_ref(lg);
-            do {
-                *f++ = *x++ * g;
-            } while (++j < bandEnd);
+            band = i;
+            const bool last = i == end - 1;
+            const int x = edge[i], y = stereoFrame ? N + edge[i] : -1;
+            const int n = edge[i + 1] - edge[i];
+            const int32_t tell = (int32_t)rc.tellFrac();
+            if (i != start) balance -= tell;
+            remaining = totalBits - tell - 1;
+            int b = 0;
+            if (i <= P.codedBands - 1) {
+                const int32_t share = balance / std::min(3, P.codedBands - i);
+                b = std::max(0, std::min(16383, (int)std::min<int32_t>(remaining + 1, P.shape[i] + share)));
+            }
+            if (edge[i] - n >= edge[start] && (refresh || foldBand == 0)) foldBand = i;
+            tfChange = tfRes[i];
+            // where a band without pulses copies from: the n bins below `foldBand`, and which blocks of them carry energy
+            int foldAt = -1;
+            unsigned xm, ym;
+            if (foldBand != 0 && (spread != kSpreadAggressive || B > 1 || tfChange < 0)) {
+                foldAt = std::max(0, edge[foldBand] - normOffset - n);
+                int f0 = foldBand;
+                while (edge[--f0] > foldAt + normOffset) {}
+                int f1 = foldBand - 1;
+                while (edge[++f1] < foldAt + normOffset + n) {}
+                xm = ym = 0;
+                for (int f = f0; f < f1; f++) {
+                    xm |= masks[f * Cn];
+                    ym |= masks[f * Cn + Cn - 1];
+                }
+            } else {
+                xm = ym = (1u << B) - 1;
+            }
+            if (dual && i == P.intensity) {                            // from here on the two channels fold from their mean
+                dual = 0;
+                emit(kOpAverage, edge[i] - normOffset, 0, 0, 0.f, 0.f, 0);
+            }
+            const int outAt = last ? -1 : edge[i] - normOffset;
+            if (dual) {
+                xm = planVector(x, n, b / 2, B, foldAt, outAt, 0, 1.0f, (int)xm, !last);
+                ym = planVector(y, n, b / 2, B, foldAt, outAt, 1, 1.0f, (int)ym, !last);
+            } else {
+                if (y >= 0) xm = planStereo(x, y, n, b, B, foldAt, outAt, (int)(xm | ym));
+                else xm = planVector(x, n, b, B, foldAt, outAt, 0, 1.0f, (int)(xm | ym), !last);
+                ym = xm;
+            }
+            masks[i * Cn] = (uint8_t)xm;
+            masks[i * Cn + Cn - 1] = (uint8_t)ym;
+            balance += P.shape[i] + tell;
+            refresh = b > (n << kBitRes);
         }
-        for (int i = M * m.eBands[end]; i < N; i++) *f++ = 0;
     }
-}
 
-}  // namespace
+    // ---- phase 2: coefficients ---------------------------------------------------------------------------------------
+    // the spreading rotation's angle for (len, K): two cosines per distinct triple, remembered per thread
+    static void spreadAngle(int len, int K, int spreadMode, float &c, float &s) {
+        static const int factorOf[3] = {15, 10, 5};
+        struct Memo { uint32_t key; float c, s; };
+        static thread_local Memo memo[1024];
+        const uint32_t key = ((uint32_t)len << 12) | ((uint32_t)K << 2) | (uint32_t)spreadMode;
+        Memo &mm = memo[(key * 2654435761u) >> 22];
+        if (mm.key != key) {
+            const float gain = (float)(1.0f * len) / (float)(len + factorOf[spreadMode - 1] * K);
+            const float theta = .5f * (gain * gain);
+            mm.c = (float)std::cos((double)((.5f * 3.141592653f) * theta));
+            mm.s = (float)std::cos((double)((.5f * 3.141592653f) * (1.0f - theta)));
+            mm.key = key;
+        }
+        c = mm.c;
+        s = mm.s;
+    }
+
+    // leaves [l0, l1) of vector x: pulses -> coefficients, then the spreading rotations (leaves of one shape side by side:
+    // a rotation pass is a chain of dependent steps), then the leaves without pulses (zero / noise / folded copy of `fold`)
+    void buildLeaves(float *x, const int16_t *pulses, const float *fold, int l0, int l1) {
+        float *rx[32];
+        float rc_[32], rs_[32];
+        for (int l = l0; l < l1; l++) {
+            const Leaf &lf = S.leaves[l];
+            if (lf.kind == kPulses) synth::fromPulses(x + lf.off, pulses + lf.off, lf.n, lf.gain, lf.yy);
+        }
+        if (spread != kSpreadNone) {
+            uint64_t done = 0;
+            for (int l = l0; l < l1; l++) {
+                const Leaf &a = S.leaves[l];
+                if ((done >> (l - l0) & 1) || a.kind != kPulses || 2 * a.k >= a.n) continue;
+                int cnt = 0;
+                const int stride = a.blocks, len = a.n / stride;
+                for (int q = l; q < l1 && cnt + stride <= 32; q++) {
+                    const Leaf &bq = S.leaves[q];
+                    if ((done >> (q - l0) & 1) || bq.kind != kPulses || bq.n != a.n || bq.blocks != a.blocks || 2 * bq.k >= bq.n) continue;
+                    done |= 1ull << (q - l0);
+                    float c, s;
+                    spreadAngle(bq.n, bq.k, spread, c, s);
+                    for (int i = 0; i < stride; i++) {                 // the leaf's interleaved blocks are chains of their own
+                        rx[cnt] = x + bq.off + i * len;
+                        rc_[cnt] = c;
+                        rs_[cnt] = s;
+                        cnt++;
+                    }
+                }
+                int stride2 = 0;
+                if (a.n >= 8 * stride) {
+                    stride2 = 1;
+                    while ((stride2 * stride2 + stride2) * stride + (stride >> 2) < a.n) stride2++;
+                }
+                // decoder direction (vq.c:65-111 with dir < 0): the long-stride pass first, with (s, c); then stride 1 with (c, s)
+                if (stride2) synth::rotateChains(rx, rs_, rc_, cnt, len, stride2);
+                synth::rotateChains(rx, rc_, rs_, cnt, len, 1);
+            }
+        }
+        for (int l = l0; l < l1; l++) {
+            const Leaf &lf = S.leaves[l];
+            float *o = x + lf.off;
+            switch (lf.kind) {
+            case kPulses: break;
+            case kZero:
+                std::memset(o, 0, sizeof(float) * (size_t)lf.n);
+                break;
+            case kNoise:
+                for (int j = 0; j < lf.n; j++) {
+                    seed = lcg(seed);
+                    o[j] = (float)((int32_t)seed >> 20);
+                }
+                synth::renormalise(o, lf.n, lf.gain);
+                break;
+            case kFold:
+                for (int j = 0; j < lf.n; j++) {
+                    seed = lcg(seed);
+                    o[j] = fold[lf.foldOff + j] + ((seed & 0x8000) ? 1.0f / 256 : -1.0f / 256);
+                }
+                synth::renormalise(o, lf.n, lf.gain);
+                break;
+            }
+        }
+    }
+
+    static void regroup(float *X, float *tmp, int n0, int stride, bool hadamard, bool toBlocks) {
+        // between "bin-major, blocks interleaved" and "block after block" (bands.c (de)interleave_hadamard)
+        const int n = n0 * stride;
+        const int *order = kHadamardOrder + stride - 2;
+        for (int i = 0; i < stride; i++) {
+            const int blk = hadamard ? order[i] : i;
+            if (toBlocks)
+                for (int j = 0; j < n0; j++) tmp[blk * n0 + j] = X[j * stride + i];
+            else
+                for (int j = 0; j < n0; j++) tmp[j * stride + i] = X[blk * n0 + j];
+        }
+        std::memcpy(X, tmp, sizeof(float) * (size_t)n);
+    }
+
+    // one vector: its fold source through the band's resolution changes (only if a leaf copies from it), the leaves, the
+    // resolution changes undone on the band, the scaled copy for later bands
+    void buildVector(const VecRec &v, float *X, float *norm, float *norm2) {
+        float *x = X + v.x;
+        const int n = v.n, recombine = v.recombine, timeDivide = v.timeDivide, Btree = v.Btree;
+        const bool longBlocks = v.Bin == 1;
+        const float *src = v.fold >= 0 ? (v.sel ? norm2 : norm) + v.fold : nullptr;
+        bool folds = false;
+        for (int l = v.leaf0; l < v.leaf1; l++) folds = folds || S.leaves[l].kind == kFold;
+        if (folds && (recombine || timeDivide || Btree > 1) && v.prepFold) {
+            float *w = S.foldWork;
+            std::memcpy(w, src, sizeof(float) * (size_t)n);
+            for (int k = 0; k < recombine; k++) synth::haar(w, n >> k, 1 << k);
+            int bb = v.Bin >> recombine, nn = (n / v.Bin) << recombine;
+            for (int k = 0; k < timeDivide; k++) {
+                synth::haar(w, nn, bb);
+                bb <<= 1;
+                nn >>= 1;
+            }
+            if (Btree > 1) regroup(w, S.regroupTmp, v.nbTree >> recombine, Btree << recombine, longBlocks, true);
+            src = w;
+        }
+        buildLeaves(x, S.pulses + v.x, src, v.leaf0, v.leaf1);
+        if (Btree > 1) regroup(x, S.regroupTmp, v.nbTree >> recombine, Btree << recombine, longBlocks, false);
+        int B = Btree, nb = v.nbTree;
+        for (int k = 0; k < timeDivide; k++) {
+            B >>= 1;
+            nb <<= 1;
+            synth::haar(x, nb, B);
+        }
+        for (int k = 0; k < recombine; k++) synth::haar(x, n >> k, 1 << k);
+        if (v.out >= 0) synth::scaleTo((v.sel ? norm2 : norm) + v.out, x, n, std::sqrt((float)n));   // what later bands fold from
+    }
+
+    void build(float *X, int start, uint32_t *seedInOut) {
+        float *norm = S.norm, *norm2 = S.norm + (K.first[kBands - 1] - K.first[start]);
+        seed = *seedInOut;
+        for (int q = 0; q < S.nops; q++) {
+            const Op &o = S.ops[q];
+            switch ((OpKind)o.kind) {
+            case kOpVector: buildVector(S.vecs[o.a], X, norm, norm2); break;
+            case kOpSingle:
+                X[o.a] = o.f0;
+                if (o.i0 >= 0) ((o.i0 >> 16) ? norm2 : norm)[o.i0 & 0xffff] = o.f0;
+                break;
+            case kOpPair2: {
+                float *x = X + o.a, *y = X + o.b;
+                const int sign = (o.i0 & 1) ? -1 : 1;
+                float *x2 = (o.i0 & 2) ? y : x, *y2 = (o.i0 & 2) ? x : y;
+                y2[0] = -sign * x2[1];
+                y2[1] = sign * x2[0];
+                const float x0 = o.f0 * x[0], x1 = o.f0 * x[1], y0 = o.f1 * y[0], y1 = o.f1 * y[1];
+                x[0] = x0 - y0;
+                y[0] = x0 + y0;
+                x[1] = x1 - y1;
+                y[1] = x1 + y1;
+                break;
+            }
+            case kOpMerge: synth::stereoMerge(X + o.a, X + o.b, o.f0, o.n); break;
+            case kOpNegate: synth::negate(X + o.a, o.n); break;
+            case kOpAverage:
+                for (int j = 0; j < o.a; j++) norm[j] = .5f * (norm[j] + norm2[j]);
+                break;
+            }
+        }
+        *seedInOut = seed;
+    }
+};
 
 // ---- the frame decoder --------------------------------------------------------------------------
 CeltDecoder::CeltDecoder(int channels) : m_(mode48k()), channels_(channels), streamChannels_(channels) { reset(); }
@@ -983,7 +958,7 @@ void CeltDecoder::reset() {
     rng_ = 0;
     for (int i = 0; i < 2 * kBands; i++) {
         oldBandE_[i] = 0.f;
-        oldLogE_[i] = oldLogE2_[i] = -28.f;      // celt_decoder_clean.c:855-856
+        oldLogE_[i] = oldLogE2_[i] = -28.f;
         backgroundLogE_[i] = 0.f;
     }
 }
@@ -991,148 +966,233 @@ void CeltDecoder::reset() {
 int CeltDecoder::decode(const uint8_t *data, int len, int frameSize, float *freqOut, CeltFrame &info) {
     const CeltMode &m = m_;
     const int CC = channels_, C = streamChannels_;
-    // A mono decoder may be handed stereo-coded packets (the TOC's stereo flag is per packet): both channels are
-    // decoded and then mixed down (celt_decoder_clean.c:648-652), so the work buffer is max(CC, C) channels wide
-    // (:396 ALLOC(freq, IMAX(CC,C)*N)) while the caller's holds CC.
+    // A mono decoder may be handed stereo-coded packets (the TOC's stereo flag is per packet): both channels are decoded and
+    // mixed down (celt_decoder_clean.c:648-652), so the work buffer is max(CC, C) channels wide while the caller's holds CC.
     float *freq = C > CC ? wide_ : freqOut;
     int LM;
     for (LM = 0; LM <= kMaxLM; LM++)
         if ((kShortMdct << LM) == frameSize) break;
-    if (LM > kMaxLM) return -1;
-    if (len < 0 || len > 1275 || !data || !freqOut) return -1;
-    const int M = 1 << LM;
-    const int N = M * kShortMdct;
-    const int start = start_, end = end_;
-    const int effEnd = std::min(end, kBands);
+    if (LM > kMaxLM || len < 0 || len > 1275 || !data || !freqOut) return -1;
+    const int M = 1 << LM, N = M * kShortMdct;
+    const int start = start_, end = end_, effEnd = std::min(end, kBands);
+    const AllocConst &K = allocConst(LM, C);
+    float *E = oldBandE_;
 
     RangeDecoder dec;
     dec.init(data, (uint32_t)len);
     if (C == 1)
-        for (int i = 0; i < kBands; i++) oldBandE_[i] = std::max(oldBandE_[i], oldBandE_[kBands + i]);
+        for (int i = 0; i < kBands; i++) E[i] = std::max(E[i], E[kBands + i]);
 
-    int32_t totalBits = len * 8;
-    int32_t tell = dec.tell();
-    int silence;
-    if (tell >= totalBits) silence = 1;
-    else if (tell == 1) silence = dec.bitLogp(15);
-    else silence = 0;
+    // ---- frame header: silence, post-filter, transient, intra (celt_decoder_clean.c:462-520) ----
+    int32_t totalBits = len * 8, tell = dec.tell();
+    const bool silence = tell >= totalBits ? true : tell == 1 ? dec.bitLogp(15) != 0 : false;
     if (silence) {
-        tell = len * 8;                      // pretend every remaining bit was read
+        tell = len * 8;
         dec.skipTo(tell);
     }
-    float pfGain = 0.f;
-    int pfPitch = 0, pfTapset = 0;
+    info.pfGain = 0.f;
+    info.pfPitch = info.pfTapset = 0;
     if (start == 0 && tell + 16 <= totalBits) {
         if (dec.bitLogp(1)) {
             const int octave = (int)dec.uint(6);
-            pfPitch = (16 << octave) + (int)dec.bits(4 + octave) - 1;
+            info.pfPitch = (16 << octave) + (int)dec.bits(4 + octave) - 1;
             const int qg = (int)dec.bits(3);
-            if (dec.tell() + 2 <= totalBits) pfTapset = dec.icdf(kTapsetIcdf, 2);
-            pfGain = .09375f * (qg + 1);
+            if (dec.tell() + 2 <= totalBits) info.pfTapset = dec.icdf(kTapsetIcdf, 2);
+            info.pfGain = .09375f * (qg + 1);
         }
         tell = dec.tell();
     }
-    int isTransient = 0;
+    int transient = 0;
     if (LM > 0 && tell + 3 <= totalBits) {
-        isTransient = dec.bitLogp(3);
+        transient = dec.bitLogp(3);
         tell = dec.tell();
     }
-    const int shortBlocks = isTransient ? M : 0;
-    const int intraEner = tell + 3 <= totalBits ? dec.bitLogp(3) : 0;
-    unquantCoarse(m, start, end, oldBandE_, intraEner, dec, C, LM);
+    const int intra = tell + 3 <= totalBits ? dec.bitLogp(3) : 0;
 
-    int tfRes[kBands];
-    tfDecode(start, end, isTransient, tfRes, LM, dec);
-
-    tell = dec.tell();
-    int spreadDecision = kSpreadNormal;
-    if (tell + 4 <= totalBits) spreadDecision = dec.icdf(kSpreadIcdf, 5);
-
-    int cap[kBands];
-    m.initCaps(cap, LM, C);
-    int offsets[kBands];
-    int dynallocLogp = 6;
-    totalBits <<= kBitRes;
-    tell = (int32_t)dec.tellFrac();
-    for (int i = start; i < end; i++) {
-        const int width = C * (m.eBands[i + 1] - m.eBands[i]) << LM;
-        const int quanta = std::min(width << kBitRes, std::max(6 << kBitRes, width));
-        int loopLogp = dynallocLogp;
-        int boost = 0;
-        while (tell + (loopLogp << kBitRes) < totalBits && boost < cap[i]) {
-            const int flag = dec.bitLogp(loopLogp);
-            tell = (int32_t)dec.tellFrac();
-            if (!flag) break;
-            boost += quanta;
-            totalBits -= quanta;
-            loopLogp = 1;
-        }
-        offsets[i] = boost;
-        if (boost > 0) dynallocLogp = std::max(2, dynallocLogp - 1);
+    // ---- coarse band energies: Laplace-coded residual of a two-way predictor (quant_bands.c:427-489) ----
+    {
+        const uint8_t *model = kEnergyModel[LM][intra];
+        const float coef = intra ? 0.f : kPredCoef[LM], beta = intra ? kBetaIntra : kBetaCoef[LM];
+        const int32_t budget = (int32_t)len * 8;
+        float prev[2] = {0.f, 0.f};
+        for (int i = start; i < end; i++)
+            for (int c = 0; c < C; c++) {
+                const int32_t room = budget - dec.tell();
+                int qi;
+                if (room >= 15) {
+                    const int pi = 2 * std::min(i, 20);
+                    qi = laplaceDecode(dec, model[pi] << 7, model[pi + 1] << 6);
+                } else if (room >= 2) {
+                    qi = dec.icdf(kSmallEnergyIcdf, 2);
+                    qi = (qi >> 1) ^ -(qi & 1);
+                } else {
+                    qi = room >= 1 ? -dec.bitLogp(1) : -1;
+                }
+                const float q = (float)qi;
+                float &e = E[i + c * kBands];
+                e = std::max(-9.f, e);
+                e = coef * e + prev[c] + q;
+                prev[c] = prev[c] + q - beta * q;
+            }
     }
-    int fineQuant[kBands], pulses[kBands], finePriority[kBands];
-    const int allocTrim = tell + (6 << kBitRes) <= totalBits ? dec.icdf(kTrimIcdf, 7) : 5;
+
+    // ---- time-frequency resolution per band (celt_decoder_clean.c:314-351) ----
+    int tfRes[kBands];
+    {
+        uint32_t budget = (uint32_t)len * 8, t = (uint32_t)dec.tell();
+        int logp = transient ? 2 : 4;
+        const int selectRsv = LM > 0 && t + logp + 1 <= budget;
+        budget -= selectRsv;
+        int changed = 0, cur = 0;
+        for (int i = start; i < end; i++) {
+            if (t + logp <= budget) {
+                cur ^= dec.bitLogp(logp);
+                t = (uint32_t)dec.tell();
+                changed |= cur;
+            }
+            tfRes[i] = cur;
+            logp = transient ? 4 : 5;
+        }
+        int select = 0;
+        if (selectRsv && kTfSelect[LM][4 * transient + changed] != kTfSelect[LM][4 * transient + 2 + changed]) select = dec.bitLogp(1);
+        for (int i = start; i < end; i++) tfRes[i] = kTfSelect[LM][4 * transient + 2 * select + tfRes[i]];
+    }
+    tell = dec.tell();
+    const int spread = tell + 4 <= totalBits ? dec.icdf(kSpreadIcdf, 5) : kSpreadNormal;
+
+    // ---- dynamic allocation boosts, trim, and the allocation itself ----
+    int boost[kBands];
+    int32_t total8 = totalBits << kBitRes;
+    {
+        int logp = 6;
+        int32_t t8 = (int32_t)dec.tellFrac();
+        for (int i = start; i < end; i++) {
+            const int quanta = K.boostQuantum[i];
+            int loopLogp = logp, bst = 0;
+            while (t8 + (loopLogp << kBitRes) < total8 && bst < K.cap[i]) {
+                const int flag = dec.bitLogp(loopLogp);
+                t8 = (int32_t)dec.tellFrac();
+                if (!flag) break;
+                bst += quanta;
+                total8 -= quanta;
+                loopLogp = 1;
+            }
+            boost[i] = bst;
+            if (bst > 0) logp = std::max(2, logp - 1);
+        }
+        tell = t8;
+    }
+    const int trim = tell + (6 << kBitRes) <= total8 ? dec.icdf(kTrimIcdf, 7) : 5;
     int32_t bits = (((int32_t)len * 8) << kBitRes) - (int32_t)dec.tellFrac() - 1;
-    const int antiCollapseRsv = isTransient && LM >= 2 && bits >= ((LM + 2) << kBitRes) ? (1 << kBitRes) : 0;
+    const int antiCollapseRsv = transient && LM >= 2 && bits >= ((LM + 2) << kBitRes) ? kOneBit : 0;
     bits -= antiCollapseRsv;
-    int intensity = 0, dualStereo = 0;
-    int32_t balance = 0;
-    const int codedBands = computeAllocation(m, start, end, offsets, cap, allocTrim, &intensity, &dualStereo, bits, &balance,
-                                             pulses, fineQuant, finePriority, C, LM, dec);
-    unquantFine(start, end, oldBandE_, fineQuant, dec, C);
+    BitPlan plan;
+    Allocator{K, m, start, end, C, LM, dec}.run(boost, trim, bits, plan);
 
-    uint8_t collapseMasks[2 * kBands];
-    std::memset(collapseMasks, 0, sizeof collapseMasks);
-    std::vector<float> Xbuf((size_t)C * N, 0.f);
-    float *X = Xbuf.data();
-    quantAllBands(m, start, end, X, C == 2 ? X + N : nullptr, collapseMasks, pulses, shortBlocks, spreadDecision, dualStereo,
-                  intensity, tfRes, len * (8 << kBitRes) - antiCollapseRsv, balance, dec, LM, codedBands, &rng_);
-    int antiCollapseOn = 0;
-    if (antiCollapseRsv > 0) antiCollapseOn = (int)dec.bits(1);
-    unquantFinalise(start, end, oldBandE_, fineQuant, finePriority, len * 8 - dec.tell(), dec, C);
-    if (antiCollapseOn)
-        antiCollapse(m, X, collapseMasks, LM, C, N, start, end, oldBandE_, oldLogE_, oldLogE2_, pulses, rng_);
+    // ---- fine energy (quant_bands.c:491-510) ----
+    for (int i = start; i < end; i++) {
+        const int fb = plan.fine[i];
+        if (fb <= 0) continue;
+        for (int c = 0; c < C; c++) {
+            const int q2 = (int)dec.bits(fb);
+            E[i + c * kBands] += (q2 + .5f) * (1 << (14 - fb)) * (1.f / 16384) - .5f;
+        }
+    }
 
+    // ---- band shapes ----
+    uint8_t masks[2 * kBands];
+    std::memset(masks, 0, sizeof masks);
+    float *X = scratch_.X;
+    std::memset(X, 0, sizeof(float) * (size_t)C * N);
+    BandShaper shaper{m, K, dec, scratch_, LM, C, N, spread, plan.intensity};
+    shaper.plan(start, end, C == 2, masks, plan, transient ? M : 0, tfRes, len * (8 << kBitRes) - antiCollapseRsv);   // phase 1: symbols
+    shaper.build(X, start, &rng_);                                                                                       // phase 2: floats
+
+    const int antiCollapseOn = antiCollapseRsv > 0 ? (int)dec.bits(1) : 0;
+    // ---- the bits that are left refine the energies once more, by priority (quant_bands.c:512-540) ----
+    {
+        int left = len * 8 - dec.tell();
+        for (int prio = 0; prio < 2; prio++)
+            for (int i = start; i < end && left >= C; i++) {
+                if (plan.fine[i] >= kMaxFineBits || plan.finePrio[i] != prio) continue;
+                for (int c = 0; c < C; c++) {
+                    const int q2 = (int)dec.bits(1);
+                    E[i + c * kBands] += (q2 - .5f) * (1 << (14 - plan.fine[i] - 1)) * (1.f / 16384);
+                    left--;
+                }
+            }
+    }
+    // ---- anti-collapse: short blocks that received nothing get noise at the level of the quieter of the two previous
+    // frames (bands.c:258-351) ----
+    if (antiCollapseOn) {
+        uint32_t seed = rng_;
+        for (int i = start; i < end; i++) {
+            const int n0 = K.width[i];
+            const int depth = (1 + plan.shape[i]) / K.bins[i];
+            const float thresh = .5f * exp2Ref(-.125f * depth);
+            const float sqrt1 = 1.f / std::sqrt((float)K.bins[i]);
+            for (int c = 0; c < C; c++) {
+                float p1 = oldLogE_[c * kBands + i], p2 = oldLogE2_[c * kBands + i];
+                if (C == 1) {
+                    p1 = std::max(p1, oldLogE_[kBands + i]);
+                    p2 = std::max(p2, oldLogE2_[kBands + i]);
+                }
+                const float ediff = std::max(0.f, E[c * kBands + i] - std::min(p1, p2));
+                float r = 2.f * exp2Ref(-ediff);
+                if (LM == 3) r *= 1.41421356f;
+                r = std::min(thresh, r) * sqrt1;
+                float *x = X + c * N + K.first[i];
+                bool touched = false;
+                for (int k = 0; k < M; k++) {
+                    if (masks[i * C + c] & 1 << k) continue;
+                    for (int j = 0; j < n0; j++) {
+                        seed = lcg(seed);
+                        x[(j << LM) + k] = (seed & 0x8000) ? r : -r;
+                    }
+                    touched = true;
+                }
+                if (touched) synth::renormalise(x, K.bins[i], 1.0f);
+            }
+        }
+    }
+
+    // ---- denormalisation: every band times 2^(energy + mean) (bands.c:192-256), silence, band limits, channel layout ----
     if (silence) {
-        for (int i = 0; i < C * kBands; i++) oldBandE_[i] = -28.f;
+        for (int i = 0; i < C * kBands; i++) E[i] = -28.f;
         std::memset(freq, 0, sizeof(float) * (size_t)std::max(CC, C) * N);
     } else {
-        denormalise(m, X, freq, oldBandE_, start, effEnd, C, M);
+        for (int c = 0; c < C; c++) {
+            float *f = freq + c * N;
+            std::memset(f, 0, sizeof(float) * (size_t)K.first[start]);
+            for (int i = start; i < effEnd; i++)
+                synth::scaleTo(f + K.first[i], X + c * N + K.first[i], K.bins[i], exp2Ref(E[i + c * kBands] + m.eMeans[i]));
+            std::memset(f + K.first[effEnd], 0, sizeof(float) * (size_t)(N - K.first[effEnd]));
+        }
     }
-    for (int c = 0; c < C; c++) {                                   // celt_decoder_clean.c:628-636
-        const int bound = M * m.eBands[effEnd];
-        for (int i = bound; i < N; i++) freq[c * N + i] = 0;
-    }
-    if (CC == 2 && C == 1) std::memcpy(freq + N, freq, sizeof(float) * N);          // :643-647
+    if (CC == 2 && C == 1) std::memcpy(freq + N, freq, sizeof(float) * N);
     if (CC == 1 && C == 2)
-        for (int i = 0; i < N; i++) freqOut[i] = .5f * (freq[i] + freq[N + i]);    // :648-652
+        for (int i = 0; i < N; i++) freqOut[i] = .5f * (freq[i] + freq[N + i]);
 
-    if (C == 1) std::memcpy(oldBandE_ + kBands, oldBandE_, sizeof(float) * kBands);  // :685-689
-    if (!isTransient) {                                                               // :691-703
+    // ---- what the next frame predicts from (celt_decoder_clean.c:685-718) ----
+    if (C == 1) std::memcpy(E + kBands, E, sizeof(float) * kBands);
+    if (!transient) {
         std::memcpy(oldLogE2_, oldLogE_, sizeof oldLogE_);
-        std::memcpy(oldLogE_, oldBandE_, sizeof oldBandE_);
-        for (int i = 0; i < 2 * kBands; i++) backgroundLogE_[i] = std::min(backgroundLogE_[i] + M * 0.001f, oldBandE_[i]);
+        std::memcpy(oldLogE_, E, sizeof oldBandE_);
+        for (int i = 0; i < 2 * kBands; i++) backgroundLogE_[i] = std::min(backgroundLogE_[i] + M * 0.001f, E[i]);
     } else {
-        for (int i = 0; i < 2 * kBands; i++) oldLogE_[i] = std::min(oldLogE_[i], oldBandE_[i]);
+        for (int i = 0; i < 2 * kBands; i++) oldLogE_[i] = std::min(oldLogE_[i], E[i]);
     }
-    for (int c = 0; c < 2; c++) {                                                     // :704-718
-        for (int i = 0; i < start; i++) {
-            oldBandE_[c * kBands + i] = 0;
-            oldLogE_[c * kBands + i] = oldLogE2_[c * kBands + i] = -28.f;
-        }
-        for (int i = end; i < kBands; i++) {
-            oldBandE_[c * kBands + i] = 0;
-            oldLogE_[c * kBands + i] = oldLogE2_[c * kBands + i] = -28.f;
-        }
-    }
+    for (int c = 0; c < 2; c++)
+        for (int i = 0; i < kBands; i++)
+            if (i < start || i >= end) {
+                E[c * kBands + i] = 0;
+                oldLogE_[c * kBands + i] = oldLogE2_[c * kBands + i] = -28.f;
+            }
     rng_ = dec.range();
     info.LM = LM;
     info.channels = CC;
-    info.transient = isTransient != 0;
-    info.silence = silence != 0;
-    info.pfPitch = pfPitch;
-    info.pfGain = pfGain;
-    info.pfTapset = pfTapset;
+    info.transient = transient != 0;
+    info.silence = silence;
     info.rangeFinal = rng_;
     if (dec.tell() > 8 * len) return -3;
     if (dec.error()) return -4;

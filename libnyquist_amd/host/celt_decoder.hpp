@@ -37,7 +37,24 @@ public:
     int decode(const uint8_t *data, int len, int frameSize, float *freq, CeltFrame &info);
     int channels() const { return channels_; }
 
+    // Working memory of a frame, owned by the decoder (no allocation on the decode path): the normalised coefficients of
+    // both channels, the pulse vectors of the band in hand, the copy later bands fold from, and the leaf list of the band's
+    // split tree (celt_decoder.cpp: BandShaper).
+    struct Scratch {
+        float X[2 * 960];
+        float norm[2 * 960];
+        float foldWork[192], regroupTmp[192];
+        // what phase 1 (symbols) hands to phase 2 (coefficients): the frame's pulse vectors at the offsets of their
+        // coefficients, the leaves of every split tree, a record per band vector, and the operations in execution order
+        int16_t pulses[2 * 960];
+        struct LeafSlot { int16_t off, n, k; uint8_t blocks, kind; float gain; int16_t foldOff; int32_t yy; } leaves[1024];
+        struct VecSlot { int16_t x, n, fold, out, nbTree, leaf0, leaf1; uint8_t sel, recombine, timeDivide, Btree, Bin; bool prepFold; } vecs[2 * 21 + 2];
+        struct OpSlot { uint8_t kind; int16_t a, b, n; float f0, f1; int i0; } ops[5 * 21 + 8];
+        int nleaves = 0, nvecs = 0, nops = 0;
+    };
+
 private:
+    struct BandShaper;
     const CeltMode &m_;
     int channels_;            // CC
     int streamChannels_;      // C
@@ -48,6 +65,7 @@ private:
     float oldLogE2_[2 * kBands];
     float backgroundLogE_[2 * kBands];
     float wide_[2 * 960];     // both channels of a stereo-coded packet handed to a mono decoder
+    Scratch scratch_;
 };
 
 }  // namespace nyq_host

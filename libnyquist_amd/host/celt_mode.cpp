@@ -159,6 +159,16 @@ const uint64_t *pvqTable() {
     return &g_U[0][0];
 }
 
+const uint32_t *pvqTable32() {
+    static const std::vector<uint32_t> t = [] {
+        const uint64_t *u = pvqTable();
+        std::vector<uint32_t> v((size_t)kPvqTableDim * kPvqTableDim);
+        for (size_t i = 0; i < v.size(); i++) v[i] = u[i] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)u[i];
+        return v;
+    }();
+    return t.data();
+}
+
 uint64_t pvqV(int n, int k) {
     std::call_once(g_once, buildMode);
     return rawV(n, k);

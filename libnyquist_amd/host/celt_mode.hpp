@@ -49,6 +49,10 @@ uint64_t pvqU(int n, int k);
 uint64_t pvqV(int n, int k);
 constexpr int kPvqTableDim = 178;      // widest band at LM 3 is 176 bins
 const uint64_t *pvqTable();            // U(n,k) at [n * kPvqTableDim + k], symmetric in (n,k)
+// The same numbers clamped to 32 bits (0xFFFFFFFF = "2^32 or more"): every codebook a CELT frame can name has fewer than
+// 2^32 codewords (ec_dec_uint's limit), so an index never reaches a clamped entry's value and the decoder's comparisons
+// against this table come out as against the exact one -- at half the cache footprint and with 32-bit arithmetic.
+const uint32_t *pvqTable32();
 // conservative integer log2 with `frac` fractional bits (cwrs.c:45-71)
 int log2Frac(uint32_t val, int frac);
 inline int ilog(uint32_t v) { return v ? 32 - __builtin_clz(v) : 0; }   // EC_ILOG

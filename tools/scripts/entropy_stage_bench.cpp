@@ -1,0 +1,40 @@
+// tools/scripts/entropy_stage_bench.cpp -- frames/s/thread of the CPU entropy stage (CeltDecoder::decode) on one Ogg Opus file, best of N passes,
+// and the chain of final range-coder states (one mis-decoded symbol anywhere changes it).
+//   g++ -O3 -std=c++17 -ffp-contract=off -Ilibnyquist_amd/host -o /tmp/esb tools/scripts/entropy_stage_bench.cpp libnyquist_amd/host/{celt_mode,celt_decoder,opus_stream}.cpp && /tmp/esb tests/golden/sb-reverie.opus 5
+#include <chrono>
+#include <cstdio>
+#include <fstream>
+#include <vector>
+#include "celt_decoder.hpp"
+#include "opus_stream.hpp"
+using namespace nyq_host;
+int main(int argc, char **argv) {
+    std::ifstream f(argv[1], std::ios::binary);
+    std::vector<uint8_t> raw((std::istreambuf_iterator<char>(f)), {});
+    int reps = argc > 2 ? atoi(argv[2]) : 3;
+    OggOpusFile of = parseOggOpus(raw.data(), raw.size());
+    const int CC = of.head.channels;
+    std::vector<float> freq(2 * 960);
+    double best = 1e9; long nframes = 0; unsigned long long chk = 0;
+    for (int r = 0; r < reps; r++) {
+        CeltDecoder dec(CC);
+        nframes = 0; chk = 0;
+        auto t0 = std::chrono::steady_clock::now();
+        for (const auto &pkt : of.packets) {
+            PacketFrames pf;
+            if (!parseOpusPacket(pkt.data(), (int)pkt.size(), pf)) return 1;
+            dec.setEndBand(pf.bandwidthEnd);
+            dec.setStreamChannels(pf.stereo ? 2 : 1);
+            for (const auto &fr : pf.frames) {
+                CeltFrame info;
+                if (dec.decode(fr.first, fr.second, pf.frameSize, freq.data(), info) < 0) return 2;
+                chk = chk * 1315423911ull + info.rangeFinal;
+                nframes++;
+            }
+        }
+        double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (s < best) best = s;
+    }
+    printf("%ld frames, best %.4f s = %.0f frames/s/thread, rangeFinal chain %016llx\n", nframes, best, nframes / best, chk);
+    return 0;
+}
