@@ -891,7 +891,7 @@ struct CeltDecoder::BandShaper {
         const float *src = v.fold >= 0 ? (v.sel ? norm2 : norm) + v.fold : nullptr;
         bool folds = false;
         for (int l = v.leaf0; l < v.leaf1; l++) folds = folds || S.leaves[l].kind == kFold;
-        if (folds && (recombine || timeDivide || Btree > 1) && v.prepFold) {
+        if (folds && (recombine || timeDivide || Btree > 1)) {   // (the last band transforms its source in place in the reference: same values)
             float *w = S.foldWork;
             std::memcpy(w, src, sizeof(float) * (size_t)n);
             for (int k = 0; k < recombine; k++) synth::haar(w, n >> k, 1 << k);

@@ -2,7 +2,11 @@
 // reference's own sources by oracle/Makefile with the capture tap of oracle/tap/) on an Opus file
 // and writes what the IMDCT hot path saw.  TEST INFRASTRUCTURE ONLY; produces fixtures.
 //
-//   ref_capture <file.opus> <out.bin> [max_frames]
+//   ref_capture <file.opus> <out.bin> [max_frames] [calls]
+//
+// With a fourth argument, <out.bin>.calls is written too: a digest of EVERY clt_mdct_backward call of the file, any frame
+// size, in call order -- int32 ncalls, then per call int32 shift, stride, n2; float64 sum, sum of squares; float32 the eight
+// coefficients k * n2 / 16 (the call's input is a block of the frame's freq[]: the entropy stage's whole output, digested).
 //
 // out.bin (little endian): int32 magic 'NYQC', channels, frames, total_calls_seen, float32
 // checksum (sum of decoded samples, as examples/src/Main.cpp:137-154), int64 decoded sample count,
@@ -122,6 +126,25 @@ int main(int argc, char **argv) {
         }
         std::fwrite(&nsamp, sizeof nsamp, 1, g);
         std::fwrite(data.samples.data(), sizeof(float), data.samples.size(), g);
+        std::fclose(g);
+    }
+    if (argc > 4) {
+        std::string cp = std::string(argv[2]) + ".calls";
+        FILE *g = std::fopen(cp.c_str(), "wb");
+        if (!g) return 5;
+        int32_t n = (int32_t)ncalls;
+        std::fwrite(&n, 4, 1, g);
+        for (long k = 0; k < ncalls; k++) {
+            const nyq_tap_call *q = nyq_tap_get(k);
+            int32_t iv[3] = {q->shift, q->stride, q->n2};
+            double acc[2] = {0, 0};
+            for (int j = 0; j < q->n2; j++) { acc[0] += q->in_copy[j]; acc[1] += (double)q->in_copy[j] * q->in_copy[j]; }
+            float pick[8];
+            for (int j = 0; j < 8; j++) pick[j] = q->in_copy[j * q->n2 / 16];
+            std::fwrite(iv, sizeof iv, 1, g);
+            std::fwrite(acc, sizeof acc, 1, g);
+            std::fwrite(pick, sizeof pick, 1, g);
+        }
         std::fclose(g);
     }
     std::printf("%s: channels %d, decoded samples %lld, sum %f, imdct calls recorded %ld, frames written %ld\n", argv[1], ch,

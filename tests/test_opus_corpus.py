@@ -54,6 +54,38 @@ def test_entropy_decoder_final_range_matches_reference_encoder(host, digest, nam
     assert (flags[:len(want), 3] == {120: 0, 240: 1, 480: 2, 960: 3}[frame]).all()
 
 
+@pytest.mark.parametrize("name", FAMILY0)
+def test_entropy_stage_freq_matches_the_reference_decoder(host, digest, name):
+    """freq[] of EVERY frame of every corpus file against what the reference decoder handed to its IMDCT
+    (corpus_freq_digest.npz, oracle/gen_corpus_freq_digest.py: per clt_mdct_backward call the block's sum, energy and
+    eight picked coefficients).  The final-range test above pins the symbols; this one pins the float half of the
+    entropy stage (folding, spreading, resolution changes, stereo merging, denormalisation) on the CPU tier."""
+    fd = np.load(os.path.join(GOLDEN, "corpus_freq_digest.npz"))
+    raw = open(os.path.join(GOLDEN, "corpus", name + ".opus"), "rb").read()
+    ch, frame = (int(v) for v in digest[name + "/meta"][:2])
+    nf = len(digest[name + "/ranges"])
+    rc, freq, flags, gain, rng, info = entropy_decode(host, raw, max_frames=nf + 4, channels=ch, n=frame)
+    assert rc == 0
+    M = frame // 120
+    blocks = []                                              # the reference's call order (celt_decoder_clean.c:286-311)
+    for f in range(nf):
+        if flags[f, 0] and M == 8 and ch == 2:
+            blocks += [freq[f, c, b::M] for b in range(M) for c in range(ch)]
+        elif flags[f, 0]:
+            blocks += [freq[f, c, b::M] for c in range(ch) for b in range(M)]
+        else:
+            blocks += [freq[f, c] for c in range(ch)]
+    shape, sums, pick = fd[name + "/shape"], fd[name + "/sums"], fd[name + "/pick"]
+    assert len(blocks) == len(shape)
+    scale = max(float(np.abs(freq[:nf]).max()), 1.0)
+    for k, x in enumerate(blocks):
+        assert x.size == shape[k, 2]
+        x64 = x.astype(np.float64)
+        assert abs(x64.sum() - sums[k, 0]) <= 2e-6 * scale * x.size, (k, x64.sum(), sums[k, 0])
+        assert abs((x64 ** 2).sum() - sums[k, 1]) <= 1e-5 * max(sums[k, 1], 1.0), k
+        assert np.abs(x[(np.arange(8) * x.size) // 16] - pick[k]).max() <= 2e-6 * scale, k
+
+
 def _load(host, raw):
     info = np.zeros(8, np.int64)
     n = host.nyqh_nyquistio_load_buffer(raw, len(raw), None, 0, info)
