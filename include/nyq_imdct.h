@@ -218,6 +218,49 @@ int nyq_device_download(nyq_ctx *ctx, void *host_dst, const void *d_src, size_t 
 /* destination channel src_slot repeated in dst_slot (a mapping may name one decoded channel twice) */
 int nyq_device_dup_channel(nyq_ctx *ctx, float *d_base, int cstride, int src_slot, int dst_slot, size_t nsamples);
 
+/* ---- band shapes on the device: the host sends SYMBOLS, not coefficients (round 4) ----
+ * What celt_decode_with_ec computes between the range decoder and denormalise_bands' output -- quant_all_bands'
+ * arithmetic (bands.c:1355-1518: pulse vectors to unit-norm coefficients, the spreading rotation vq.c:65-111, folding and
+ * noise filling, Haar / Hadamard resolution changes, mid / side merging) and denormalise_bands (bands.c:192-256) -- needs no
+ * bit of the stream once the SYMBOLS are known.  The host's entropy stage therefore stops at the symbols (pulse vectors as
+ * integers, the leaves of every band's split tree, a short program of vector operations, the band gains) and
+ * nyq_celt_shape_dev builds freq[] from them on the device, one wavefront per frame.  20 ms frames (LM 3), mono or stereo.
+ * One frame = one record of nyq_celt_symbol_bytes(channels) bytes:
+ *     nyq_sym_head | float gain[42] (2^(energy + mean) per band, channel-major) | nyq_sym_op ops[113] | nyq_sym_vec vecs[44] |
+ *     body: int16 pulses[channels * 960] then nyq_sym_leaf leaves[..]  --  or, with NYQ_SYM_HOST_FREQ, float freq[channels * 960]
+ * A record of zeros is a silent frame.  Offsets inside a frame are in floats of X (channel c at c * 960). */
+#define NYQ_SYM_HOST_FREQ 1          /* flags: the body holds freq[] computed on the host (anti-collapse frames, overlong leaf lists) */
+#define NYQ_SYM_MAX_OPS   113
+#define NYQ_SYM_MAX_VECS  44
+typedef struct nyq_sym_head {
+    unsigned int seed;               /* state of the noise generator when the frame's band loop starts (bands.c:61-64) */
+    unsigned short nleaves, nvecs, nops;
+    unsigned char flags, spread, start, end, channels, lm;
+    unsigned int reserved[4];
+} nyq_sym_head;                      /* 32 bytes */
+typedef struct nyq_sym_leaf {        /* a leaf of a band's split tree */
+    short off, n, k;                 /* offset inside its vector, bins, pulses */
+    unsigned char blocks, kind;      /* interleaved short blocks; 0 pulses, 1 zeros, 2 noise, 3 folded copy */
+    float gain;
+    short fold_off, pad;
+} nyq_sym_leaf;                      /* 16 bytes */
+typedef struct nyq_sym_vec {         /* one vector (one channel, or mid / side) of one band */
+    short x, n, fold, out, nb_tree, leaf0, leaf1;
+    unsigned char sel, recombine, time_divide, b_tree, b_in, pad;
+} nyq_sym_vec;                       /* 20 bytes */
+typedef struct nyq_sym_op {          /* kinds: 0 vector a | 1 single X[a] = f0 (copy to fold memory b, channel n, if b >= 0) | 2 two-bin stereo
+                                        pair a, b (mid f0, side f1, n = sign | swap << 1) | 3 merge a, b over n bins (mid f0) | 4 negate a over n |
+                                        5 average the two channels' fold memories over a bins */
+    unsigned char kind, pad;
+    short a, b, n;
+    float f0, f1;
+} nyq_sym_op;                        /* 16 bytes */
+size_t nyq_celt_symbol_bytes(int channels);
+/* d_sym [nstreams][sstride frames][record] -> d_freq [nstreams][nframes][channels][960] (dense); sstride = frames per stream
+ * in d_sym (0 = nframes).  Asynchronous on the context stream. */
+int nyq_celt_shape_dev(nyq_ctx *ctx, const void *d_sym, float *d_freq, size_t nstreams, size_t nframes, int channels,
+                       size_t sstride);
+
 /* libvorbis' mdct_backward (third_party/libvorbis/src/mdct.c:397-491) on `batch` rows: n/2 coefficients
  * in, n samples out per row, n a power of two in 64..8192 (every Vorbis block size).
  * d_in [batch][n/2], d_out [batch][n].  out[i] = sum_k in[k] cos(2 pi/n (i + 1/2 + n/4)(k + 1/2)):
@@ -276,6 +319,13 @@ int nyq_celt_frames_to_pcm_mapped(nyq_ctx *ctx, int LM, const float *freq, const
                                   const int *pf_pitch, const float *pf_gain, const int *pf_tapset,
                                   float *out, const nyq_out_desc *desc, float *state, size_t nstreams, size_t nframes,
                                   int channels, size_t frames_per_stream);
+
+/* The same with SYMBOL records in place of freq[] (LM 3; `sym` [nstreams][frames_per_stream][nyq_celt_symbol_bytes]): the
+ * band shapes are built on the device (nyq_celt_shape_dev), then the chain runs as above.  desc may be NULL (dense `out`). */
+int nyq_celt_symbols_to_pcm_mapped(nyq_ctx *ctx, const void *sym, const unsigned char *transient,
+                                   const int *pf_pitch, const float *pf_gain, const int *pf_tapset,
+                                   float *out, const nyq_out_desc *desc, float *state, size_t nstreams, size_t nframes,
+                                   int channels, size_t frames_per_stream);
 
 /* ---- the reference's operator boundary, kept verbatim ------------------- */
 /* cuda/mdct_cuda.hpp:89-91 (impl mdct_cuda.cu:314-392).  Host pointers, caller-owned.

@@ -22,6 +22,7 @@
 #include "nyq_kernels.hpp"
 #include "nyq_post_pipe.hpp"
 #include "nyq_chain_kernel.hpp"    // the one-launch frames -> PCM kernel (round 4)
+#include "nyq_shape_kernel.hpp"    // band shapes from symbol records (round 4)
 // The round-1 post-filter kernels (one wave per channel / per stereo pair) and round 2's fused chain are measured-and-
 // rejected designs kept for A/B runs: their sources live under tools/ab/ and are compiled only into the tools' build of this
 // library (-DNYQ_AB_FORMS -Itools/ab, tools/libnyq_imdct_ab.so), selected through nyq_ctx_set_option; the product has neither.
@@ -814,6 +815,37 @@ extern "C" int nyq_celt_chain_mapped_dev(nyq_ctx *ctx, int LM, const float *d_fr
                       d_hist, d_deemph, out, d_pcm, d_work, nstreams, nframes, channels, 0, reinterpret_cast<const OutDesc *>(d_desc));
 }
 
+// ---- band shapes from symbol records -------------------------------------------------------------------------------
+static_assert(sizeof(nyq_sym_head) == sizeof(SymHead) && sizeof(nyq_sym_leaf) == sizeof(SymLeaf) && sizeof(nyq_sym_vec) == sizeof(SymVec) &&
+                  sizeof(nyq_sym_op) == sizeof(SymOp) && NYQ_SYM_MAX_OPS == kSymMaxOps && NYQ_SYM_MAX_VECS == kSymMaxVecs &&
+                  offsetof(nyq_sym_head, nops) == offsetof(SymHead, nops) && offsetof(nyq_sym_head, lm) == offsetof(SymHead, lm) &&
+                  offsetof(nyq_sym_leaf, fold_off) == offsetof(SymLeaf, fold_off) && offsetof(nyq_sym_vec, b_in) == offsetof(SymVec, b_in) &&
+                  offsetof(nyq_sym_op, f1) == offsetof(SymOp, f1),
+              "nyq_sym_* (C ABI) and nyq::Sym* (kernel) are one layout");
+
+extern "C" size_t nyq_celt_symbol_bytes(int channels) { return channels == 1 || channels == 2 ? sym_bytes(channels) : 0; }
+
+static int shape_core(nyq_ctx *ctx, const void *d_sym, float *d_freq, size_t nstreams, size_t nframes, int channels, size_t sstride) {
+    if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_celt_shape_dev: ctx is NULL");
+    if (channels != 1 && channels != 2) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_shape_dev: symbol records carry mono and stereo streams");
+    if (nstreams == 0 || nframes == 0) return NYQ_OK;
+    if (!d_sym || !d_freq) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_shape_dev: NULL buffer");
+    if (sstride == 0) sstride = nframes;
+    if (sstride < nframes) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_shape_dev: sstride is smaller than nframes");
+    const size_t total = nstreams * nframes;
+    if (total > (size_t)0x7fffffff) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_shape_dev: more than 2^31 frames in one call");
+    NYQ_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(celt_shape_kernel, dim3((unsigned)total), dim3(kWave), 0, ctx->stream, static_cast<const unsigned char *>(d_sym), d_freq,
+                       (long)nstreams, (long)nframes, channels, (long)sstride);
+    NYQ_HIP(ctx, hipGetLastError());
+    return NYQ_OK;
+}
+
+extern "C" int nyq_celt_shape_dev(nyq_ctx *ctx, const void *d_sym, float *d_freq, size_t nstreams, size_t nframes, int channels,
+                                  size_t sstride) {
+    return shape_core(ctx, d_sym, d_freq, nstreams, nframes, channels, sstride);
+}
+
 extern "C" void *nyq_device_alloc(nyq_ctx *ctx, size_t bytes) {
     void *p = nullptr;
     if (!ctx || bytes == 0 || hipSetDevice(ctx->device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) return nullptr;
@@ -1123,19 +1155,23 @@ static hipError_t copy_rows(void *dst, size_t dpitch, const void *src, size_t sp
 
 // desc: per-stream destinations (HOST array of nstreams records whose `base` are DEVICE pointers) or null.  A stream with a
 // destination is written there by the kernels and is not downloaded; when EVERY stream has one, `out` may be null.
+// sym: the host input is symbol records (nyq_celt_symbol_bytes(channels) per frame) in place of freq[]: uploaded to their own
+// scratch region, turned into freq[] by the shape kernel on the context stream, then the same chain.
 static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const unsigned char *transient,
                               const int *pf_pitch, const float *pf_gain, const int *pf_tapset, float *out,
                               float *state, size_t nstreams, size_t nframes, int channels, size_t hstride,
-                              const nyq_out_desc *desc = nullptr) {
+                              const nyq_out_desc *desc = nullptr, const unsigned char *sym = nullptr) {
     if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm: ctx is NULL");
     if (LM < 0 || LM > 3) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm: LM must be 0..3");
     if (channels < 1 || channels > 255) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm: channels must be 1..255");
     if (nstreams == 0 || nframes == 0) return NYQ_OK;
     bool all_mapped = desc != nullptr;
     for (size_t k = 0; desc && k < nstreams; k++) all_mapped = all_mapped && desc[k].base != nullptr;
-    if (!freq || !pf_pitch || !pf_gain || !pf_tapset || (!out && !all_mapped))
+    if ((!freq && !sym) || !pf_pitch || !pf_gain || !pf_tapset || (!out && !all_mapped))
         return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm: NULL buffer");
     if (desc && channels > 2) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm_mapped: output descriptors serve mono and stereo streams");
+    if (sym && (LM != 3 || channels > 2)) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_symbols_to_pcm_mapped: symbol records carry 20 ms mono and stereo frames");
+    const size_t rec = sym ? sym_bytes(channels) : 0;
     NYQ_HIP(ctx, hipSetDevice(ctx->device));
     const size_t N = (size_t)120 << LM, nsc = nstreams * (size_t)channels, nfr = nstreams * nframes;
     const size_t n_x = round16f(nsc * nframes * N), n_w = round16f(nyq_celt_synth_work_floats(nstreams, nframes, channels)),
@@ -1144,7 +1180,8 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
     const size_t n_ov = round16f(nsc * NYQ_HALF_OV), n_hi = round16f(nsc * kPostHist), n_de = round16f(nsc),
                  n_pf = round16f(nstreams * 6);
     const size_t n_ds = desc ? round16f(nstreams * sizeof(nyq_out_desc) / sizeof(float)) : 0;
-    int rc = need_scratch(ctx, (3 * n_x + n_w + 3 * n_p + n_t + n_ov + n_hi + n_de + 2 * n_pf + n_ds) * sizeof(float));
+    const size_t n_sy = sym ? round16f(nfr * rec / sizeof(float)) : 0;
+    int rc = need_scratch(ctx, (3 * n_x + n_w + 3 * n_p + n_t + n_ov + n_hi + n_de + 2 * n_pf + n_ds + n_sy) * sizeof(float));
     if (rc != NYQ_OK) return rc;
     float *d_x = ctx->d_scratch, *d_pcm = d_x + n_x, *d_out = d_pcm + n_x, *d_w = d_out + n_x, *d_pg = d_w + n_w;
     int *d_pp = reinterpret_cast<int *>(d_pg + n_p), *d_pt = d_pp + n_p;
@@ -1152,6 +1189,7 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
     float *d_ov = reinterpret_cast<float *>(d_pt + n_p) + n_t, *d_hi = d_ov + n_ov, *d_de = d_hi + n_hi,
           *d_pfi = d_de + n_de, *d_pfo = d_pfi + n_pf;
     nyq_out_desc *d_ds = desc ? reinterpret_cast<nyq_out_desc *>(d_pfo + n_pf) : nullptr;
+    unsigned char *d_sy = sym ? reinterpret_cast<unsigned char *>(d_pfo + n_pf + n_ds) : nullptr;
     float *h_ov = state, *h_hi = state ? h_ov + nsc * NYQ_HALF_OV : nullptr, *h_de = state ? h_hi + nsc * kPostHist : nullptr,
           *h_pf = state ? h_de + nsc : nullptr;
     // pieces of whole streams: upload of piece k+1, kernels of piece k, download of piece k-1 at the same time
@@ -1186,7 +1224,8 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
         const size_t xw = nframes * channels * N * sizeof(float), xp = hstride * channels * N * sizeof(float);
         (void)xn;
         (void)fn;
-        NYQ_HIP(ctx, copy_rows(d_x + xo, xw, freq + hx, xp, xw, cnt, hipMemcpyHostToDevice, hs));
+        if (sym) NYQ_HIP(ctx, copy_rows(d_sy + fo * rec, nframes * rec, sym + hf * rec, hstride * rec, nframes * rec, cnt, hipMemcpyHostToDevice, hs));
+        else NYQ_HIP(ctx, copy_rows(d_x + xo, xw, freq + hx, xp, xw, cnt, hipMemcpyHostToDevice, hs));
         if (transient) NYQ_HIP(ctx, copy_rows(d_t + fo, nframes, transient + hf, hstride, nframes, cnt, hipMemcpyHostToDevice, hs));
         NYQ_HIP(ctx, copy_rows(d_pg + fo, nframes * 4, pf_gain + hf, hstride * 4, nframes * 4, cnt, hipMemcpyHostToDevice, hs));
         NYQ_HIP(ctx, copy_rows(d_pp + fo, nframes * 4, pf_pitch + hf, hstride * 4, nframes * 4, cnt, hipMemcpyHostToDevice, hs));
@@ -1200,6 +1239,12 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
         }
         NYQ_HIP(ctx, hipEventRecord(up, hs));
         NYQ_HIP(ctx, hipStreamWaitEvent(ctx->stream, up, 0));
+        if (sym && (rc = shape_core(ctx, d_sy + fo * rec, d_x + xo, cnt, nframes, channels, nframes)) != NYQ_OK) {
+            (void)hipStreamSynchronize(hs);
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipStreamSynchronize(ds);
+            return rc;
+        }
         // (one launch for 20 ms stereo frames, synthesis + post-filter through d_pcm otherwise)
         rc = chain_core(ctx, LM, d_x + xo, transient ? d_t + fo : nullptr, d_pp + fo, d_pg + fo, d_pt + fo,
                         state ? d_pfi + s0 * 6 : nullptr, state ? d_pfo + s0 * 6 : nullptr,
@@ -1241,6 +1286,16 @@ extern "C" int nyq_celt_frames_to_pcm_mapped(nyq_ctx *ctx, int LM, const float *
         return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm_mapped: frames_per_stream is smaller than nframes");
     return frames_to_pcm_core(ctx, LM, freq, transient, pf_pitch, pf_gain, pf_tapset, out, state, nstreams, nframes, channels,
                               frames_per_stream, desc);
+}
+
+extern "C" int nyq_celt_symbols_to_pcm_mapped(nyq_ctx *ctx, const void *sym, const unsigned char *transient, const int *pf_pitch,
+                                              const float *pf_gain, const int *pf_tapset, float *out, const nyq_out_desc *desc,
+                                              float *state, size_t nstreams, size_t nframes, int channels, size_t frames_per_stream) {
+    if (ctx && frames_per_stream < nframes)
+        return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_symbols_to_pcm_mapped: frames_per_stream is smaller than nframes");
+    if (ctx && !sym) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_symbols_to_pcm_mapped: NULL buffer");
+    return frames_to_pcm_core(ctx, 3, nullptr, transient, pf_pitch, pf_gain, pf_tapset, out, state, nstreams, nframes, channels,
+                              frames_per_stream, desc, static_cast<const unsigned char *>(sym));
 }
 
 extern "C" int nyq_celt_frames_to_pcm_window(nyq_ctx *ctx, int LM, const float *freq, const unsigned char *transient,

@@ -59,7 +59,11 @@ struct StreamFrames {
     std::vector<Segment> later;         // plan[1..] decoded
     // where the first segment goes (set by the layout step): slot `slot` of group `group`
     size_t group = 0, slot = 0, piece = 0;
-    float *freq0 = nullptr;
+    // input of the GPU stages, one record per frame: freq[channels][N] floats, or -- symbols -- the frame's symbol record
+    // (nyq_celt_symbol_bytes: 20 ms mono / stereo streams, whose band shapes the GPU builds itself)
+    uint8_t *in0 = nullptr;
+    size_t frameBytes = 0;
+    bool symbols = false;
     uint8_t *tr0 = nullptr;
     int *pp0 = nullptr, *pt0 = nullptr;
     float *pg0 = nullptr;
@@ -149,10 +153,15 @@ void entropyDecode(FileJob &job, OnSlice &&onSlice) {
                 if (done[k] == s.plan[seg[k]].nframes) { seg[k]++; done[k] = 0; }
                 const long i = done[k]++;
                 Segment *L = seg[k] ? &s.later[seg[k] - 1] : nullptr;
-                float *dst = (L ? L->freq.data() : s.freq0) + (size_t)i * s.channels * N;
                 CeltFrame info;
-                if (decs[k].decode(fr.first, fr.second, pf.frameSize, dst, info) < 0)
-                    throw std::runtime_error("CELT frame failed to decode");
+                int rc;
+                if (!L && s.symbols) {
+                    rc = decs[k].decodeSymbols(fr.first, fr.second, pf.frameSize, s.in0 + (size_t)i * s.frameBytes, info);
+                } else {
+                    float *dst = L ? L->freq.data() + (size_t)i * s.channels * N : reinterpret_cast<float *>(s.in0 + (size_t)i * s.frameBytes);
+                    rc = decs[k].decode(fr.first, fr.second, pf.frameSize, dst, info);
+                }
+                if (rc < 0) throw std::runtime_error("CELT frame failed to decode");
                 (L ? L->transient.data() : s.tr0)[i] = info.transient;
                 (L ? L->pfPitch.data() : s.pp0)[i] = info.pfPitch;
                 (L ? L->pfTapset.data() : s.pt0)[i] = info.pfTapset;
@@ -173,9 +182,12 @@ void entropyDecode(FileJob &job, OnSlice &&onSlice) {
 struct Group {
     bool mapped = false;                // its streams write through output records into their files' device buffers
     int ch = 0, LM = 0, dev = 0;        // dev: index into the decoder's device list
+    bool symbols = false;               // the entropy stage stops at the symbols: the GPU builds the band shapes (20 ms, <= 2 channels)
     size_t N = 0, ns = 0, maxF = 0;
+    size_t frameBytes = 0;              // of GPU input per frame: freq[ch][N] or a symbol record
     std::vector<size_t> ids;            // flattened stream indices, slot order
-    float *freq = nullptr, *out = nullptr, *pg = nullptr;
+    uint8_t *in = nullptr;
+    float *out = nullptr, *pg = nullptr;
     int *pp = nullptr, *pt = nullptr;
     uint8_t *tr = nullptr;
 };
@@ -309,6 +321,10 @@ public:
           finished_(jobs.size(), 0), streamed_(jobs.size(), 0), window_(jobs.size()), subsLeft_(jobs.size()), fileDev_(jobs.size(), 0),
           devOut_(jobs.size(), nullptr), ready_((size_t)ndev), gpuBusy_((size_t)(ndev * feedersPerDev), 0.0) {}
 
+    // 20 ms mono / stereo streams hand SYMBOL records to the GPU (their band shapes are built there); off: freq[] as for every other shape
+    bool symbolRecords_ = true;
+    bool symbolRecords() const { return symbolRecords_; }
+
     // returns when every file of the sub-batch is decoded (or has its error set); throws if the GPU failed
     void run() {
         const auto tb = std::chrono::steady_clock::now();
@@ -410,6 +426,9 @@ private:
                 groups_.back().N = (size_t)120 << std::get<1>(key);
                 groups_.back().dev = dev;
                 groups_.back().mapped = mapped;
+                groups_.back().symbols = symbolRecords() && groups_.back().LM == 3 && groups_.back().ch <= 2;
+                groups_.back().frameBytes = groups_.back().symbols ? nyq_celt_symbol_bytes(groups_.back().ch)
+                                                                   : (size_t)groups_.back().ch * groups_.back().N * sizeof(float);
             }
             Group &g = groups_[it->second];
             sf(i).group = it->second;
@@ -421,7 +440,7 @@ private:
         for (Group &g : groups_) {
             g.ns = g.ids.size();
             const size_t x = g.ns * g.maxF * g.ch * g.N * sizeof(float), q = g.ns * g.maxF;
-            bytes[(size_t)g.dev] += (g.mapped ? 1 : 2) * align256(x) + 3 * align256(q * 4) + align256(q);   // (mapped: no dense output)
+            bytes[(size_t)g.dev] += align256(q * g.frameBytes) + (g.mapped ? 0 : 1) * align256(x) + 3 * align256(q * 4) + align256(q);   // (mapped: no dense output)
         }
         std::vector<char *> bases((size_t)ndev_, nullptr);
         for (int d = 0; d < ndev_; d++)
@@ -430,7 +449,7 @@ private:
             Group &g = groups_[gi];
             char *&base = bases[(size_t)g.dev];
             const size_t x = g.ns * g.maxF * g.ch * g.N * sizeof(float), q = g.ns * g.maxF;
-            g.freq = (float *)base; base += align256(x);
+            g.in = (uint8_t *)base; base += align256(q * g.frameBytes);
             g.out = nullptr;
             if (!g.mapped) { g.out = (float *)base; base += align256(x); }
             g.pg = (float *)base; base += align256(q * 4);
@@ -443,7 +462,7 @@ private:
             std::memset(g.tr, 0, q);
             // ~24 MB of freq per piece, but never fewer streams than decoding threads: long streams finish in rounds
             // of `threads` files, and the GPU's post-filter (one sequential wave per channel) wants them together
-            const size_t per = std::max<size_t>((size_t)std::max(1, threads_), kPieceBytes / std::max<size_t>(1, g.maxF * g.ch * g.N * sizeof(float)));
+            const size_t per = std::max<size_t>((size_t)std::max(1, threads_), kPieceBytes / std::max<size_t>(1, g.maxF * g.frameBytes));
             for (size_t k0 = 0; k0 < g.ns; k0 += per) {
                 pieces_.emplace_back();
                 Piece &p = pieces_.back();
@@ -452,7 +471,7 @@ private:
                 p.k1 = std::min(g.ns, k0 + per);
                 // time slices: multiples of 64 frames (the synthesis kernels' in-wave carry chains then restart at the
                 // same frames as in one call over the whole length: bit-identical results whatever the slicing)
-                const size_t frame_bytes = (p.k1 - p.k0) * g.ch * g.N * sizeof(float);
+                const size_t frame_bytes = (p.k1 - p.k0) * g.frameBytes;
                 p.sliceLen = g.maxF;
                 if (g.maxF * frame_bytes > (kSliceBytes * 3) / 2) p.sliceLen = std::max<size_t>(64, (kSliceBytes / frame_bytes) & ~(size_t)63);
                 p.nslices = (g.maxF + p.sliceLen - 1) / p.sliceLen;
@@ -467,7 +486,9 @@ private:
                 while (!(pieces_[pi].group == gi && k >= pieces_[pi].k0 && k < pieces_[pi].k1)) pi++;
                 StreamFrames &s = sf(g.ids[k]);
                 s.piece = pi;
-                s.freq0 = g.freq + k * g.maxF * g.ch * g.N;
+                s.in0 = g.in + k * g.maxF * g.frameBytes;
+                s.frameBytes = g.frameBytes;
+                s.symbols = g.symbols;
                 s.tr0 = g.tr + k * g.maxF;
                 s.pp0 = g.pp + k * g.maxF;
                 s.pt0 = g.pt + k * g.maxF;
@@ -567,7 +588,7 @@ private:
         for (StreamFrames &s : job.subs) {
             const Group &g = groups_[s.group];
             const size_t have = job.error.empty() ? (size_t)s.plan[0].nframes : 0;   // a failed file plays as silence
-            std::memset(s.freq0 + have * g.ch * g.N, 0, (g.maxF - have) * g.ch * g.N * sizeof(float));
+            std::memset(s.in0 + have * g.frameBytes, 0, (g.maxF - have) * g.frameBytes);   // (a record of zeros is a silent frame too)
             if (!job.error.empty()) {
                 std::memset(s.tr0, 0, g.maxF);
                 std::memset(s.pp0, 0, g.maxF * 4);
@@ -618,17 +639,21 @@ private:
             const auto c0 = std::chrono::steady_clock::now();
             try {
                 int rc;
-                if (g.mapped) {
-                    // every stream of the piece writes its samples of this slice straight into its file's interleaved
-                    // device buffer: channel slot, pre-skip / end trim and header gain are in the record
-                    std::vector<nyq_out_desc> desc(p.k1 - p.k0);
-                    for (size_t k = p.k0; k < p.k1; k++) desc[k - p.k0] = recordOf(g.ids[k], (int64_t)(f0 * g.N));
-                    rc = nyq_celt_frames_to_pcm_mapped(ctx, g.LM, g.freq + so * g.ch * g.N, g.tr + so, g.pp + so, g.pg + so, g.pt + so, nullptr,
-                                                       desc.data(), p.state.empty() ? nullptr : p.state.data(), p.k1 - p.k0, len, g.ch, g.maxF);
+                // every stream of a mapped piece writes its samples of this slice straight into its file's interleaved
+                // device buffer: channel slot, pre-skip / end trim and header gain are in the record
+                std::vector<nyq_out_desc> desc(g.mapped ? p.k1 - p.k0 : 0);
+                for (size_t k = p.k0; k < p.k1 && g.mapped; k++) desc[k - p.k0] = recordOf(g.ids[k], (int64_t)(f0 * g.N));
+                const uint8_t *in = g.in + so * g.frameBytes;
+                float *out = g.mapped ? nullptr : g.out + so * g.ch * g.N, *state = p.state.empty() ? nullptr : p.state.data();
+                if (g.symbols) {
+                    rc = nyq_celt_symbols_to_pcm_mapped(ctx, in, g.tr + so, g.pp + so, g.pg + so, g.pt + so, out, g.mapped ? desc.data() : nullptr,
+                                                        state, p.k1 - p.k0, len, g.ch, g.maxF);
+                } else if (g.mapped) {
+                    rc = nyq_celt_frames_to_pcm_mapped(ctx, g.LM, reinterpret_cast<const float *>(in), g.tr + so, g.pp + so, g.pg + so, g.pt + so,
+                                                       nullptr, desc.data(), state, p.k1 - p.k0, len, g.ch, g.maxF);
                 } else {
-                    rc = nyq_celt_frames_to_pcm_window(ctx, g.LM, g.freq + so * g.ch * g.N, g.tr + so, g.pp + so, g.pg + so, g.pt + so,
-                                                       g.out + so * g.ch * g.N, p.state.empty() ? nullptr : p.state.data(), p.k1 - p.k0, len,
-                                                       g.ch, g.maxF);
+                    rc = nyq_celt_frames_to_pcm_window(ctx, g.LM, reinterpret_cast<const float *>(in), g.tr + so, g.pp + so, g.pg + so, g.pt + so,
+                                                       out, state, p.k1 - p.k0, len, g.ch, g.maxF);
                 }
                 if (rc != NYQ_OK) throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(ctx));
                 // the GPU part of the slice is done: the piece's next slice may start (its kernels only need the
@@ -717,8 +742,11 @@ private:
             std::vector<float> st1(nyq_celt_state_floats(1, g.ch), 0.f);
             if ((size_t)s.plan[0].nframes != g.maxF) {
                 std::vector<float> out1((size_t)s.plan[0].nframes * g.N * g.ch);
-                if (nyq_celt_frames_to_pcm(ctx, g.LM, s.freq0, s.tr0, s.pp0, s.pg0, s.pt0, out1.data(), st1.data(), 1,
-                                           (size_t)s.plan[0].nframes, g.ch) != NYQ_OK)
+                const size_t nf0 = (size_t)s.plan[0].nframes;
+                if ((g.symbols ? nyq_celt_symbols_to_pcm_mapped(ctx, s.in0, s.tr0, s.pp0, s.pg0, s.pt0, out1.data(), nullptr, st1.data(), 1, nf0,
+                                                                g.ch, nf0)
+                               : nyq_celt_frames_to_pcm(ctx, g.LM, reinterpret_cast<const float *>(s.in0), s.tr0, s.pp0, s.pg0, s.pt0, out1.data(),
+                                                        st1.data(), 1, nf0, g.ch)) != NYQ_OK)
                     throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(ctx));
             } else {
                 stateOfStream(p.state.data(), p.k1 - p.k0, g.ch, k - p.k0, st1.data());
@@ -891,6 +919,7 @@ BatchOpusDecoder::BatchOpusDecoder(const std::vector<int> &devices) : devices_(d
         const long long v = std::atoll(e);
         if (v > 0) stagingBudget_ = (size_t)v;
     }
+    if (const char *e = std::getenv("NYQ_HOST_SYMBOLS")) symbolRecords_ = std::atoi(e) != 0;   // (A/B switch, read once like the budget)
     const int ndev = nyq_device_count();
     for (int d : devices_)
         if (d < 0 || d >= ndev)
@@ -1008,8 +1037,11 @@ void BatchOpusDecoder::decodeImpl(const std::vector<const std::vector<uint8_t> *
         };
         auto estimate = [&]() {
             size_t bytes = 0;
-            for (const auto &kv : shape)
-                bytes += kv.second.first * kv.second.second * (size_t)kv.first.first * ((size_t)120 << kv.first.second) * 2 * sizeof(float);
+            for (const auto &kv : shape) {
+                const size_t pcm = (size_t)kv.first.first * ((size_t)120 << kv.first.second) * sizeof(float);
+                const size_t in = symbolRecords_ && kv.first.second == 3 && kv.first.first <= 2 ? nyq_celt_symbol_bytes(kv.first.first) : pcm;
+                bytes += kv.second.first * kv.second.second * (in + pcm);
+            }
             return bytes;
         };
         for (size_t i = 0; i < nfiles; i++) {
@@ -1050,6 +1082,7 @@ void BatchOpusDecoder::decodeImpl(const std::vector<const std::vector<uint8_t> *
                     out[i].pcm.clear();
                 }
         SubBatch sb(jobs, out, members, ctx_.data(), (int)devices_.size(), kFeeders, threads, arenaFn, devArenaFn);
+        sb.symbolRecords_ = symbolRecords_;
         sb.run();
         cpuSecs += sb.cpuSeconds;
         tailSecs += sb.tailSeconds;

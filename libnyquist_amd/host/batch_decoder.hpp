@@ -66,6 +66,10 @@ public:
     static constexpr int kFeedersPerDevice = 6;   // GPU contexts / feeder threads per device: pieces in flight at once
     // page-locked staging memory a sub-batch may use (default 6 GiB, or NYQ_BATCH_BYTES as it stood at construction)
     void setStagingBudget(size_t bytes) { if (bytes) stagingBudget_ = bytes; }
+    // 20 ms mono / stereo streams: the entropy stage stops at the symbols and the GPU builds the band shapes
+    // (nyq_celt_symbols_to_pcm_mapped); off = freq[] built on the host as for every other frame size.  Default on
+    // (NYQ_HOST_SYMBOLS=0 at construction turns it off: the A/B switch of bench.py's file legs).
+    void setSymbolRecords(bool on) { symbolRecords_ = on; }
 
     // give the page-locked staging memory back if it has grown beyond `keepBytes` (a pooled decoder should not sit
     // on gigabytes of pinned memory after one big job)
@@ -84,6 +88,7 @@ private:
     };
     std::vector<int> devices_;
     size_t stagingBudget_ = (size_t)6 << 30;
+    bool symbolRecords_ = true;
     std::vector<void *> ctx_;                 // nyq_ctx*, device d's feeders at [d * kFeeders, (d + 1) * kFeeders)
     std::vector<Arena> arenas_;
     std::vector<Arena> devArenas_;            // per device: device memory (Arena::pinned unused)

@@ -20,6 +20,7 @@
 #include <cstring>
 #include <vector>
 
+#include "../../include/nyq_imdct.h"
 #include "celt_synth.hpp"
 
 namespace nyq_host {
@@ -576,7 +577,9 @@ struct CeltDecoder::BandShaper {
                 cost = q ? cache[q] + 1 : 0;
                 remaining -= cost;
             }
-            Leaf &lf = S.leaves[nleaves++];
+            const int leafIndex = nleaves++;
+            Leaf &lf = S.leaves[leafIndex];
+            lf.pad = 0;
             lf.off = nd.off;
             lf.n = nd.n;
             lf.blocks = (uint8_t)nd.B;
@@ -589,7 +592,7 @@ struct CeltDecoder::BandShaper {
                 lf.k = (int16_t)K;
                 int16_t *y = pulses + nd.off;
                 const uint32_t *urow = U32 + (size_t)nd.n * kPvqTableDim + K;          // codebook size V = U(n, K) + U(n, K + 1)
-                lf.yy = unrankPulses(nd.n, K, rc.uint(urow[0] + urow[1]), y);
+                S.leafEnergy[leafIndex] = unrankPulses(nd.n, K, rc.uint(urow[0] + urow[1]), y);
                 if (nd.B <= 1) {
                     lcm = 1;
                 } else {                                              // which of the interleaved blocks received a pulse
@@ -629,14 +632,17 @@ struct CeltDecoder::BandShaper {
     using VecRec = Scratch::VecSlot;
     using Op = Scratch::OpSlot;
     enum OpKind : uint8_t { kOpVector, kOpSingle, kOpPair2, kOpMerge, kOpNegate, kOpAverage };
-    void emit(OpKind kind, int a, int b, int n, float f0, float f1, int i0) {
+    // kOpVector: a = index of the vector | kOpSingle: X[a] = f0, copied to fold memory b of channel n if b >= 0 |
+    // kOpPair2: bins a, b, mid f0, side f1, n = sign | swap << 1 | kOpMerge: a, b over n bins, mid f0 | kOpNegate: a over n |
+    // kOpAverage: the two channels' fold memories over a bins
+    void emit(OpKind kind, int a, int b, int n, float f0, float f1) {
         Op &o = S.ops[S.nops++];
-        o.kind = kind; o.a = (int16_t)a; o.b = (int16_t)b; o.n = (int16_t)n; o.f0 = f0; o.f1 = f1; o.i0 = i0;
+        o.kind = kind; o.pad = 0; o.a = (int16_t)a; o.b = (int16_t)b; o.n = (int16_t)n; o.f0 = f0; o.f1 = f1;
     }
 
     // One vector of one band (quant_band, bands.c:1060-1191), phase 1: the resolution changes' effect on the masks, then the
     // split tree.  x: offset of the vector in X; fold / out: offsets into the fold memory (or -1), sel: which channel's.
-    unsigned planVector(int x, int n, int b, int B, int fold, int out, int sel, float gain, int fill, bool prepFold) {
+    unsigned planVector(int x, int n, int b, int B, int fold, int out, int sel, float gain, int fill) {
         if (n == 1) return planSingles(x, -1, out, sel);
         const int Bin = B;
         int recombine = tfChange > 0 ? tfChange : 0, tf = tfChange, timeDivide = 0, nb = n / B;
@@ -654,11 +660,11 @@ struct CeltDecoder::BandShaper {
         VecRec &v = S.vecs[S.nvecs];
         v.x = (int16_t)x; v.n = (int16_t)n; v.fold = (int16_t)fold; v.out = (int16_t)out; v.sel = (uint8_t)sel;
         v.recombine = (uint8_t)recombine; v.timeDivide = (uint8_t)timeDivide; v.Btree = (uint8_t)B; v.Bin = (uint8_t)Bin;
-        v.nbTree = (int16_t)nb; v.prepFold = prepFold;
+        v.nbTree = (int16_t)nb; v.pad = 0;
         v.leaf0 = (int16_t)S.nleaves;
         unsigned cm = readTree(n, b, B, fold >= 0, LM, gain, fill, S.pulses + x, S.nleaves);
         v.leaf1 = (int16_t)S.nleaves;
-        emit(kOpVector, S.nvecs++, 0, 0, 0.f, 0.f, 0);
+        emit(kOpVector, S.nvecs++, 0, 0, 0.f, 0.f);
         // the masks follow the band back through the resolution changes
         for (int k = 0; k < timeDivide; k++) {
             B >>= 1;
@@ -678,7 +684,7 @@ struct CeltDecoder::BandShaper {
                 sign = (int)rc.bits(1);
                 remaining -= kOneBit;
             }
-            emit(kOpSingle, c ? y : x, 0, 0, sign ? -1.f : 1.f, 0.f, c == 0 ? (out >= 0 ? out | sel << 16 : -1) : -1);
+            emit(kOpSingle, c ? y : x, c == 0 ? out : -1, sel, sign ? -1.f : 1.f, 0.f);
         }
         return 1;
     }
@@ -698,26 +704,26 @@ struct CeltDecoder::BandShaper {
             const int swap = a.itheta > 8192;
             remaining -= a.qalloc + sbits;
             const int sign = 1 - 2 * (sbits ? (int)rc.bits(1) : 0);
-            cm = planVector(swap ? y : x, n, mbits, B, fold, out, 0, 1.0f, fill0, true);
-            emit(kOpPair2, x, y, 0, mid, side, (sign < 0) | swap << 1);
+            cm = planVector(swap ? y : x, n, mbits, B, fold, out, 0, 1.0f, fill0);
+            emit(kOpPair2, x, y, (sign < 0) | swap << 1, mid, side);
         } else {
             int mbits = std::max(0, std::min(b, (b - a.delta) / 2)), sbits = b - mbits;
             remaining -= a.qalloc;
             const int32_t before = remaining;
             if (mbits >= sbits) {
-                cm = planVector(x, n, mbits, B, fold, out, 0, 1.0f, fill, true);
+                cm = planVector(x, n, mbits, B, fold, out, 0, 1.0f, fill);
                 const int32_t surplus = mbits - (before - remaining);
                 if (surplus > 3 << kBitRes && a.itheta != 0) sbits += surplus - (3 << kBitRes);
-                cm |= planVector(y, n, sbits, B, -1, -1, 0, side, fill >> B, false);
+                cm |= planVector(y, n, sbits, B, -1, -1, 0, side, fill >> B);
             } else {
-                cm = planVector(y, n, sbits, B, -1, -1, 0, side, fill >> B, false);
+                cm = planVector(y, n, sbits, B, -1, -1, 0, side, fill >> B);
                 const int32_t surplus = sbits - (before - remaining);
                 if (surplus > 3 << kBitRes && a.itheta != 16384) mbits += surplus - (3 << kBitRes);
-                cm |= planVector(x, n, mbits, B, fold, out, 0, 1.0f, fill, true);
+                cm |= planVector(x, n, mbits, B, fold, out, 0, 1.0f, fill);
             }
-            emit(kOpMerge, x, y, n, mid, 0.f, 0);
+            emit(kOpMerge, x, y, n, mid, 0.f);
         }
-        if (a.inv) emit(kOpNegate, y, 0, n, 0.f, 0.f, 0);
+        if (a.inv) emit(kOpNegate, y, 0, n, 0.f, 0.f);
         return cm;
     }
 
@@ -766,15 +772,15 @@ struct CeltDecoder::BandShaper {
             }
             if (dual && i == P.intensity) {                            // from here on the two channels fold from their mean
                 dual = 0;
-                emit(kOpAverage, edge[i] - normOffset, 0, 0, 0.f, 0.f, 0);
+                emit(kOpAverage, edge[i] - normOffset, 0, 0, 0.f, 0.f);
             }
             const int outAt = last ? -1 : edge[i] - normOffset;
             if (dual) {
-                xm = planVector(x, n, b / 2, B, foldAt, outAt, 0, 1.0f, (int)xm, !last);
-                ym = planVector(y, n, b / 2, B, foldAt, outAt, 1, 1.0f, (int)ym, !last);
+                xm = planVector(x, n, b / 2, B, foldAt, outAt, 0, 1.0f, (int)xm);
+                ym = planVector(y, n, b / 2, B, foldAt, outAt, 1, 1.0f, (int)ym);
             } else {
                 if (y >= 0) xm = planStereo(x, y, n, b, B, foldAt, outAt, (int)(xm | ym));
-                else xm = planVector(x, n, b, B, foldAt, outAt, 0, 1.0f, (int)(xm | ym), !last);
+                else xm = planVector(x, n, b, B, foldAt, outAt, 0, 1.0f, (int)(xm | ym));
                 ym = xm;
             }
             masks[i * Cn] = (uint8_t)xm;
@@ -810,7 +816,7 @@ struct CeltDecoder::BandShaper {
         float rc_[32], rs_[32];
         for (int l = l0; l < l1; l++) {
             const Leaf &lf = S.leaves[l];
-            if (lf.kind == kPulses) synth::fromPulses(x + lf.off, pulses + lf.off, lf.n, lf.gain, lf.yy);
+            if (lf.kind == kPulses) synth::fromPulses(x + lf.off, pulses + lf.off, lf.n, lf.gain, S.leafEnergy[l]);
         }
         if (spread != kSpreadNone) {
             uint64_t done = 0;
@@ -925,12 +931,12 @@ struct CeltDecoder::BandShaper {
             case kOpVector: buildVector(S.vecs[o.a], X, norm, norm2); break;
             case kOpSingle:
                 X[o.a] = o.f0;
-                if (o.i0 >= 0) ((o.i0 >> 16) ? norm2 : norm)[o.i0 & 0xffff] = o.f0;
+                if (o.b >= 0) (o.n ? norm2 : norm)[o.b] = o.f0;
                 break;
             case kOpPair2: {
                 float *x = X + o.a, *y = X + o.b;
-                const int sign = (o.i0 & 1) ? -1 : 1;
-                float *x2 = (o.i0 & 2) ? y : x, *y2 = (o.i0 & 2) ? x : y;
+                const int sign = (o.n & 1) ? -1 : 1;
+                float *x2 = (o.n & 2) ? y : x, *y2 = (o.n & 2) ? x : y;
                 y2[0] = -sign * x2[1];
                 y2[1] = sign * x2[0];
                 const float x0 = o.f0 * x[0], x1 = o.f0 * x[1], y0 = o.f1 * y[0], y1 = o.f1 * y[1];
@@ -964,6 +970,30 @@ void CeltDecoder::reset() {
 }
 
 int CeltDecoder::decode(const uint8_t *data, int len, int frameSize, float *freqOut, CeltFrame &info) {
+    return decodeFrame(data, len, frameSize, freqOut, nullptr, info);
+}
+
+// layout of a symbol record (include/nyq_imdct.h): head | gain[42] | ops[113] | vecs[44] | (16-byte aligned) body
+namespace {
+constexpr size_t kSymGainOff = sizeof(nyq_sym_head), kSymOpsOff = kSymGainOff + 2 * kBands * sizeof(float),
+                 kSymVecsOff = kSymOpsOff + NYQ_SYM_MAX_OPS * sizeof(nyq_sym_op),
+                 kSymBodyOff = (kSymVecsOff + NYQ_SYM_MAX_VECS * sizeof(nyq_sym_vec) + 15) & ~(size_t)15;
+static_assert(sizeof(nyq_sym_head) == 32 && sizeof(nyq_sym_leaf) == 16 && sizeof(nyq_sym_vec) == 20 && sizeof(nyq_sym_op) == 16, "record layout");
+static_assert(sizeof(CeltDecoder::Scratch::LeafSlot) == sizeof(nyq_sym_leaf) && sizeof(CeltDecoder::Scratch::VecSlot) == sizeof(nyq_sym_vec) &&
+                  sizeof(CeltDecoder::Scratch::OpSlot) == sizeof(nyq_sym_op),
+              "the decoder's scratch records travel to the GPU as they are");
+static_assert(sizeof(CeltDecoder::Scratch::ops) / sizeof(nyq_sym_op) == NYQ_SYM_MAX_OPS && sizeof(CeltDecoder::Scratch::vecs) / sizeof(nyq_sym_vec) == NYQ_SYM_MAX_VECS, "record capacity");
+}  // namespace
+
+size_t CeltDecoder::symbolBytes(int channels) { return kSymBodyOff + (size_t)channels * 960 * sizeof(float); }
+
+int CeltDecoder::decodeSymbols(const uint8_t *data, int len, int frameSize, void *record, CeltFrame &info) {
+    if (!record || frameSize != 960) return -1;
+    uint8_t *r = static_cast<uint8_t *>(record);
+    return decodeFrame(data, len, frameSize, reinterpret_cast<float *>(r + kSymBodyOff), r, info);
+}
+
+int CeltDecoder::decodeFrame(const uint8_t *data, int len, int frameSize, float *freqOut, uint8_t *record, CeltFrame &info) {
     const CeltMode &m = m_;
     const int CC = channels_, C = streamChannels_;
     // A mono decoder may be handed stereo-coded packets (the TOC's stereo flag is per packet): both channels are decoded and
@@ -1106,9 +1136,10 @@ int CeltDecoder::decode(const uint8_t *data, int len, int frameSize, float *freq
     std::memset(X, 0, sizeof(float) * (size_t)C * N);
     BandShaper shaper{m, K, dec, scratch_, LM, C, N, spread, plan.intensity};
     shaper.plan(start, end, C == 2, masks, plan, transient ? M : 0, tfRes, len * (8 << kBitRes) - antiCollapseRsv);   // phase 1: symbols
-    shaper.build(X, start, &rng_);                                                                                       // phase 2: floats
-
     const int antiCollapseOn = antiCollapseRsv > 0 ? (int)dec.bits(1) : 0;
+    // phase 2 (floats) here, or -- symbol records -- on the GPU, unless the frame needs what the record does not carry
+    const bool asSymbols = record && !silence && !antiCollapseOn && C == CC && LM == 3 && scratch_.nleaves <= 120 * C;
+    if (!asSymbols) shaper.build(X, start, &rng_);
     // ---- the bits that are left refine the energies once more, by priority (quant_bands.c:512-540) ----
     {
         int left = len * 8 - dec.tell();
@@ -1159,8 +1190,36 @@ int CeltDecoder::decode(const uint8_t *data, int len, int frameSize, float *freq
     // ---- denormalisation: every band times 2^(energy + mean) (bands.c:192-256), silence, band limits, channel layout ----
     if (silence) {
         for (int i = 0; i < C * kBands; i++) E[i] = -28.f;
-        std::memset(freq, 0, sizeof(float) * (size_t)std::max(CC, C) * N);
+        if (record) std::memset(record, 0, sizeof(nyq_sym_head));         // (a record without operations is a silent frame)
+        else std::memset(freq, 0, sizeof(float) * (size_t)std::max(CC, C) * N);
+    } else if (asSymbols) {
+        nyq_sym_head *H = reinterpret_cast<nyq_sym_head *>(record);
+        std::memset(H, 0, sizeof *H);
+        H->seed = rng_;                                                   // the band loop starts from the previous frame's final range
+        H->nleaves = (unsigned short)scratch_.nleaves;
+        H->nvecs = (unsigned short)scratch_.nvecs;
+        H->nops = (unsigned short)scratch_.nops;
+        H->spread = (unsigned char)spread;
+        H->start = (unsigned char)start;
+        H->end = (unsigned char)effEnd;
+        H->channels = (unsigned char)C;
+        H->lm = (unsigned char)LM;
+        float *gain = reinterpret_cast<float *>(record + kSymGainOff);
+        for (int c = 0; c < C; c++)
+            for (int i = start; i < effEnd; i++) gain[c * kBands + i] = exp2Ref(E[i + c * kBands] + m.eMeans[i]);
+        std::memcpy(record + kSymOpsOff, scratch_.ops, sizeof(nyq_sym_op) * (size_t)scratch_.nops);
+        std::memcpy(record + kSymVecsOff, scratch_.vecs, sizeof(nyq_sym_vec) * (size_t)scratch_.nvecs);
+        const size_t pulseBytes = sizeof(int16_t) * (size_t)C * N;
+        std::memcpy(record + kSymBodyOff, scratch_.pulses, pulseBytes);
+        std::memcpy(record + kSymBodyOff + pulseBytes, scratch_.leaves, sizeof(nyq_sym_leaf) * (size_t)scratch_.nleaves);
     } else {
+        if (record) {
+            nyq_sym_head *H = reinterpret_cast<nyq_sym_head *>(record);
+            std::memset(H, 0, sizeof *H);
+            H->flags = NYQ_SYM_HOST_FREQ;
+            H->channels = (unsigned char)CC;
+            H->lm = (unsigned char)LM;
+        }
         for (int c = 0; c < C; c++) {
             float *f = freq + c * N;
             std::memset(f, 0, sizeof(float) * (size_t)K.first[start]);
@@ -1169,9 +1228,11 @@ int CeltDecoder::decode(const uint8_t *data, int len, int frameSize, float *freq
             std::memset(f + K.first[effEnd], 0, sizeof(float) * (size_t)(N - K.first[effEnd]));
         }
     }
-    if (CC == 2 && C == 1) std::memcpy(freq + N, freq, sizeof(float) * N);
-    if (CC == 1 && C == 2)
-        for (int i = 0; i < N; i++) freqOut[i] = .5f * (freq[i] + freq[N + i]);
+    if (!silence || !record) {
+        if (CC == 2 && C == 1) std::memcpy(freq + N, freq, sizeof(float) * N);
+        if (CC == 1 && C == 2)
+            for (int i = 0; i < N; i++) freqOut[i] = .5f * (freq[i] + freq[N + i]);
+    }
 
     // ---- what the next frame predicts from (celt_decoder_clean.c:685-718) ----
     if (C == 1) std::memcpy(E + kBands, E, sizeof(float) * kBands);

@@ -6,6 +6,7 @@
 // on the MI355X through libnyq_imdct.so.  One CeltDecoder per Opus stream (it carries the inter-frame
 // energy prediction state).
 #pragma once
+#include <cstddef>
 #include <cstdint>
 
 #include "celt_mode.hpp"
@@ -35,6 +36,12 @@ public:
     // freq: channels() * frameSize floats, channel-major (celt_decoder_clean.c:620-652).
     // Returns 0, or a negative OPUS_* style code (-1 bad arg, -3 internal, -4 corrupt).
     int decode(const uint8_t *data, int len, int frameSize, float *freq, CeltFrame &info);
+    // The same frame as a SYMBOL record for the GPU (include/nyq_imdct.h: nyq_celt_symbol_bytes(channels()) bytes, 20 ms
+    // frames): the bit-serial work only -- the band shapes are built from the record by nyq_celt_shape_dev.  Frames the
+    // record cannot carry (anti-collapse, a channel count that differs from the decoder's, an overlong leaf list) are
+    // finished here and travel as freq[] inside the record (NYQ_SYM_HOST_FREQ).
+    int decodeSymbols(const uint8_t *data, int len, int frameSize, void *record, CeltFrame &info);
+    static size_t symbolBytes(int channels);        // = nyq_celt_symbol_bytes (computed here: the entropy stage needs no GPU library)
     int channels() const { return channels_; }
 
     // Working memory of a frame, owned by the decoder (no allocation on the decode path): the normalised coefficients of
@@ -47,14 +54,18 @@ public:
         // what phase 1 (symbols) hands to phase 2 (coefficients): the frame's pulse vectors at the offsets of their
         // coefficients, the leaves of every split tree, a record per band vector, and the operations in execution order
         int16_t pulses[2 * 960];
-        struct LeafSlot { int16_t off, n, k; uint8_t blocks, kind; float gain; int16_t foldOff; int32_t yy; } leaves[1024];
-        struct VecSlot { int16_t x, n, fold, out, nbTree, leaf0, leaf1; uint8_t sel, recombine, timeDivide, Btree, Bin; bool prepFold; } vecs[2 * 21 + 2];
-        struct OpSlot { uint8_t kind; int16_t a, b, n; float f0, f1; int i0; } ops[5 * 21 + 8];
+        // (the three records are laid out like include/nyq_imdct.h's nyq_sym_leaf / nyq_sym_vec / nyq_sym_op: decodeSymbols()
+        // hands them to the GPU as they are)
+        struct LeafSlot { int16_t off, n, k; uint8_t blocks, kind; float gain; int16_t foldOff, pad; } leaves[1024];
+        int32_t leafEnergy[1024];       // |y|^2 of a leaf's pulse vector (an exact small integer)
+        struct VecSlot { int16_t x, n, fold, out, nbTree, leaf0, leaf1; uint8_t sel, recombine, timeDivide, Btree, Bin, pad; } vecs[2 * 21 + 2];
+        struct OpSlot { uint8_t kind, pad; int16_t a, b, n; float f0, f1; } ops[5 * 21 + 8];
         int nleaves = 0, nvecs = 0, nops = 0;
     };
 
 private:
     struct BandShaper;
+    int decodeFrame(const uint8_t *data, int len, int frameSize, float *freq, uint8_t *record, CeltFrame &info);
     const CeltMode &m_;
     int channels_;            // CC
     int streamChannels_;      // C

@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 
+#include "../../include/nyq_imdct.h"
 #include "batch_decoder.hpp"
 #include "celt_decoder.hpp"
 #include "libnyquist/Decoders.h"
@@ -82,6 +83,60 @@ done:
     info[3] = frameSize;
     info[4] = (long)f.lastGranule;
     info[5] = (long)f.packets.size();
+    return 0;
+}
+
+// The same walk with the entropy stage stopping at the SYMBOLS (CeltDecoder::decodeSymbols): records[max_frames] of
+// nyqh_symbol_bytes(channels) bytes each; the dump ends at the first frame that is not 20 ms (-12 if the very first); info[6] = frames that carry host-built freq[]
+// (NYQ_SYM_HOST_FREQ) instead of symbols.  A test hook: the GPU's band shapes against decode()'s.
+long nyqh_symbol_bytes(int channels) { return (long)CeltDecoder::symbolBytes(channels); }
+int nyqh_decode_to_symbols(const unsigned char *file, long size, long max_frames, unsigned char *records, int *flags, float *pf_gain,
+                           unsigned *range, long *info) {
+    OggOpusFile f;
+    try {
+        f = parseOggOpus(file, (size_t)size);
+    } catch (const std::exception &) {
+        return -10;
+    }
+    if (f.head.mappingFamily != 0 || f.head.channels < 1 || f.head.channels > 2) return -11;
+    const int CC = f.head.channels;
+    const size_t rec = CeltDecoder::symbolBytes(CC);
+    CeltDecoder dec(CC);
+    long nframes = 0, hostBuilt = 0;
+    for (const auto &pkt : f.packets) {
+        PacketFrames pf;
+        if (!parseOpusPacket(pkt.data(), (int)pkt.size(), pf)) return -10;
+        if (pf.config < 16) return -11;
+        if (pf.frameSize != 960) {
+            if (nframes == 0) return -12;
+            goto done;                                   // a different frame size ends this fixed-shape dump
+        }
+        dec.setEndBand(pf.bandwidthEnd);
+        dec.setStreamChannels(pf.stereo ? 2 : 1);
+        for (const auto &fr : pf.frames) {
+            if (nframes >= max_frames) goto done;
+            CeltFrame info1;
+            unsigned char *r = records + (size_t)nframes * rec;
+            const int rc = dec.decodeSymbols(fr.first, fr.second, pf.frameSize, r, info1);
+            if (rc < 0) return rc;
+            hostBuilt += reinterpret_cast<const nyq_sym_head *>(r)->flags & NYQ_SYM_HOST_FREQ;
+            flags[4 * nframes + 0] = info1.transient;
+            flags[4 * nframes + 1] = info1.pfPitch;
+            flags[4 * nframes + 2] = info1.pfTapset;
+            flags[4 * nframes + 3] = info1.LM;
+            pf_gain[nframes] = info1.pfGain;
+            range[nframes] = info1.rangeFinal;
+            nframes++;
+        }
+    }
+done:
+    info[0] = CC;
+    info[1] = f.head.preSkip;
+    info[2] = nframes;
+    info[3] = 960;
+    info[4] = (long)f.lastGranule;
+    info[5] = (long)f.packets.size();
+    info[6] = hostBuilt;
     return 0;
 }
 

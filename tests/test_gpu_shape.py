@@ -1,0 +1,100 @@
+"""GPU tier: the band shapes of 20 ms CELT frames built ON THE DEVICE from symbol records (nyq_celt_shape_dev,
+nyq_shape_kernel.hpp) against the host entropy stage's own freq[] (CeltDecoder::decode -- itself pinned to the reference
+decoder by tests/test_opus_corpus.py and tests/test_host_decoder.py on the CPU tier): every 20 ms file of the corpus and
+the two bundled files, every frame; then the whole way to PCM (nyq_celt_symbols_to_pcm_mapped) against the freq[] path."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from test_host_decoder import entropy_decode, load_host
+
+pytestmark = pytest.mark.gpu
+
+FILES = sorted(p for p in glob.glob(os.path.join(GOLDEN, "corpus", "*20ms*.opus")) if "surround" not in p) + \
+    [os.path.join(GOLDEN, "short.opus"), os.path.join(GOLDEN, "sb-reverie.opus")]
+
+
+@pytest.fixture(scope="module")
+def host():
+    H = load_host()
+    H.nyqh_symbol_bytes.argtypes = [C.c_int]
+    H.nyqh_symbol_bytes.restype = C.c_long
+    u8 = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+    H.nyqh_decode_to_symbols.argtypes = [C.c_char_p, C.c_long, C.c_long, u8] + list(H.nyqh_decode_to_freq.argtypes[4:])
+    return H
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import libnyquist_amd as nyq
+    c = nyq.Context(0)
+    yield c
+    c.close()
+
+
+def symbols(H, raw, max_frames, channels):
+    rec = H.nyqh_symbol_bytes(channels)
+    sym = np.zeros((max_frames, rec), np.uint8)
+    flags = np.zeros((max_frames, 4), np.int32)
+    gain = np.zeros(max_frames, np.float32)
+    rng = np.zeros(max_frames, np.uint32)
+    info = np.zeros(8, np.int64)
+    rc = H.nyqh_decode_to_symbols(raw, len(raw), max_frames, sym, flags, gain, rng, info)
+    return rc, sym, flags, gain, rng, info
+
+
+def test_record_size_is_one_number_on_both_sides(host, ctx):
+    for ch in (1, 2):
+        assert host.nyqh_symbol_bytes(ch) == ctx.lib.nyq_celt_symbol_bytes(ch) == 2896 + ch * 3840
+    assert ctx.lib.nyq_celt_symbol_bytes(3) == 0
+
+
+@pytest.mark.parametrize("path", FILES, ids=lambda p: os.path.basename(p)[:-5])
+def test_device_band_shapes_equal_the_host_entropy_stage(host, ctx, path):
+    import torch
+    raw = open(path, "rb").read()
+    cap = 12000
+    rc, freq, flags, gain, rng, info = entropy_decode(host, raw, max_frames=cap, channels=2, n=960)
+    assert rc == 0
+    ch, nf = int(info[0]), int(info[2])
+    if ch == 1:                                               # (entropy_decode's buffer was shaped for two channels)
+        rc, freq, flags, gain, rng, info = entropy_decode(host, raw, max_frames=cap, channels=1, n=960)
+    freq = freq[:nf]
+    rc, sym, flags2, gain2, rng2, info2 = symbols(host, raw, cap, ch)
+    assert rc == 0 and int(info2[2]) == nf
+    assert np.array_equal(rng[:nf], rng2[:nf]) and np.array_equal(flags[:nf], flags2[:nf])
+    host_built = int(info2[6])
+    print(f"{os.path.basename(path)}: {nf} frames, {host_built} travel as host-built freq[]")
+    # (anti-collapse frames -- the corpus is full of clicks -- and packets whose channel count differs from the stream's)
+    if os.path.basename(path) == "sb-reverie.opus":
+        assert host_built <= nf // 20                         # music: a few percent
+    dev = torch.device("cuda", 0)
+    d_sym = torch.from_numpy(sym[:nf]).to(dev)
+    d_freq = torch.full((nf, ch, 960), float("nan"), device=dev)
+    torch.cuda.synchronize(dev)
+    ctx.celt_shape_dev(d_sym.data_ptr(), d_freq.data_ptr(), 1, nf, ch)
+    ctx.synchronize()
+    got = d_freq.cpu().numpy()
+    assert np.isfinite(got).all()
+    # reductions (norms, the stereo merge's dot products) are summed in another order on the device: a few ulp per band,
+    # relative to the band's own peak -- 2e-6 of the frame's peak bounds it with room
+    peak = np.abs(freq).reshape(nf, -1).max(1)
+    err = np.abs(got - freq).reshape(nf, -1).max(1)
+    bad = np.nonzero(err > 2e-6 * np.maximum(peak, 1.0))[0]
+    assert bad.size == 0, (bad[:8], err[bad[:8]], peak[bad[:8]])
+
+
+def test_symbols_to_pcm_equals_the_freq_path(host, ctx):
+    raw = open(os.path.join(GOLDEN, "short.opus"), "rb").read()
+    rc, freq, flags, gain, rng, info = entropy_decode(host, raw, max_frames=400, channels=2, n=960)
+    nf = int(info[2])
+    rc2, sym, *_ = symbols(host, raw, 400, 2)
+    assert rc == 0 and rc2 == 0
+    tr, pp, pt = (np.ascontiguousarray(flags[:nf, k]) for k in range(3))
+    want = ctx.celt_frames_to_pcm(3, freq[None, :nf], tr[None], pp[None], gain[None, :nf], pt[None], 2)
+    got = ctx.celt_symbols_to_pcm(sym[:nf], tr.astype(np.uint8), pp.astype(np.int32), gain[:nf], pt.astype(np.int32), 1, nf, 2)
+    assert np.abs(got - want).max() <= 1e-6                   # samples are in [-1, 1)
