@@ -220,14 +220,14 @@ int nyq_device_dup_channel(nyq_ctx *ctx, float *d_base, int cstride, int src_slo
 
 /* ---- band shapes on the device: the host sends SYMBOLS, not coefficients (round 4) ----
  * What celt_decode_with_ec computes between the range decoder and denormalise_bands' output -- quant_all_bands'
- * arithmetic (bands.c:1355-1518: pulse vectors to unit-norm coefficients, the spreading rotation vq.c:65-111, folding and
- * noise filling, Haar / Hadamard resolution changes, mid / side merging) and denormalise_bands (bands.c:192-256) -- needs no
- * bit of the stream once the SYMBOLS are known.  The host's entropy stage therefore stops at the symbols (pulse vectors as
- * integers, the leaves of every band's split tree, a short program of vector operations, the band gains) and
- * nyq_celt_shape_dev builds freq[] from them on the device, one wavefront per frame.  20 ms frames (LM 3), mono or stereo.
- * One frame = one record of nyq_celt_symbol_bytes(channels) bytes:
+ * arithmetic (bands.c:1355-1518: pulse vectors from their codewords cwrs.c:decode_pulses, unit-norm coefficients, the
+ * spreading rotation vq.c:65-111, collapse masks, folding and noise filling, Haar / Hadamard resolution changes, mid / side
+ * merging) and denormalise_bands (bands.c:192-256) -- needs no bit of the stream once the SYMBOLS are known.  The host's
+ * entropy stage therefore stops at the symbols (the codeword of every pulse vector, the leaves of every band's split tree,
+ * a short program of vector operations, the band gains) and nyq_celt_shape_dev builds freq[] from them on the device, one
+ * wavefront per frame.  20 ms frames (LM 3), mono or stereo.  One frame = one record of nyq_celt_symbol_bytes(channels):
  *     nyq_sym_head | float gain[42] (2^(energy + mean) per band, channel-major) | nyq_sym_op ops[113] | nyq_sym_vec vecs[44] |
- *     body: int16 pulses[channels * 960] then nyq_sym_leaf leaves[..]  --  or, with NYQ_SYM_HOST_FREQ, float freq[channels * 960]
+ *     body: nyq_sym_leaf leaves[.. 96 * channels]  --  or, with NYQ_SYM_HOST_FREQ, float freq[channels * 960]
  * A record of zeros is a silent frame.  Offsets inside a frame are in floats of X (channel c at c * 960). */
 #define NYQ_SYM_HOST_FREQ 1          /* flags: the body holds freq[] computed on the host (anti-collapse frames, overlong leaf lists) */
 #define NYQ_SYM_MAX_OPS   113
@@ -238,20 +238,30 @@ typedef struct nyq_sym_head {
     unsigned char flags, spread, start, end, channels, lm;
     unsigned int reserved[4];
 } nyq_sym_head;                      /* 32 bytes */
-typedef struct nyq_sym_leaf {        /* a leaf of a band's split tree */
+typedef struct nyq_sym_leaf {        /* a leaf of a band's split tree (quant_partition's recursion ends, bands.c:1005-1052) */
     short off, n, k;                 /* offset inside its vector, bins, pulses */
-    unsigned char blocks, kind;      /* interleaved short blocks; 0 pulses, 1 zeros, 2 noise, 3 folded copy */
+    unsigned char blocks, kind;      /* interleaved short blocks; 0: a pulse vector, 1: no pulses (zeros / noise / folded copy,
+                                        decided on the device from the collapse masks of the bands below) */
     float gain;
-    short fold_off, pad;
-} nyq_sym_leaf;                      /* 16 bytes */
+    short fold_off;                  /* offset of its source inside the band's fold source, -1: none (noise) */
+    unsigned char shift, pad;        /* where its blocks sit in the band's collapse mask */
+    unsigned int index;              /* codeword of the pulse vector (decode_pulses' ec_dec_uint) */
+    short abs, pad2;                 /* offset in X */
+    unsigned short img[8];           /* its fill mask = OR of img[i] over the set bits i of the vector's initial fill mask */
+} nyq_sym_leaf;                      /* 40 bytes */
 typedef struct nyq_sym_vec {         /* one vector (one channel, or mid / side) of one band */
     short x, n, fold, out, nb_tree, leaf0, leaf1;
-    unsigned char sel, recombine, time_divide, b_tree, b_in, pad;
-} nyq_sym_vec;                       /* 20 bytes */
-typedef struct nyq_sym_op {          /* kinds: 0 vector a | 1 single X[a] = f0 (copy to fold memory b, channel n, if b >= 0) | 2 two-bin stereo
-                                        pair a, b (mid f0, side f1, n = sign | swap << 1) | 3 merge a, b over n bins (mid f0) | 4 negate a over n |
-                                        5 average the two channels' fold memories over a bins */
-    unsigned char kind, pad;
+    unsigned char sel, recombine, time_divide, b_tree, b_in;
+    unsigned char band;
+    unsigned char cm_ch;             /* its collapse mask is ORed into the band's mask of channel 1: first, 2: second, 3: both */
+    unsigned char fill_mode;         /* initial fill mask: 0 both channels' masks of bands [fill_lo, fill_hi) ORed, 1 the first
+                                        channel's, 2 the second's, 3 all blocks */
+    unsigned char fill_lo, fill_hi;
+} nyq_sym_vec;                       /* 24 bytes */
+typedef struct nyq_sym_op {          /* kinds: 0 vector a | 1 single X[a] = f0 (copy to fold memory b, channel n, if b >= 0; band's masks = 1) |
+                                        2 two-bin stereo pair a, b (mid f0, side f1, n = sign | swap << 1) | 3 merge a, b over n bins (mid f0) |
+                                        4 negate a over n | 5 average the two channels' fold memories over a bins */
+    unsigned char kind, band;
     short a, b, n;
     float f0, f1;
 } nyq_sym_op;                        /* 16 bytes */

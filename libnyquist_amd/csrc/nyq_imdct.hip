@@ -69,6 +69,7 @@ struct nyq_ctx {
     long opt_chain_window = 0;           // frames per window of the two-kernel chain; 0 = built-in choice
     int opt_chain_overlap = 0;           // windows: post-filter of window k on a second stream beside the synthesis of window k + 1
     hipStream_t s_post = nullptr;        // (created on first use)
+    unsigned *d_pvq = nullptr;           // U(n, k) of the pulse-vector codebooks (shape kernel; created on first use)
     float *d_vtab = nullptr;             // Vorbis rotation + twiddle tables of every block size, one allocation
     size_t vrot_off[12] = {0}, vtw_off[12] = {0};   // float offsets by log2(n/4)
     std::string err;
@@ -252,6 +253,7 @@ extern "C" void nyq_ctx_destroy(nyq_ctx *ctx) {
     if (ctx->s_post) { (void)hipStreamSynchronize(ctx->s_post); (void)hipStreamDestroy(ctx->s_post); }
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_vtab) (void)hipFree(ctx->d_vtab);
+    if (ctx->d_pvq) (void)hipFree(ctx->d_pvq);
     if (ctx->d_trig) (void)hipFree(ctx->d_trig);
     if (ctx->d_window) (void)hipFree(ctx->d_window);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -819,7 +821,9 @@ extern "C" int nyq_celt_chain_mapped_dev(nyq_ctx *ctx, int LM, const float *d_fr
 static_assert(sizeof(nyq_sym_head) == sizeof(SymHead) && sizeof(nyq_sym_leaf) == sizeof(SymLeaf) && sizeof(nyq_sym_vec) == sizeof(SymVec) &&
                   sizeof(nyq_sym_op) == sizeof(SymOp) && NYQ_SYM_MAX_OPS == kSymMaxOps && NYQ_SYM_MAX_VECS == kSymMaxVecs &&
                   offsetof(nyq_sym_head, nops) == offsetof(SymHead, nops) && offsetof(nyq_sym_head, lm) == offsetof(SymHead, lm) &&
-                  offsetof(nyq_sym_leaf, fold_off) == offsetof(SymLeaf, fold_off) && offsetof(nyq_sym_vec, b_in) == offsetof(SymVec, b_in) &&
+                  offsetof(nyq_sym_leaf, fold_off) == offsetof(SymLeaf, fold_off) && offsetof(nyq_sym_leaf, img) == offsetof(SymLeaf, img) &&
+                  offsetof(nyq_sym_leaf, index) == offsetof(SymLeaf, index) && offsetof(nyq_sym_vec, b_in) == offsetof(SymVec, b_in) &&
+                  offsetof(nyq_sym_vec, fill_hi) == offsetof(SymVec, fill_hi) &&
                   offsetof(nyq_sym_op, f1) == offsetof(SymOp, f1),
               "nyq_sym_* (C ABI) and nyq::Sym* (kernel) are one layout");
 
@@ -835,8 +839,14 @@ static int shape_core(nyq_ctx *ctx, const void *d_sym, float *d_freq, size_t nst
     const size_t total = nstreams * nframes;
     if (total > (size_t)0x7fffffff) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_shape_dev: more than 2^31 frames in one call");
     NYQ_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d_pvq) {
+        std::vector<unsigned> table((size_t)kPvqDim * kPvqDim);
+        pvq_table_build(table.data());
+        NYQ_HIP(ctx, hipMalloc(&ctx->d_pvq, table.size() * sizeof(unsigned)));
+        NYQ_HIP(ctx, hipMemcpy(ctx->d_pvq, table.data(), table.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    }
     hipLaunchKernelGGL(celt_shape_kernel, dim3((unsigned)total), dim3(kWave), 0, ctx->stream, static_cast<const unsigned char *>(d_sym), d_freq,
-                       (long)nstreams, (long)nframes, channels, (long)sstride);
+                       ctx->d_pvq, (long)nstreams, (long)nframes, channels, (long)sstride);
     NYQ_HIP(ctx, hipGetLastError());
     return NYQ_OK;
 }

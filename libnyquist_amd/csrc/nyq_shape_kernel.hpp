@@ -3,11 +3,13 @@
 // quant_all_bands' arithmetic (bands.c:1355-1518) -- pulse vectors to unit-norm coefficients (vq.c normalise_residual), the
 // spreading rotation (vq.c:40-111), folding and noise filling, the Haar / Hadamard resolution changes (bands.c haar1,
 // (de)interleave_hadamard), mid / side merging (bands.c:391-441) -- and denormalise_bands (bands.c:192-256) need no bit of the
-// stream once the symbols are known: the host (libnyquist_amd/host/celt_decoder.cpp, phase 1) sends, per frame, the integer
-// pulse vectors, the leaves of every band's split tree, one record per band vector and a short list of operations in execution
-// order (include/nyq_imdct.h: nyq_sym_*), and this kernel executes that list -- what the host's own phase 2 does (same order of
-// the dependent operations: the rotation recurrences, the noise generator, the fold sources; reductions are summed in another
-// order).  A quarter of the host's per-frame time moves here, where it is one wavefront per frame among thousands.
+// stream once the symbols are known: the host (libnyquist_amd/host/celt_decoder.cpp, phase 1) sends, per frame, the leaves of
+// every band's split tree with the CODEWORD of each pulse vector, one record per band vector and a short list of operations in
+// execution order (include/nyq_imdct.h: nyq_sym_*), and this kernel (a) unranks every pulse vector of the frame (cwrs.c
+// decode_pulses), a leaf per lane, (b) executes the list -- collapse masks, fill decisions and all the float work; what the
+// host's own phases 1b and 2 do (same order of the dependent operations: the rotation recurrences, the noise generator, the fold
+// sources; reductions are summed in another order).  Half of the host's per-frame time moves here, where it is one wavefront
+// per frame among thousands.
 //
 // One wavefront = one frame at a time (grid-stride over frames); the frame's coefficients X[C][960] and the fold memory live
 // in the wave's LDS slice; the control flow is the record list, wave-uniform.  Rotation passes are chains of dependent steps:
@@ -33,25 +35,101 @@ struct SymLeaf {
     short off, n, k;
     unsigned char blocks, kind;
     float gain;
-    short fold_off, pad;
+    short fold_off;
+    unsigned char shift, pad;
+    unsigned index;
+    short abs, pad2;
+    unsigned short img[8];
 };
 struct SymVec {
     short x, n, fold, out, nb_tree, leaf0, leaf1;
-    unsigned char sel, recombine, time_divide, b_tree, b_in, pad;
+    unsigned char sel, recombine, time_divide, b_tree, b_in, band, cm_ch, fill_mode, fill_lo, fill_hi;
 };
 struct SymOp {
-    unsigned char kind, pad;
+    unsigned char kind, band;
     short a, b, n;
     float f0, f1;
 };
 constexpr int kSymMaxOps = 113, kSymMaxVecs = 44;
 constexpr int kSymN = 960;                                           // bins per channel (LM 3)
-constexpr int kSymFixed = 32 + 42 * 4 + kSymMaxOps * 16 + kSymMaxVecs * 20;   // 2888
-constexpr int kSymBodyOff = (kSymFixed + 15) & ~15;                  // 2896
+constexpr int kSymFixed = 32 + 42 * 4 + kSymMaxOps * 16 + kSymMaxVecs * 24;   // 3064
+constexpr int kSymBodyOff = (kSymFixed + 15) & ~15;                  // 3072
+constexpr int kSymMaxLeaves = 192;                                   // 96 per channel: what the body holds
+constexpr int kPvqDim = 178;                                         // U(n, k) for n, k < 178 (the widest band has 176 bins)
 __host__ __device__ inline size_t sym_bytes(int channels) { return (size_t)kSymBodyOff + (size_t)channels * kSymN * 4; }
 
 constexpr int kShapeNorm = 2 * 800;                                  // fold memory: two channels x bins below the last band
 constexpr int kShapeLdsFloats = 2 * kSymN + kShapeNorm + 192 + 192;
+
+// U(n, k) of cwrs.c (the number of k-pulse vectors in n dimensions whose first coordinate is not negative ... ), 32-bit,
+// saturated: entries a valid codeword never reaches.  Built once per context on the host (shape_core).
+inline void pvq_table_build(unsigned *T) {
+    const unsigned long long cap = ~0ull >> 1;
+    static unsigned long long U[kPvqDim][kPvqDim];
+    for (int n = 0; n < kPvqDim; n++)
+        for (int k = 0; k < kPvqDim; k++) {
+            if (n == 0 || k == 0) {
+                U[n][k] = (n == 0 && k == 0) ? 1 : 0;
+                continue;
+            }
+            unsigned long long v = U[n - 1][k] + U[n][k - 1];
+            if (v > cap) v = cap;
+            v += U[n - 1][k - 1];
+            if (v > cap) v = cap;
+            U[n][k] = v;
+        }
+    for (int n = 0; n < kPvqDim; n++)
+        for (int k = 0; k < kPvqDim; k++) T[n * kPvqDim + k] = U[n][k] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)U[n][k];
+}
+
+// codeword -> pulse vector y[0 .. n) (cwrs.c cwrsi, 32-bit rows): one lane, its leaf.  Returns |y|^2; *cm = which of the
+// leaf's `blocks` interleaved short blocks received a pulse.
+__device__ __forceinline__ int pvq_unrank(const unsigned *__restrict__ T, int n, int k, unsigned idx, short *y, int blocks, unsigned *cm) {
+    const int per = blocks > 1 ? n / blocks : n;
+    int yy = 0, j = 0;
+    unsigned mask = 0;
+    while (n > 2) {
+        unsigned a = T[(k + 1) * kPvqDim + n];                       // U(n, k + 1)
+        const bool neg = idx >= a;
+        if (neg) idx -= a;
+        a = T[k * kPvqDim + n];
+        int v = 0;
+        if (a <= idx) {
+            idx -= a;
+        } else {
+            int kk = k;
+            if (kk > n && T[n * kPvqDim + n] > idx) kk = n;
+            unsigned p;
+            do {
+                kk--;
+                p = T[kk * kPvqDim + n];
+            } while (p > idx);
+            idx -= p;
+            v = k - kk;
+            k = kk;
+        }
+        y[j] = (short)(neg ? -v : v);
+        yy += v * v;
+        if (v) mask |= 1u << (j / per);
+        j++;
+        n--;
+    }
+    {
+        const unsigned a = 2 * (unsigned)k + 1;
+        const bool neg = idx >= a;
+        if (neg) idx -= a;
+        const int kk = (int)((idx + 1) >> 1);
+        if (kk) idx -= 2 * (unsigned)kk - 1;
+        const int v = k - kk;
+        y[j] = (short)(neg ? -v : v);
+        y[j + 1] = (short)(idx ? -kk : kk);
+        yy += v * v + kk * kk;
+        if (v) mask |= 1u << (j / per);
+        if (kk) mask |= 1u << ((j + 1) / per);
+    }
+    *cm = blocks > 1 ? mask : 1u;
+    return yy;
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -146,8 +224,11 @@ struct ShapeFrame {
     const float *gain;
     const SymOp *ops;
     const SymVec *vecs;
-    const short *pulses;
     const SymLeaf *leaves;
+    const short *pulses;             // LDS: the frame's pulse vectors at the offsets of their coefficients
+    const int *energy;               // LDS: |y|^2 per leaf
+    const unsigned short *leafCm;    // LDS: collapse mask of a pulse leaf
+    unsigned char *masks;            // LDS: [2][21] collapse masks of the bands so far
 };
 
 __device__ __forceinline__ void shape_vector(const ShapeFrame &F, const SymVec v, float *X, float *norm, float *norm2, float *work,
@@ -157,8 +238,61 @@ __device__ __forceinline__ void shape_vector(const ShapeFrame &F, const SymVec v
     const int n = v.n, recombine = v.recombine, timeDivide = v.time_divide, Btree = v.b_tree;
     const bool longBlocks = v.b_in == 1;
     const float *src = v.fold >= 0 ? (v.sel ? norm2 : norm) + v.fold : nullptr;
+    // the vector's initial fill mask: the collapse masks of the bands it may fold from (bands.c:1455-1481)
+    unsigned fill0 = 0;
+    if (v.fill_mode == 3) {
+        fill0 = (1u << v.b_in) - 1;
+    } else {
+        for (int f = v.fill_lo; f < v.fill_hi; f++)
+            fill0 |= v.fill_mode == 1 ? F.masks[f] : v.fill_mode == 2 ? F.masks[21 + f] : (unsigned)(F.masks[f] | F.masks[21 + f]);
+    }
+    // what becomes of the leaves without pulses, and the vector's collapse mask (every lane computes the same)
+    unsigned cm = 0, kinds = 0;                                      // kinds: 2 bits per leaf of the vector (at most 16)
     bool folds = false;
-    for (int l = v.leaf0; l < v.leaf1; l++) folds = folds || F.leaves[l].kind == 3;
+    for (int l = v.leaf0; l < v.leaf1; l++) {
+        const SymLeaf lf = F.leaves[l];
+        unsigned lcm, kind = 0;
+        if (lf.kind == 0) {
+            lcm = F.leafCm[l];
+        } else {
+            unsigned fill = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (fill0 >> i & 1) fill |= lf.img[i];
+            if (!fill) {
+                kind = 1;
+                lcm = 0;
+            } else if (lf.fold_off < 0) {
+                kind = 2;
+                lcm = (1u << lf.blocks) - 1;
+            } else {
+                kind = 3;
+                lcm = fill;
+                folds = true;
+            }
+        }
+        kinds |= kind << (2 * (l - v.leaf0));
+        cm |= lcm << lf.shift;
+    }
+    {
+        int Bm = Btree;
+        for (int k = 0; k < timeDivide; k++) {
+            Bm >>= 1;
+            cm |= cm >> Bm;
+        }
+        for (int k = 0; k < recombine; k++) {                       // (bit_deinterleave_table: every bit doubled)
+            const unsigned c4 = cm & 0xF;
+            cm = (c4 & 1) * 3 | (c4 >> 1 & 1) * 0xC | (c4 >> 2 & 1) * 0x30 | (c4 >> 3 & 1) * 0xC0;
+        }
+        Bm <<= recombine;
+        cm &= (1u << Bm) - 1;
+        NYQ_WAVE_SYNC();
+        if (lane == 0) {
+            if (v.cm_ch & 1) F.masks[v.band] |= (unsigned char)cm;
+            if (v.cm_ch & 2) F.masks[21 + v.band] |= (unsigned char)cm;
+        }
+        NYQ_WAVE_SYNC();
+    }
     if (folds && (recombine || timeDivide || Btree > 1)) {
         for (int j = lane; j < n; j += kWave) work[j] = src[j];
         NYQ_WAVE_SYNC();
@@ -175,14 +309,12 @@ __device__ __forceinline__ void shape_vector(const ShapeFrame &F, const SymVec v
     // leaves in tree order (the noise generator advances through the filled ones in this order)
     for (int l = v.leaf0; l < v.leaf1; l++) {
         const SymLeaf lf = F.leaves[l];
+        const unsigned kind = kinds >> (2 * (l - v.leaf0)) & 3;
         float *o = x + lf.off;
         const int ln = lf.n;
-        if (lf.kind == 0) {
-            const short *y = F.pulses + v.x + lf.off;
-            int e = 0;
-            for (int j = lane; j < ln; j += kWave) e += (int)y[j] * (int)y[j];
-            const int yy = wave_sum_i(e);
-            const float g = (1.f / sqrtf((float)yy)) * lf.gain;
+        if (kind == 0) {
+            const short *y = F.pulses + lf.abs;
+            const float g = (1.f / sqrtf((float)F.energy[l])) * lf.gain;
             for (int j = lane; j < ln; j += kWave) o[j] = g * (float)y[j];
             NYQ_WAVE_SYNC();
             if (spread != 0 && 2 * lf.k < ln) {
@@ -200,14 +332,14 @@ __device__ __forceinline__ void shape_vector(const ShapeFrame &F, const SymVec v
                 if (stride2) shape_rotate(o, stride, len, stride2, s, c, lane);
                 shape_rotate(o, stride, len, 1, c, s, lane);
             }
-        } else if (lf.kind == 1) {
+        } else if (kind == 1) {
             for (int j = lane; j < ln; j += kWave) o[j] = 0.f;
             NYQ_WAVE_SYNC();
         } else {
             float e = 0.f;
             for (int j = lane; j < ln; j += kWave) {
                 const unsigned sj = lcg_jump(seed, j + 1);
-                const float val = lf.kind == 2 ? (float)((int)sj >> 20) : src[lf.fold_off + j] + ((sj & 0x8000u) ? 1.0f / 256 : -1.0f / 256);
+                const float val = kind == 2 ? (float)((int)sj >> 20) : src[lf.fold_off + j] + ((sj & 0x8000u) ? 1.0f / 256 : -1.0f / 256);
                 o[j] = val;
                 e += val * val;
             }
@@ -241,10 +373,15 @@ __device__ __forceinline__ int shape_edge(int i) {
     return e[i];
 }
 
-__global__ __launch_bounds__(kWave) void celt_shape_kernel(const unsigned char *__restrict__ sym, float *__restrict__ freq, long nstreams,
-                                                           long nframes, int channels, long sstride) {
+__global__ __launch_bounds__(kWave) void celt_shape_kernel(const unsigned char *__restrict__ sym, float *__restrict__ freq,
+                                                           const unsigned *__restrict__ pvq, long nstreams, long nframes, int channels,
+                                                           long sstride) {
 #pragma clang fp contract(off)
     __shared__ __attribute__((aligned(16))) float lds[kShapeLdsFloats];
+    __shared__ short pulses[2 * kSymN];
+    __shared__ int energy[kSymMaxLeaves];
+    __shared__ unsigned short leafCm[kSymMaxLeaves];
+    __shared__ unsigned char masks[2 * 21 + 6];
     float *X = lds, *norm = lds + 2 * kSymN, *work = norm + kShapeNorm, *tmp = work + 192;
     const int lane = threadIdx.x;
     const size_t rec = sym_bytes(channels);
@@ -271,10 +408,24 @@ __global__ __launch_bounds__(kWave) void celt_shape_kernel(const unsigned char *
         F.gain = reinterpret_cast<const float *>(r + 32);
         F.ops = reinterpret_cast<const SymOp *>(r + 32 + 42 * 4);
         F.vecs = reinterpret_cast<const SymVec *>(r + 32 + 42 * 4 + kSymMaxOps * 16);
-        F.pulses = reinterpret_cast<const short *>(r + kSymBodyOff);
-        F.leaves = reinterpret_cast<const SymLeaf *>(r + kSymBodyOff + (size_t)C * kSymN * 2);
+        F.leaves = reinterpret_cast<const SymLeaf *>(r + kSymBodyOff);
+        F.pulses = pulses;
+        F.energy = energy;
+        F.leafCm = leafCm;
+        F.masks = masks;
         float *norm2 = norm + (shape_edge(20) - shape_edge(H.start));
         unsigned seed = H.seed;
+        NYQ_WAVE_SYNC();
+        // (a) every pulse vector of the frame from its codeword: a leaf per lane
+        if (lane < 2 * 21) masks[lane] = 0;
+        const int nleaves = H.nleaves < kSymMaxLeaves ? H.nleaves : kSymMaxLeaves;
+        for (int l = lane; l < nleaves; l += kWave) {
+            const SymLeaf lf = F.leaves[l];
+            if (lf.kind != 0) continue;
+            unsigned cm;
+            energy[l] = pvq_unrank(pvq, lf.n, lf.k, lf.index, pulses + lf.abs, lf.blocks, &cm);
+            leafCm[l] = (unsigned short)cm;
+        }
         NYQ_WAVE_SYNC();
         for (int q = 0; q < H.nops; q++) {
             const SymOp o = F.ops[q];
@@ -284,6 +435,8 @@ __global__ __launch_bounds__(kWave) void celt_shape_kernel(const unsigned char *
                 if (lane == 0) {
                     X[o.a] = o.f0;
                     if (o.b >= 0) (o.n ? norm2 : norm)[o.b] = o.f0;
+                    masks[o.band] |= 1;
+                    masks[21 + o.band] |= 1;
                 }
                 NYQ_WAVE_SYNC();
                 break;

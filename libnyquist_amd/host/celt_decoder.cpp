@@ -451,11 +451,24 @@ struct CeltDecoder::BandShaper {
     uint32_t seed = 0;
     int band = 0, tfChange = 0;
 
+    // The collapse masks ("which short blocks of a band carry energy") steer the folding of later bands but never the
+    // bitstream, and they depend on the pulse vectors -- which phase 1 does not unrank.  Phase 1 therefore carries, in place
+    // of a band's `fill` mask, its IMAGE under every input bit: lane i of an Img is what the mask becomes when only bit i of
+    // the band's initial mask is set (16 bits: a transient band whose time resolution is raised once more has 16 blocks).
+    // Every step of the reference on `fill` (bands.c:1106-1123, 905-1003) is a shift, an AND with a constant or an OR, so
+    // the images are transformed lane-wise by the same steps (one vector register) and a leaf's fill is the OR of the images
+    // of the bits that are set -- evaluated later, by whoever knows the masks (resolve() below, or the GPU).
+    typedef uint16_t Img __attribute__((vector_size(16)));
+    static Img rep(unsigned m) {
+        const uint16_t v = (uint16_t)m;
+        return Img{v, v, v, v, v, v, v, v};
+    }
+
     // ---- phase 1: symbols ------------------------------------------------------------------------------------------
     struct Angle {
         int inv, imid, iside, delta, itheta, qalloc;
     };
-    Angle readAngle(int n, int &b, int B, int B0, int lm, bool stereo, int &fill) {
+    Angle readAngle(int n, int &b, int B, int B0, int lm, bool stereo, Img &fill) {
         const int pulseCap = m.logN[band] + lm * kOneBit;
         const int offset = (pulseCap >> 1) - (stereo && n == 2 ? kQThetaOffsetTwoPhase : kQThetaOffset);
         int qn = angleResolution(n, b, offset, pulseCap, stereo);
@@ -495,10 +508,10 @@ struct CeltDecoder::BandShaper {
         Angle a{inv, 0, 0, 0, itheta, qalloc};
         if (itheta == 0) {
             a.imid = 32767; a.iside = 0; a.delta = -16384;
-            fill &= (1 << B) - 1;
+            fill &= rep((1u << B) - 1);
         } else if (itheta == 16384) {
             a.imid = 0; a.iside = 32767; a.delta = 16384;
-            fill &= ((1 << B) - 1) << B;
+            fill &= rep(((1u << B) - 1) << B);
         } else {
             a.imid = bitexactCos((int16_t)itheta);
             a.iside = bitexactCos((int16_t)(16384 - itheta));
@@ -508,12 +521,16 @@ struct CeltDecoder::BandShaper {
     }
 
     // a leaf of the split tree (Scratch::LeafSlot): off / n = where in the vector and how many bins, k = pulses, blocks =
-    // interleaved short blocks inside it, kind, gain, foldOff = (kFold) offset of its source inside the band's fold source
+    // interleaved short blocks inside it, kind, gain, foldOff = offset of its source inside the band's fold source (-1: none),
+    // index = the pulse vector's codeword, img = the images of its fill mask, shift = where its blocks sit in the band's mask.
+    // Phase 1 knows two kinds -- kPulses and "no pulses" (kZero) --; resolve() turns the latter into kZero / kNoise / kFold.
     enum LeafKind : uint8_t { kPulses, kZero, kNoise, kFold };
     using Leaf = Scratch::LeafSlot;
     struct Node {                    // a pending partition of the split tree
         int16_t off, n, foldOff;
-        int b, B, lm, fill, shift;
+        int b, B, lm;
+        Img fill;
+        int shift;
         float gain;
         // second halves wait for what the first half really spent: b += max(0, surplus - 3 bits) unless the angle is degenerate
         bool deferred, mayGrow;
@@ -522,15 +539,13 @@ struct CeltDecoder::BandShaper {
     };
 
     // Walk the split tree of one vector (quant_partition's recursion, bands.c:879-1055, as an explicit stack) reading every
-    // angle and pulse vector; leaves go to S.leaves[nleaves..], pulses to `pulses` (same offsets as the coefficients).
-    // Returns the collapse mask of the vector.
-    unsigned readTree(int n0, int b0, int B0, bool hasFold, int lm0, float gain0, int fill0, int16_t *pulses, int &nleaves) {
+    // angle and every pulse vector's CODEWORD; leaves go to S.leaves[nleaves..] (x0: where the vector starts in X).
+    void readTree(int n0, int b0, int B0, bool hasFold, int lm0, float gain0, Img fill0, int x0, int &nleaves) {
         Node stack[2 * (kMaxLM + 2)];
         const PulseLut &lut = pulseLut();
         const uint32_t *U32 = pvqTable32();
         int sp = 0;
         stack[sp++] = Node{0, (int16_t)n0, (int16_t)(hasFold ? 0 : -1), b0, B0, lm0, fill0, 0, gain0, false, false, 0, 0};
-        unsigned cm = 0;
         while (sp > 0) {
             Node nd = stack[--sp];
             if (nd.deferred) {
@@ -541,8 +556,8 @@ struct CeltDecoder::BandShaper {
             if (nd.lm != -1 && nd.b > cache[cache[0]] + 12 && nd.n > 2) {
                 // split in two halves and an angle
                 const int half = nd.n >> 1, lm = nd.lm - 1, Bbefore = nd.B;
-                int fill = nd.fill;
-                if (nd.B == 1) fill = (fill & 1) | (fill << 1);
+                Img fill = nd.fill;
+                if (nd.B == 1) fill = (fill & rep(1)) | (fill << 1);
                 const int B = (nd.B + 1) >> 1;
                 int b = nd.b;
                 const Angle a = readAngle(half, b, B, Bbefore, lm, false, fill);
@@ -584,45 +599,24 @@ struct CeltDecoder::BandShaper {
             lf.n = nd.n;
             lf.blocks = (uint8_t)nd.B;
             lf.gain = nd.gain;
-            lf.foldOff = -1;
-            unsigned lcm;
+            lf.foldOff = nd.foldOff;
+            lf.shift = (uint8_t)nd.shift;
+            lf.abs = (int16_t)(x0 + nd.off);
+            lf.pad2 = 0;
+            const Img img = nd.fill & rep((1u << nd.B) - 1);
+            std::memcpy(lf.img, &img, sizeof img);                    // (lane i = the image of input bit i)
             if (q != 0) {
                 const int K = CeltMode::pulsesOf(q);
                 lf.kind = kPulses;
                 lf.k = (int16_t)K;
-                int16_t *y = pulses + nd.off;
                 const uint32_t *urow = U32 + (size_t)nd.n * kPvqTableDim + K;          // codebook size V = U(n, K) + U(n, K + 1)
-                S.leafEnergy[leafIndex] = unrankPulses(nd.n, K, rc.uint(urow[0] + urow[1]), y);
-                if (nd.B <= 1) {
-                    lcm = 1;
-                } else {                                              // which of the interleaved blocks received a pulse
-                    const int per = nd.n / nd.B;
-                    lcm = 0;
-                    for (int i = 0; i < nd.B; i++) {
-                        int any = 0;
-                        for (int j = 0; j < per; j++) any |= y[i * per + j];
-                        lcm |= (unsigned)(any != 0) << i;
-                    }
-                }
+                lf.index = rc.uint(urow[0] + urow[1]);
             } else {
-                const unsigned all = (1u << nd.B) - 1;
-                const int fill = nd.fill & (int)all;
+                lf.kind = kZero;
                 lf.k = 0;
-                if (!fill) {
-                    lf.kind = kZero;
-                    lcm = 0;
-                } else if (nd.foldOff < 0) {
-                    lf.kind = kNoise;
-                    lcm = all;
-                } else {
-                    lf.kind = kFold;
-                    lf.foldOff = nd.foldOff;
-                    lcm = (unsigned)fill;
-                }
+                lf.index = 0;
             }
-            cm |= lcm << nd.shift;
         }
-        return cm;
     }
 
     // ---- what phase 1 leaves behind: a flat program for phase 2 (Scratch::vecs, ops, leaves, pulses) ----------------------
@@ -637,17 +631,27 @@ struct CeltDecoder::BandShaper {
     // kOpAverage: the two channels' fold memories over a bins
     void emit(OpKind kind, int a, int b, int n, float f0, float f1) {
         Op &o = S.ops[S.nops++];
-        o.kind = kind; o.pad = 0; o.a = (int16_t)a; o.b = (int16_t)b; o.n = (int16_t)n; o.f0 = f0; o.f1 = f1;
+        o.kind = kind; o.band = 0; o.a = (int16_t)a; o.b = (int16_t)b; o.n = (int16_t)n; o.f0 = f0; o.f1 = f1;
     }
 
     // One vector of one band (quant_band, bands.c:1060-1191), phase 1: the resolution changes' effect on the masks, then the
     // split tree.  x: offset of the vector in X; fold / out: offsets into the fold memory (or -1), sel: which channel's.
-    unsigned planVector(int x, int n, int b, int B, int fold, int out, int sel, float gain, int fill) {
-        if (n == 1) return planSingles(x, -1, out, sel);
+    // fillMode: where the vector's initial fill mask comes from (FillSource), cmCh: which channels' masks of the band its own
+    // collapse mask is ORed into (1 = first, 2 = second, 3 = both)
+    enum FillSource : uint8_t { kFillBoth, kFillFirst, kFillSecond, kFillAll };
+    int fillLo = 0, fillHi = 0;      // the bands whose masks make up the current band's initial fill
+    void planVector(int x, int n, int b, int B, int fold, int out, int sel, float gain, Img fill, int fillMode, int cmCh) {
+        if (n == 1) {
+            planSingles(x, -1, out, sel);
+            return;
+        }
         const int Bin = B;
         int recombine = tfChange > 0 ? tfChange : 0, tf = tfChange, timeDivide = 0, nb = n / B;
-        static const uint8_t bitInterleave[16] = {0, 1, 1, 1, 2, 3, 3, 3, 2, 3, 3, 3, 2, 3, 3, 3};
-        for (int k = 0; k < recombine; k++) fill = bitInterleave[fill & 0xF] | bitInterleave[fill >> 4] << 2;
+        // (bit_interleave_table: output bit j = input bits 2j | 2j + 1)
+        for (int k = 0; k < recombine; k++) {
+            const Img g = fill | (fill >> 1);
+            fill = (g & rep(1)) | ((g >> 1) & rep(2)) | ((g >> 2) & rep(4)) | ((g >> 3) & rep(8));
+        }
         B >>= recombine;
         nb <<= recombine;
         while ((nb & 1) == 0 && tf < 0) {
@@ -660,24 +664,16 @@ struct CeltDecoder::BandShaper {
         VecRec &v = S.vecs[S.nvecs];
         v.x = (int16_t)x; v.n = (int16_t)n; v.fold = (int16_t)fold; v.out = (int16_t)out; v.sel = (uint8_t)sel;
         v.recombine = (uint8_t)recombine; v.timeDivide = (uint8_t)timeDivide; v.Btree = (uint8_t)B; v.Bin = (uint8_t)Bin;
-        v.nbTree = (int16_t)nb; v.pad = 0;
+        v.nbTree = (int16_t)nb;
+        v.band = (uint8_t)band; v.cmCh = (uint8_t)cmCh; v.fillMode = (uint8_t)fillMode; v.fillLo = (uint8_t)fillLo; v.fillHi = (uint8_t)fillHi;
         v.leaf0 = (int16_t)S.nleaves;
-        unsigned cm = readTree(n, b, B, fold >= 0, LM, gain, fill, S.pulses + x, S.nleaves);
+        readTree(n, b, B, fold >= 0, LM, gain, fill, x, S.nleaves);
         v.leaf1 = (int16_t)S.nleaves;
         emit(kOpVector, S.nvecs++, 0, 0, 0.f, 0.f);
-        // the masks follow the band back through the resolution changes
-        for (int k = 0; k < timeDivide; k++) {
-            B >>= 1;
-            cm |= cm >> B;
-        }
-        static const uint8_t bitDeinterleave[16] = {0x00, 0x03, 0x0C, 0x0F, 0x30, 0x33, 0x3C, 0x3F, 0xC0, 0xC3, 0xCC, 0xCF, 0xF0, 0xF3, 0xFC, 0xFF};
-        for (int k = 0; k < recombine; k++) cm = bitDeinterleave[cm];
-        B <<= recombine;
-        return cm & ((1u << B) - 1);
     }
 
     // bands of one bin: a sign per channel while bits last (bands.c:834-872)
-    unsigned planSingles(int x, int y, int out, int sel) {
+    void planSingles(int x, int y, int out, int sel) {
         for (int c = 0; c < 1 + (y >= 0); c++) {
             int sign = 0;
             if (remaining >= kOneBit) {
@@ -685,17 +681,20 @@ struct CeltDecoder::BandShaper {
                 remaining -= kOneBit;
             }
             emit(kOpSingle, c ? y : x, c == 0 ? out : -1, sel, sign ? -1.f : 1.f, 0.f);
+            S.ops[S.nops - 1].band = (uint8_t)band;                    // (its collapse mask is 1: resolve() / the GPU set it)
         }
-        return 1;
     }
 
     // both channels of a band that is coded as mid / side around an angle (quant_band_stereo, bands.c:1194-1353)
-    unsigned planStereo(int x, int y, int n, int b, int B, int fold, int out, int fill) {
-        if (n == 1) return planSingles(x, y, out, 0);
-        const int fill0 = fill;
+    void planStereo(int x, int y, int n, int b, int B, int fold, int out, Img fill, int fillMode) {
+        if (n == 1) {
+            planSingles(x, y, out, 0);
+            return;
+        }
+        const Img fill0 = fill;
         const Angle a = readAngle(n, b, B, B, LM, true, fill);
         const float mid = (1.f / 32768) * a.imid, side = (1.f / 32768) * a.iside;
-        unsigned cm;
+        const Img sideFill = fill >> B;
         if (n == 2) {
             // two bins: the side is the mid turned by a quarter, its sign one raw bit
             int mbits = b, sbits = 0;
@@ -704,33 +703,31 @@ struct CeltDecoder::BandShaper {
             const int swap = a.itheta > 8192;
             remaining -= a.qalloc + sbits;
             const int sign = 1 - 2 * (sbits ? (int)rc.bits(1) : 0);
-            cm = planVector(swap ? y : x, n, mbits, B, fold, out, 0, 1.0f, fill0);
+            planVector(swap ? y : x, n, mbits, B, fold, out, 0, 1.0f, fill0, fillMode, 3);
             emit(kOpPair2, x, y, (sign < 0) | swap << 1, mid, side);
         } else {
             int mbits = std::max(0, std::min(b, (b - a.delta) / 2)), sbits = b - mbits;
             remaining -= a.qalloc;
             const int32_t before = remaining;
             if (mbits >= sbits) {
-                cm = planVector(x, n, mbits, B, fold, out, 0, 1.0f, fill);
+                planVector(x, n, mbits, B, fold, out, 0, 1.0f, fill, fillMode, 3);
                 const int32_t surplus = mbits - (before - remaining);
                 if (surplus > 3 << kBitRes && a.itheta != 0) sbits += surplus - (3 << kBitRes);
-                cm |= planVector(y, n, sbits, B, -1, -1, 0, side, fill >> B);
+                planVector(y, n, sbits, B, -1, -1, 0, side, sideFill, fillMode, 3);
             } else {
-                cm = planVector(y, n, sbits, B, -1, -1, 0, side, fill >> B);
+                planVector(y, n, sbits, B, -1, -1, 0, side, sideFill, fillMode, 3);
                 const int32_t surplus = sbits - (before - remaining);
                 if (surplus > 3 << kBitRes && a.itheta != 16384) mbits += surplus - (3 << kBitRes);
-                cm |= planVector(x, n, mbits, B, fold, out, 0, 1.0f, fill);
+                planVector(x, n, mbits, B, fold, out, 0, 1.0f, fill, fillMode, 3);
             }
             emit(kOpMerge, x, y, n, mid, 0.f);
         }
         if (a.inv) emit(kOpNegate, y, 0, n, 0.f, 0.f);
-        return cm;
     }
 
     // the band loop (quant_all_bands, bands.c:1355-1518), phase 1
-    void plan(int start, int end, bool stereoFrame, uint8_t *masks, const BitPlan &P, int shortBlocks, const int *tfRes,
-              int32_t totalBits) {
-        const int M = 1 << LM, B = shortBlocks ? M : 1, Cn = stereoFrame ? 2 : 1;
+    void plan(int start, int end, bool stereoFrame, const BitPlan &P, int shortBlocks, const int *tfRes, int32_t totalBits) {
+        const int M = 1 << LM, B = shortBlocks ? M : 1;
         const int16_t *edge = K.first;
         const int normOffset = edge[start];
         int foldBand = 0;                        // the lowest band whose copy may serve as fold source ("lowband_offset")
@@ -755,38 +752,106 @@ struct CeltDecoder::BandShaper {
             tfChange = tfRes[i];
             // where a band without pulses copies from: the n bins below `foldBand`, and which blocks of them carry energy
             int foldAt = -1;
-            unsigned xm, ym;
+            bool fromMasks = false;
+            fillLo = fillHi = 0;
             if (foldBand != 0 && (spread != kSpreadAggressive || B > 1 || tfChange < 0)) {
                 foldAt = std::max(0, edge[foldBand] - normOffset - n);
                 int f0 = foldBand;
                 while (edge[--f0] > foldAt + normOffset) {}
                 int f1 = foldBand - 1;
                 while (edge[++f1] < foldAt + normOffset + n) {}
-                xm = ym = 0;
-                for (int f = f0; f < f1; f++) {
-                    xm |= masks[f * Cn];
-                    ym |= masks[f * Cn + Cn - 1];
-                }
-            } else {
-                xm = ym = (1u << B) - 1;
+                fillLo = f0;                                              // initial fill = the masks of bands [f0, f1) ORed
+                fillHi = f1;
+                fromMasks = true;
             }
+            const Img fill = Img{1, 2, 4, 8, 16, 32, 64, 128} & rep((1u << B) - 1);
             if (dual && i == P.intensity) {                            // from here on the two channels fold from their mean
                 dual = 0;
                 emit(kOpAverage, edge[i] - normOffset, 0, 0, 0.f, 0.f);
             }
             const int outAt = last ? -1 : edge[i] - normOffset;
             if (dual) {
-                xm = planVector(x, n, b / 2, B, foldAt, outAt, 0, 1.0f, (int)xm);
-                ym = planVector(y, n, b / 2, B, foldAt, outAt, 1, 1.0f, (int)ym);
+                planVector(x, n, b / 2, B, foldAt, outAt, 0, 1.0f, fill, fromMasks ? kFillFirst : kFillAll, 1);
+                planVector(y, n, b / 2, B, foldAt, outAt, 1, 1.0f, fill, fromMasks ? kFillSecond : kFillAll, 2);
+            } else if (y >= 0) {
+                planStereo(x, y, n, b, B, foldAt, outAt, fill, fromMasks ? kFillBoth : kFillAll);
             } else {
-                if (y >= 0) xm = planStereo(x, y, n, b, B, foldAt, outAt, (int)(xm | ym));
-                else xm = planVector(x, n, b, B, foldAt, outAt, 0, 1.0f, (int)(xm | ym));
-                ym = xm;
+                planVector(x, n, b, B, foldAt, outAt, 0, 1.0f, fill, fromMasks ? kFillBoth : kFillAll, 3);
             }
-            masks[i * Cn] = (uint8_t)xm;
-            masks[i * Cn + Cn - 1] = (uint8_t)ym;
             balance += P.shape[i] + tell;
             refresh = b > (n << kBitRes);
+        }
+    }
+
+    // ---- phase 1b: what the symbols imply without reading another bit -------------------------------------------------
+    // Pulse vectors from their codewords, the collapse mask of every band (bands.c:1483-1511) and, from the masks of the
+    // bands below, what becomes of the leaves without pulses (zeros / noise / a folded copy: bands.c:1005-1047).  The GPU
+    // does the same from the record (nyq_shape_kernel.hpp); masks[c][band].
+    void resolve(uint8_t masks[2][kBands]) {
+        std::memset(masks, 0, 2 * kBands);
+        for (int q = 0; q < S.nops; q++) {
+            const Op &o = S.ops[q];
+            if (o.kind == kOpSingle) {
+                masks[0][o.band] |= 1;
+                masks[1][o.band] |= 1;
+                continue;
+            }
+            if (o.kind != kOpVector) continue;
+            const VecRec &v = S.vecs[o.a];
+            unsigned fill0 = 0;
+            if (v.fillMode == kFillAll) {
+                fill0 = (1u << v.Bin) - 1;
+            } else {
+                for (int f = v.fillLo; f < v.fillHi; f++)
+                    fill0 |= v.fillMode == kFillFirst ? masks[0][f] : v.fillMode == kFillSecond ? masks[1][f] : (unsigned)(masks[0][f] | masks[1][f]);
+            }
+            unsigned cm = 0;
+            for (int l = v.leaf0; l < v.leaf1; l++) {
+                Leaf &lf = S.leaves[l];
+                unsigned lcm;
+                if (lf.kind == kPulses) {
+                    int16_t *y = S.pulses + lf.abs;
+                    S.leafEnergy[l] = unrankPulses(lf.n, lf.k, lf.index, y);
+                    if (lf.blocks <= 1) {
+                        lcm = 1;
+                    } else {                                          // which of the interleaved blocks received a pulse
+                        const int per = lf.n / lf.blocks;
+                        lcm = 0;
+                        for (int i = 0; i < lf.blocks; i++) {
+                            int any = 0;
+                            for (int j = 0; j < per; j++) any |= y[i * per + j];
+                            lcm |= (unsigned)(any != 0) << i;
+                        }
+                    }
+                } else {
+                    unsigned fill = 0;
+                    for (int i = 0; i < 8; i++)
+                        if (fill0 >> i & 1) fill |= lf.img[i];
+                    if (!fill) {
+                        lf.kind = kZero;
+                        lcm = 0;
+                    } else if (lf.foldOff < 0) {
+                        lf.kind = kNoise;
+                        lcm = (1u << lf.blocks) - 1;
+                    } else {
+                        lf.kind = kFold;
+                        lcm = fill;
+                    }
+                }
+                cm |= lcm << lf.shift;
+            }
+            // the mask follows the band back through the resolution changes
+            int B = v.Btree;
+            for (int k = 0; k < v.timeDivide; k++) {
+                B >>= 1;
+                cm |= cm >> B;
+            }
+            static const uint8_t bitDeinterleave[16] = {0x00, 0x03, 0x0C, 0x0F, 0x30, 0x33, 0x3C, 0x3F, 0xC0, 0xC3, 0xCC, 0xCF, 0xF0, 0xF3, 0xFC, 0xFF};
+            for (int k = 0; k < v.recombine; k++) cm = bitDeinterleave[cm & 0xF];
+            B <<= v.recombine;
+            cm &= (1u << B) - 1;
+            if (v.cmCh & 1) masks[0][v.band] |= (uint8_t)cm;
+            if (v.cmCh & 2) masks[1][v.band] |= (uint8_t)cm;
         }
     }
 
@@ -978,7 +1043,7 @@ namespace {
 constexpr size_t kSymGainOff = sizeof(nyq_sym_head), kSymOpsOff = kSymGainOff + 2 * kBands * sizeof(float),
                  kSymVecsOff = kSymOpsOff + NYQ_SYM_MAX_OPS * sizeof(nyq_sym_op),
                  kSymBodyOff = (kSymVecsOff + NYQ_SYM_MAX_VECS * sizeof(nyq_sym_vec) + 15) & ~(size_t)15;
-static_assert(sizeof(nyq_sym_head) == 32 && sizeof(nyq_sym_leaf) == 16 && sizeof(nyq_sym_vec) == 20 && sizeof(nyq_sym_op) == 16, "record layout");
+static_assert(sizeof(nyq_sym_head) == 32 && sizeof(nyq_sym_leaf) == 40 && sizeof(nyq_sym_vec) == 24 && sizeof(nyq_sym_op) == 16, "record layout");
 static_assert(sizeof(CeltDecoder::Scratch::LeafSlot) == sizeof(nyq_sym_leaf) && sizeof(CeltDecoder::Scratch::VecSlot) == sizeof(nyq_sym_vec) &&
                   sizeof(CeltDecoder::Scratch::OpSlot) == sizeof(nyq_sym_op),
               "the decoder's scratch records travel to the GPU as they are");
@@ -1130,16 +1195,18 @@ int CeltDecoder::decodeFrame(const uint8_t *data, int len, int frameSize, float 
     }
 
     // ---- band shapes ----
-    uint8_t masks[2 * kBands];
-    std::memset(masks, 0, sizeof masks);
+    uint8_t masks[2][kBands];
     float *X = scratch_.X;
     std::memset(X, 0, sizeof(float) * (size_t)C * N);
     BandShaper shaper{m, K, dec, scratch_, LM, C, N, spread, plan.intensity};
-    shaper.plan(start, end, C == 2, masks, plan, transient ? M : 0, tfRes, len * (8 << kBitRes) - antiCollapseRsv);   // phase 1: symbols
+    shaper.plan(start, end, C == 2, plan, transient ? M : 0, tfRes, len * (8 << kBitRes) - antiCollapseRsv);   // phase 1: symbols
     const int antiCollapseOn = antiCollapseRsv > 0 ? (int)dec.bits(1) : 0;
     // phase 2 (floats) here, or -- symbol records -- on the GPU, unless the frame needs what the record does not carry
-    const bool asSymbols = record && !silence && !antiCollapseOn && C == CC && LM == 3 && scratch_.nleaves <= 120 * C;
-    if (!asSymbols) shaper.build(X, start, &rng_);
+    const bool asSymbols = record && !silence && !antiCollapseOn && C == CC && LM == 3 && scratch_.nleaves <= 96 * C;
+    if (!asSymbols) {
+        shaper.resolve(masks);                                            // phase 1b: pulse vectors, collapse masks, fill decisions
+        shaper.build(X, start, &rng_);                                    // phase 2: floats
+    }
     // ---- the bits that are left refine the energies once more, by priority (quant_bands.c:512-540) ----
     {
         int left = len * 8 - dec.tell();
@@ -1175,7 +1242,7 @@ int CeltDecoder::decodeFrame(const uint8_t *data, int len, int frameSize, float 
                 float *x = X + c * N + K.first[i];
                 bool touched = false;
                 for (int k = 0; k < M; k++) {
-                    if (masks[i * C + c] & 1 << k) continue;
+                    if (masks[c][i] & 1 << k) continue;
                     for (int j = 0; j < n0; j++) {
                         seed = lcg(seed);
                         x[(j << LM) + k] = (seed & 0x8000) ? r : -r;
@@ -1209,9 +1276,7 @@ int CeltDecoder::decodeFrame(const uint8_t *data, int len, int frameSize, float 
             for (int i = start; i < effEnd; i++) gain[c * kBands + i] = exp2Ref(E[i + c * kBands] + m.eMeans[i]);
         std::memcpy(record + kSymOpsOff, scratch_.ops, sizeof(nyq_sym_op) * (size_t)scratch_.nops);
         std::memcpy(record + kSymVecsOff, scratch_.vecs, sizeof(nyq_sym_vec) * (size_t)scratch_.nvecs);
-        const size_t pulseBytes = sizeof(int16_t) * (size_t)C * N;
-        std::memcpy(record + kSymBodyOff, scratch_.pulses, pulseBytes);
-        std::memcpy(record + kSymBodyOff + pulseBytes, scratch_.leaves, sizeof(nyq_sym_leaf) * (size_t)scratch_.nleaves);
+        std::memcpy(record + kSymBodyOff, scratch_.leaves, sizeof(nyq_sym_leaf) * (size_t)scratch_.nleaves);
     } else {
         if (record) {
             nyq_sym_head *H = reinterpret_cast<nyq_sym_head *>(record);

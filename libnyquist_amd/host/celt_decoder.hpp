@@ -51,15 +51,22 @@ public:
         float X[2 * 960];
         float norm[2 * 960];
         float foldWork[192], regroupTmp[192];
-        // what phase 1 (symbols) hands to phase 2 (coefficients): the frame's pulse vectors at the offsets of their
-        // coefficients, the leaves of every split tree, a record per band vector, and the operations in execution order
+        // what phase 1 (symbols) leaves behind: the leaves of every split tree (with their pulse vectors' codewords), a record
+        // per band vector, and the operations in execution order; phase 1b adds the pulse vectors themselves, at the
+        // offsets of their coefficients
         int16_t pulses[2 * 960];
         // (the three records are laid out like include/nyq_imdct.h's nyq_sym_leaf / nyq_sym_vec / nyq_sym_op: decodeSymbols()
         // hands them to the GPU as they are)
-        struct LeafSlot { int16_t off, n, k; uint8_t blocks, kind; float gain; int16_t foldOff, pad; } leaves[1024];
+        struct LeafSlot {
+            int16_t off, n, k; uint8_t blocks, kind; float gain; int16_t foldOff; uint8_t shift, pad;
+            uint32_t index; int16_t abs, pad2; uint16_t img[8];
+        } leaves[1024];
         int32_t leafEnergy[1024];       // |y|^2 of a leaf's pulse vector (an exact small integer)
-        struct VecSlot { int16_t x, n, fold, out, nbTree, leaf0, leaf1; uint8_t sel, recombine, timeDivide, Btree, Bin, pad; } vecs[2 * 21 + 2];
-        struct OpSlot { uint8_t kind, pad; int16_t a, b, n; float f0, f1; } ops[5 * 21 + 8];
+        struct VecSlot {
+            int16_t x, n, fold, out, nbTree, leaf0, leaf1;
+            uint8_t sel, recombine, timeDivide, Btree, Bin, band, cmCh, fillMode, fillLo, fillHi;
+        } vecs[2 * 21 + 2];
+        struct OpSlot { uint8_t kind, band; int16_t a, b, n; float f0, f1; } ops[5 * 21 + 8];
         int nleaves = 0, nvecs = 0, nops = 0;
     };
 

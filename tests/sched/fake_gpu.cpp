@@ -111,9 +111,9 @@ int nyq_celt_frames_to_pcm_mapped(nyq_ctx *ctx, int LM, const float *freq, const
 
 // Symbol records: the stand-in's "band shapes" are a digest of everything the record DEFINES (head, gains, operations, vectors,
 // leaves, or the host-built freq[]) spread over a freq[] buffer, which then goes through the call above -- so a record that is
-// stale, misplaced or half written changes the output.  (Bytes the entropy stage leaves undefined -- unused slots, pulses outside
-// pulse leaves -- are not read, as the real kernel does not read them.)
-size_t nyq_celt_symbol_bytes(int channels) { return channels == 1 || channels == 2 ? (size_t)2896 + (size_t)channels * 3840 : 0; }
+// stale, misplaced or half written changes the output.  (Bytes the entropy stage leaves undefined -- unused slots -- are not
+// read, as the real kernel does not read them.)
+size_t nyq_celt_symbol_bytes(int channels) { return channels == 1 || channels == 2 ? (size_t)3072 + (size_t)channels * 3840 : 0; }
 int nyq_celt_symbols_to_pcm_mapped(nyq_ctx *ctx, const void *sym, const unsigned char *transient, const int *pf_pitch, const float *pf_gain,
                                    const int *pf_tapset, float *out, const nyq_out_desc *desc, float *state, size_t nstreams, size_t nframes,
                                    int channels, size_t frames_per_stream) {
@@ -125,7 +125,7 @@ int nyq_celt_symbols_to_pcm_mapped(nyq_ctx *ctx, const void *sym, const unsigned
             float *x = freq + (s * frames_per_stream + f) * per;
             const nyq_sym_head *H = (const nyq_sym_head *)r;
             if (H->flags & NYQ_SYM_HOST_FREQ) {
-                std::memcpy(x, r + 2896, sizeof(float) * per);
+                std::memcpy(x, r + 3072, sizeof(float) * per);
                 continue;
             }
             unsigned h = 2166136261u;
@@ -137,7 +137,7 @@ int nyq_celt_symbols_to_pcm_mapped(nyq_ctx *ctx, const void *sym, const unsigned
                 for (int c = 0; c < H->channels; c++) mix(r + 32 + 4 * (c * 21 + H->start), 4 * (size_t)(H->end - H->start));
                 mix(r + 200, sizeof(nyq_sym_op) * H->nops);
                 mix(r + 200 + 16 * NYQ_SYM_MAX_OPS, sizeof(nyq_sym_vec) * H->nvecs);
-                mix(r + 2896 + 2 * per, sizeof(nyq_sym_leaf) * H->nleaves);
+                mix(r + 3072, sizeof(nyq_sym_leaf) * H->nleaves);
             }
             for (size_t k = 0; k < per; k++) x[k] = H->nops ? (float)((h >> (k % 13)) & 0xff) * (1.f / 64) : 0.f;
         }

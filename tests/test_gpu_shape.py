@@ -49,7 +49,7 @@ def symbols(H, raw, max_frames, channels):
 
 def test_record_size_is_one_number_on_both_sides(host, ctx):
     for ch in (1, 2):
-        assert host.nyqh_symbol_bytes(ch) == ctx.lib.nyq_celt_symbol_bytes(ch) == 2896 + ch * 3840
+        assert host.nyqh_symbol_bytes(ch) == ctx.lib.nyq_celt_symbol_bytes(ch) == 3072 + ch * 3840
     assert ctx.lib.nyq_celt_symbol_bytes(3) == 0
 
 
