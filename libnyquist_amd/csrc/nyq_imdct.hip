@@ -840,12 +840,16 @@ static int shape_core(nyq_ctx *ctx, const void *d_sym, float *d_freq, size_t nst
     if (total > (size_t)0x7fffffff) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_shape_dev: more than 2^31 frames in one call");
     NYQ_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->d_pvq) {
-        std::vector<unsigned> table((size_t)kPvqDim * kPvqDim);
-        pvq_table_build(table.data());
+        std::vector<unsigned> table((size_t)kPvqInfo + kPvqWords);
+        if (pvq_table_build(table.data()) != kPvqWords) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_shape_dev: pulse-vector table has an unexpected size");
         NYQ_HIP(ctx, hipMalloc(&ctx->d_pvq, table.size() * sizeof(unsigned)));
         NYQ_HIP(ctx, hipMemcpy(ctx->d_pvq, table.data(), table.size() * sizeof(unsigned), hipMemcpyHostToDevice));
     }
-    hipLaunchKernelGGL(celt_shape_kernel, dim3((unsigned)total), dim3(kWave), 0, ctx->stream, static_cast<const unsigned char *>(d_sym), d_freq,
+    // a resident grid (one workgroup of kShapeWaves frames per CU: 141 KB of LDS), grid-stride over the frames: the table
+    // is staged into LDS once per workgroup
+    const size_t want = (total + kShapeWaves - 1) / kShapeWaves, resident = (size_t)ctx->cus;
+    const unsigned grid = (unsigned)(want < resident ? want : resident);
+    hipLaunchKernelGGL(celt_shape_kernel, dim3(grid), dim3(kWave * kShapeWaves), 0, ctx->stream, static_cast<const unsigned char *>(d_sym), d_freq,
                        ctx->d_pvq, (long)nstreams, (long)nframes, channels, (long)sstride);
     NYQ_HIP(ctx, hipGetLastError());
     return NYQ_OK;

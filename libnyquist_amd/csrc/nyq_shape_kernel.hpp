@@ -11,10 +11,12 @@
 // sources; reductions are summed in another order).  Half of the host's per-frame time moves here, where it is one wavefront
 // per frame among thousands.
 //
-// One wavefront = one frame at a time (grid-stride over frames); the frame's coefficients X[C][960] and the fold memory live
-// in the wave's LDS slice; the control flow is the record list, wave-uniform.  Rotation passes are chains of dependent steps:
-// the residues of a pass (and the interleaved short blocks) are independent chains and run on different lanes, each with the
-// carried value in a register.
+// One wavefront = one frame at a time (grid-stride over frames; kShapeWaves frames side by side in a workgroup, sharing the
+// codebook table).  The frame's record is staged into the wave's LDS slice, where its coefficients X[C][960] and the fold
+// memory live too.  Pass A, a leaf per LANE: everything a pulse leaf needs is its own -- codeword -> pulse counts ->
+// unit-norm coefficients -> spreading rotation, all in place in X, the chains' carried values in registers and the loads
+// of a chain issued four steps ahead (a step is otherwise one LDS round trip).  Pass B, wave-uniform: the operation list in
+// order -- collapse masks, fills from the bands below, resolution changes, stereo -- lanes over the bins.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -61,11 +63,15 @@ __host__ __device__ inline size_t sym_bytes(int channels) { return (size_t)kSymB
 constexpr int kShapeNorm = 2 * 800;                                  // fold memory: two channels x bins below the last band
 constexpr int kShapeLdsFloats = 2 * kSymN + kShapeNorm + 192 + 192;
 
-// U(n, k) of cwrs.c (the number of k-pulse vectors in n dimensions whose first coordinate is not negative ... ), 32-bit,
-// saturated: entries a valid codeword never reaches.  Built once per context on the host (shape_core).
-inline void pvq_table_build(unsigned *T) {
-    const unsigned long long cap = ~0ull >> 1;
+// U(n, k) of cwrs.c (cwrs.c:206-440: the number of k-pulse vectors in n dimensions whose first coordinate is not negative
+// ...), as 32-bit words.  A valid codeword only ever meets entries below 2^32 -- 2595 of the 178 x 178 -- so the table is kept
+// COMPACT: row k holds U(0 .. len_k - 1, k), everything beyond reads as 2^32 - 1 ("larger than any codeword"); 10.4 KB, which
+// a workgroup keeps in LDS (the unranking walk is a chain of dependent look-ups: LDS latency, not L2 latency, per step).
+// Layout: info[kPvqDim] = offset | len << 16, then the rows.  Built once per context on the host (shape_core).
+constexpr int kPvqWords = 2595, kPvqInfo = 180;
+inline int pvq_table_build(unsigned *out /* kPvqInfo + kPvqWords */) {
     static unsigned long long U[kPvqDim][kPvqDim];
+    const unsigned long long cap = ~0ull >> 1;
     for (int n = 0; n < kPvqDim; n++)
         for (int k = 0; k < kPvqDim; k++) {
             if (n == 0 || k == 0) {
@@ -78,41 +84,67 @@ inline void pvq_table_build(unsigned *T) {
             if (v > cap) v = cap;
             U[n][k] = v;
         }
-    for (int n = 0; n < kPvqDim; n++)
-        for (int k = 0; k < kPvqDim; k++) T[n * kPvqDim + k] = U[n][k] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)U[n][k];
+    int off = 0;
+    for (int k = 0; k < kPvqInfo; k++) {
+        int len = 0;
+        while (k < kPvqDim && len < kPvqDim && U[len][k] < 0x100000000ull) len++;   // (U grows with n: a prefix)
+        out[k] = (unsigned)off | (unsigned)len << 16;
+        for (int n = 0; n < len; n++) {
+            if (off < kPvqWords) out[kPvqInfo + off] = (unsigned)U[n][k];
+            off++;
+        }
+    }
+    return off;                                                      // == kPvqWords
 }
 
-// codeword -> pulse vector y[0 .. n) (cwrs.c cwrsi, 32-bit rows): one lane, its leaf.  Returns |y|^2; *cm = which of the
-// leaf's `blocks` interleaved short blocks received a pulse.
-__device__ __forceinline__ int pvq_unrank(const unsigned *__restrict__ T, int n, int k, unsigned idx, short *y, int blocks, unsigned *cm) {
+// codeword -> pulse vector y[0 .. n) (cwrs.c cwrsi): one lane, its leaf.  y: the leaf's slots in X (the pulse counts are
+// left there as integers; the caller turns them into coefficients in place).  Returns |y|^2; *cm = which of the leaf's
+// `blocks` interleaved short blocks received a pulse.  While no pulse is found the row pair (k, k + 1) stands still and the
+// look-ups of the next coordinates do not depend on the codeword: they are issued four coordinates ahead.
+__device__ __forceinline__ unsigned pvq_at(const unsigned *tab, unsigned info, int n) {
+    return n < (int)(info >> 16) ? tab[kPvqInfo + (info & 0xffffu) + n] : 0xFFFFFFFFu;
+}
+__device__ __forceinline__ int pvq_unrank(const unsigned *tab, int n, int k, unsigned idx, int *y, int blocks, unsigned *cm) {
     const int per = blocks > 1 ? n / blocks : n;
     int yy = 0, j = 0;
     unsigned mask = 0;
     while (n > 2) {
-        unsigned a = T[(k + 1) * kPvqDim + n];                       // U(n, k + 1)
-        const bool neg = idx >= a;
-        if (neg) idx -= a;
-        a = T[k * kPvqDim + n];
-        int v = 0;
-        if (a <= idx) {
-            idx -= a;
-        } else {
-            int kk = k;
-            if (kk > n && T[n * kPvqDim + n] > idx) kk = n;
-            unsigned p;
-            do {
-                kk--;
-                p = T[kk * kPvqDim + n];
-            } while (p > idx);
-            idx -= p;
-            v = k - kk;
-            k = kk;
+        const unsigned info0 = tab[k], info1 = tab[k + 1];
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            hi[q] = pvq_at(tab, info1, n - q);                       // U(n - q, k + 1)
+            lo[q] = pvq_at(tab, info0, n - q);                       // U(n - q, k)
         }
-        y[j] = (short)(neg ? -v : v);
-        yy += v * v;
-        if (v) mask |= 1u << (j / per);
-        j++;
-        n--;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (n <= 2) break;
+            const bool neg = idx >= hi[q];
+            if (neg) idx -= hi[q];
+            int v = 0;
+            bool moved = false;
+            if (lo[q] <= idx) {
+                idx -= lo[q];
+            } else {
+                int kk = k;
+                if (kk > n && pvq_at(tab, tab[n], n) > idx) kk = n;
+                unsigned p;
+                do {
+                    kk--;
+                    p = pvq_at(tab, tab[kk], n);
+                } while (p > idx);
+                idx -= p;
+                v = k - kk;
+                k = kk;
+                moved = true;
+            }
+            y[j] = neg ? -v : v;
+            yy += v * v;
+            if (v) mask |= 1u << (j / per);
+            j++;
+            n--;
+            if (moved) break;                                        // (another row pair: look up again)
+        }
     }
     {
         const unsigned a = 2 * (unsigned)k + 1;
@@ -121,8 +153,8 @@ __device__ __forceinline__ int pvq_unrank(const unsigned *__restrict__ T, int n,
         const int kk = (int)((idx + 1) >> 1);
         if (kk) idx -= 2 * (unsigned)kk - 1;
         const int v = k - kk;
-        y[j] = (short)(neg ? -v : v);
-        y[j + 1] = (short)(idx ? -kk : kk);
+        y[j] = neg ? -v : v;
+        y[j + 1] = idx ? -kk : kk;
         yy += v * v + kk * kk;
         if (v) mask |= 1u << (j / per);
         if (kk) mask |= 1u << ((j + 1) / per);
@@ -132,11 +164,6 @@ __device__ __forceinline__ int pvq_unrank(const unsigned *__restrict__ T, int n,
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    return v;
-}
-__device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
     return v;
@@ -182,32 +209,42 @@ __device__ __forceinline__ void shape_regroup(float *x, float *tmp, int n0, int 
     NYQ_WAVE_SYNC();
 }
 
-// one rotation pass (vq.c exp_rotation1) over `blocks` consecutive blocks of `len` floats at x: the residues modulo `stride`
-// of a block are independent chains; a lane owns one (block, residue), forward walk then backward walk, the carried value in
-// a register
-__device__ __forceinline__ void shape_rotate(float *x, int blocks, int len, int stride, float c, float s, int lane) {
+// One rotation pass (vq.c exp_rotation1) over one block of `len` floats, by ONE lane: the residues modulo `stride` are
+// independent chains, each walked forward then backward with the carried value in a register; the other operand of a step
+// is untouched data, so its loads are issued four steps ahead of the arithmetic.
+__device__ __forceinline__ void lane_rotate(float *p, int len, int stride, float c, float s) {
 #pragma clang fp contract(off)
-    const int chains = blocks * stride;
-    for (int t = lane; t < chains; t += kWave) {
-        const int blk = t / stride, r = t - blk * stride;
-        float *p = x + blk * len;
-        // forward: i = r, r + stride, ... < len - stride
-        if (r < len - stride) {
+    const int top = len - 2 * stride - 1;
+    for (int r = 0; r < stride; r++) {
+        if (r < len - stride) {                                      // forward: i = r, r + stride, ... < len - stride
             float a = p[r];
             int i = r;
+            for (; i + 3 * stride < len - stride; i += 4 * stride) {
+                const float x0 = p[i + stride], x1 = p[i + 2 * stride], x2 = p[i + 3 * stride], x3 = p[i + 4 * stride];
+                float h;
+                h = c * x0 + s * a; p[i] = c * a - s * x0; a = h;
+                h = c * x1 + s * a; p[i + stride] = c * a - s * x1; a = h;
+                h = c * x2 + s * a; p[i + 2 * stride] = c * a - s * x2; a = h;
+                h = c * x3 + s * a; p[i + 3 * stride] = c * a - s * x3; a = h;
+            }
             for (; i < len - stride; i += stride) {
                 const float x2 = p[i + stride];
-                const float hi = c * x2 + s * a;
+                const float h = c * x2 + s * a;
                 p[i] = c * a - s * x2;
-                a = hi;
+                a = h;
             }
             p[i] = a;
         }
-        // backward: i = the largest index = r (mod stride) that is <= len - 2 stride - 1, down to r
-        const int top = len - 2 * stride - 1;
-        if (r <= top) {
+        if (r <= top) {                                              // backward: from the largest i = r (mod stride) <= top
             int i = top - ((top - r) % stride);
             float b = p[i + stride];
+            for (; i - 3 * stride >= 0; i -= 4 * stride) {
+                const float x0 = p[i], x1 = p[i - stride], x2 = p[i - 2 * stride], x3 = p[i - 3 * stride];
+                p[i + stride] = c * b + s * x0; b = c * x0 - s * b;
+                p[i] = c * b + s * x1; b = c * x1 - s * b;
+                p[i - stride] = c * b + s * x2; b = c * x2 - s * b;
+                p[i - 2 * stride] = c * b + s * x3; b = c * x3 - s * b;
+            }
             for (; i >= 0; i -= stride) {
                 const float x1 = p[i];
                 p[i + stride] = c * b + s * x1;
@@ -216,23 +253,46 @@ __device__ __forceinline__ void shape_rotate(float *x, int blocks, int len, int 
             p[i + stride] = b;
         }
     }
-    NYQ_WAVE_SYNC();
 }
 
-struct ShapeFrame {
-    const SymHead *head;
-    const float *gain;
+// a pulse leaf, start to finish, by one lane: codeword -> pulse counts -> gain / |y| -> the spreading rotation (vq.c:65-111,
+// decoder direction: the long-stride pass with (s, c) first, then stride 1 with (c, s)), every interleaved block a chain
+__device__ __forceinline__ void lane_pulse_leaf(const unsigned *tab, const SymLeaf &lf, float *X, int spread, unsigned *cm) {
+#pragma clang fp contract(off)
+    float *o = X + lf.abs;
+    int *y = reinterpret_cast<int *>(o);
+    const int n = lf.n;
+    const int yy = pvq_unrank(tab, n, lf.k, lf.index, y, lf.blocks, cm);
+    const float g = (1.f / sqrtf((float)yy)) * lf.gain;
+    for (int j = 0; j < n; j++) o[j] = g * (float)y[j];
+    if (spread == 0 || 2 * lf.k >= n) return;
+    const int factor = spread == 1 ? 15 : spread == 2 ? 10 : 5;
+    const float gn = (float)(1.0f * n) / (float)(n + factor * lf.k);
+    const float theta = .5f * (gn * gn);
+    const float c = cosf((.5f * 3.141592653f) * theta);              // (the host rounds a double cosine: the same to an ulp)
+    const float s = cosf((.5f * 3.141592653f) * (1.0f - theta));
+    const int stride = lf.blocks, len = n / stride;
+    int stride2 = 0;
+    if (n >= 8 * stride) {
+        stride2 = 1;
+        while ((stride2 * stride2 + stride2) * stride + (stride >> 2) < n) stride2++;
+    }
+    for (int b = 0; b < stride; b++) {
+        if (stride2) lane_rotate(o + b * len, len, stride2, s, c);
+        lane_rotate(o + b * len, len, 1, c, s);
+    }
+}
+
+struct ShapeFrame {                  // (all in the wave's LDS slice)
     const SymOp *ops;
     const SymVec *vecs;
     const SymLeaf *leaves;
-    const short *pulses;             // LDS: the frame's pulse vectors at the offsets of their coefficients
-    const int *energy;               // LDS: |y|^2 per leaf
-    const unsigned short *leafCm;    // LDS: collapse mask of a pulse leaf
-    unsigned char *masks;            // LDS: [2][21] collapse masks of the bands so far
+    const unsigned short *leafCm;    // collapse mask of a pulse leaf
+    unsigned char *masks;            // [2][21] collapse masks of the bands so far
 };
 
 __device__ __forceinline__ void shape_vector(const ShapeFrame &F, const SymVec v, float *X, float *norm, float *norm2, float *work,
-                                             float *tmp, unsigned &seed, int spread, int lane) {
+                                             float *tmp, unsigned &seed, int lane) {
 #pragma clang fp contract(off)
     float *x = X + v.x;
     const int n = v.n, recombine = v.recombine, timeDivide = v.time_divide, Btree = v.b_tree;
@@ -250,7 +310,7 @@ __device__ __forceinline__ void shape_vector(const ShapeFrame &F, const SymVec v
     unsigned cm = 0, kinds = 0;                                      // kinds: 2 bits per leaf of the vector (at most 16)
     bool folds = false;
     for (int l = v.leaf0; l < v.leaf1; l++) {
-        const SymLeaf lf = F.leaves[l];
+        const SymLeaf &lf = F.leaves[l];
         unsigned lcm, kind = 0;
         if (lf.kind == 0) {
             lcm = F.leafCm[l];
@@ -306,33 +366,15 @@ __device__ __forceinline__ void shape_vector(const ShapeFrame &F, const SymVec v
         if (Btree > 1) shape_regroup(work, tmp, v.nb_tree >> recombine, Btree << recombine, longBlocks, true, lane);
         src = work;
     }
-    // leaves in tree order (the noise generator advances through the filled ones in this order)
+    // the leaves without pulses, in tree order (the noise generator advances through the filled ones in this order); the
+    // pulse leaves were built by pass A
     for (int l = v.leaf0; l < v.leaf1; l++) {
-        const SymLeaf lf = F.leaves[l];
         const unsigned kind = kinds >> (2 * (l - v.leaf0)) & 3;
+        if (kind == 0) continue;
+        const SymLeaf &lf = F.leaves[l];
         float *o = x + lf.off;
         const int ln = lf.n;
-        if (kind == 0) {
-            const short *y = F.pulses + lf.abs;
-            const float g = (1.f / sqrtf((float)F.energy[l])) * lf.gain;
-            for (int j = lane; j < ln; j += kWave) o[j] = g * (float)y[j];
-            NYQ_WAVE_SYNC();
-            if (spread != 0 && 2 * lf.k < ln) {
-                const int factor = spread == 1 ? 15 : spread == 2 ? 10 : 5;
-                const float gn = (float)(1.0f * ln) / (float)(ln + factor * lf.k);
-                const float theta = .5f * (gn * gn);
-                const float c = (float)cos((double)((.5f * 3.141592653f) * theta));
-                const float s = (float)cos((double)((.5f * 3.141592653f) * (1.0f - theta)));
-                const int stride = lf.blocks, len = ln / stride;
-                int stride2 = 0;
-                if (ln >= 8 * stride) {
-                    stride2 = 1;
-                    while ((stride2 * stride2 + stride2) * stride + (stride >> 2) < ln) stride2++;
-                }
-                if (stride2) shape_rotate(o, stride, len, stride2, s, c, lane);
-                shape_rotate(o, stride, len, 1, c, s, lane);
-            }
-        } else if (kind == 1) {
+        if (kind == 1) {
             for (int j = lane; j < ln; j += kWave) o[j] = 0.f;
             NYQ_WAVE_SYNC();
         } else {
@@ -373,20 +415,47 @@ __device__ __forceinline__ int shape_edge(int i) {
     return e[i];
 }
 
-__global__ __launch_bounds__(kWave) void celt_shape_kernel(const unsigned char *__restrict__ sym, float *__restrict__ freq,
-                                                           const unsigned *__restrict__ pvq, long nstreams, long nframes, int channels,
-                                                           long sstride) {
+// measurement switches (tools/shape_time.py builds variants with them; the product defines none)
+#ifndef NYQ_SHAPE_WAVES
+#define NYQ_SHAPE_WAVES 5
+#endif
+#ifndef NYQ_SHAPE_DBG_NO_A
+#define NYQ_SHAPE_DBG_NO_A 0
+#endif
+#ifndef NYQ_SHAPE_DBG_NO_B
+#define NYQ_SHAPE_DBG_NO_B 0
+#endif
+constexpr int kShapeWaves = NYQ_SHAPE_WAVES;                         // frames side by side in a workgroup (they share the table)
+struct ShapeWaveLds {
+    float f[kShapeLdsFloats];                                        // X | fold memory | two work vectors
+    SymLeaf leaves[kSymMaxLeaves];                                   // the frame's record, staged
+    SymOp ops[kSymMaxOps];
+    SymVec vecs[kSymMaxVecs];
+    unsigned short leafCm[kSymMaxLeaves];
+    unsigned char masks[2 * 21 + 6];
+};
+static_assert(sizeof(SymLeaf) % 4 == 0 && sizeof(SymOp) % 4 == 0 && sizeof(SymVec) % 4 == 0, "staged word by word");
+
+__device__ __forceinline__ void stage_words(void *dst, const void *src, int bytes, int lane) {
+    unsigned *d = static_cast<unsigned *>(dst);
+    const unsigned *s = static_cast<const unsigned *>(src);
+    for (int w = lane; w < bytes / 4; w += kWave) d[w] = s[w];
+}
+
+__global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const unsigned char *__restrict__ sym, float *__restrict__ freq,
+                                                                        const unsigned *__restrict__ pvq, long nstreams, long nframes,
+                                                                        int channels, long sstride) {
 #pragma clang fp contract(off)
-    __shared__ __attribute__((aligned(16))) float lds[kShapeLdsFloats];
-    __shared__ short pulses[2 * kSymN];
-    __shared__ int energy[kSymMaxLeaves];
-    __shared__ unsigned short leafCm[kSymMaxLeaves];
-    __shared__ unsigned char masks[2 * 21 + 6];
-    float *X = lds, *norm = lds + 2 * kSymN, *work = norm + kShapeNorm, *tmp = work + 192;
-    const int lane = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) ShapeWaveLds wl[kShapeWaves];
+    __shared__ unsigned tab[kPvqInfo + kPvqWords];
+    for (int i = threadIdx.x; i < kPvqInfo + kPvqWords; i += kWave * kShapeWaves) tab[i] = pvq[i];
+    __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+    ShapeWaveLds &L = wl[wv];
+    float *X = L.f, *norm = L.f + 2 * kSymN, *work = norm + kShapeNorm, *tmp = work + 192;
     const size_t rec = sym_bytes(channels);
     const long total = nstreams * nframes;
-    for (long u = blockIdx.x; u < total; u += gridDim.x) {
+    for (long u = (long)blockIdx.x * kShapeWaves + wv; u < total; u += (long)gridDim.x * kShapeWaves) {
         const long s = u / nframes, f = u - s * nframes;
         const unsigned char *r = sym + ((size_t)s * (size_t)sstride + (size_t)f) * rec;
         float *out = freq + (size_t)u * (size_t)channels * kSymN;
@@ -403,40 +472,43 @@ __global__ __launch_bounds__(kWave) void celt_shape_kernel(const unsigned char *
             for (int j = lane; j < C * kSymN / 4; j += kWave) o4[j] = float4{0.f, 0.f, 0.f, 0.f};
             continue;
         }
+        const int nleaves = H.nleaves < kSymMaxLeaves ? H.nleaves : kSymMaxLeaves;
+        const int nops = H.nops < kSymMaxOps ? H.nops : kSymMaxOps, nvecs = H.nvecs < kSymMaxVecs ? H.nvecs : kSymMaxVecs;
+        const float laneGain = lane < 2 * 21 ? reinterpret_cast<const float *>(r + 32)[lane] : 0.f;   // lane c * 21 + band
+        NYQ_WAVE_SYNC();                                             // (the previous frame's last reads of this slice)
+        stage_words(L.ops, r + 32 + 42 * 4, nops * (int)sizeof(SymOp), lane);
+        stage_words(L.vecs, r + 32 + 42 * 4 + kSymMaxOps * (int)sizeof(SymOp), nvecs * (int)sizeof(SymVec), lane);
+        stage_words(L.leaves, r + kSymBodyOff, nleaves * (int)sizeof(SymLeaf), lane);
+        if (lane < 2 * 21) L.masks[lane] = 0;
+        NYQ_WAVE_SYNC();
         ShapeFrame F;
-        F.head = reinterpret_cast<const SymHead *>(r);
-        F.gain = reinterpret_cast<const float *>(r + 32);
-        F.ops = reinterpret_cast<const SymOp *>(r + 32 + 42 * 4);
-        F.vecs = reinterpret_cast<const SymVec *>(r + 32 + 42 * 4 + kSymMaxOps * 16);
-        F.leaves = reinterpret_cast<const SymLeaf *>(r + kSymBodyOff);
-        F.pulses = pulses;
-        F.energy = energy;
-        F.leafCm = leafCm;
-        F.masks = masks;
+        F.ops = L.ops;
+        F.vecs = L.vecs;
+        F.leaves = L.leaves;
+        F.leafCm = L.leafCm;
+        F.masks = L.masks;
         float *norm2 = norm + (shape_edge(20) - shape_edge(H.start));
         unsigned seed = H.seed;
-        NYQ_WAVE_SYNC();
-        // (a) every pulse vector of the frame from its codeword: a leaf per lane
-        if (lane < 2 * 21) masks[lane] = 0;
-        const int nleaves = H.nleaves < kSymMaxLeaves ? H.nleaves : kSymMaxLeaves;
-        for (int l = lane; l < nleaves; l += kWave) {
-            const SymLeaf lf = F.leaves[l];
+        // pass A: every pulse leaf of the frame, a leaf per lane
+        for (int l = lane; l < nleaves && !NYQ_SHAPE_DBG_NO_A; l += kWave) {
+            const SymLeaf &lf = L.leaves[l];
             if (lf.kind != 0) continue;
             unsigned cm;
-            energy[l] = pvq_unrank(pvq, lf.n, lf.k, lf.index, pulses + lf.abs, lf.blocks, &cm);
-            leafCm[l] = (unsigned short)cm;
+            lane_pulse_leaf(tab, lf, X, H.spread, &cm);
+            L.leafCm[l] = (unsigned short)cm;
         }
         NYQ_WAVE_SYNC();
-        for (int q = 0; q < H.nops; q++) {
+        // pass B: the operation list
+        for (int q = 0; q < nops && !NYQ_SHAPE_DBG_NO_B; q++) {
             const SymOp o = F.ops[q];
             switch (o.kind) {
-            case 0: shape_vector(F, F.vecs[o.a], X, norm, norm2, work, tmp, seed, H.spread, lane); break;
+            case 0: shape_vector(F, F.vecs[o.a], X, norm, norm2, work, tmp, seed, lane); break;
             case 1:
                 if (lane == 0) {
                     X[o.a] = o.f0;
                     if (o.b >= 0) (o.n ? norm2 : norm)[o.b] = o.f0;
-                    masks[o.band] |= 1;
-                    masks[21 + o.band] |= 1;
+                    L.masks[o.band] |= 1;
+                    L.masks[21 + o.band] |= 1;
                 }
                 NYQ_WAVE_SYNC();
                 break;
@@ -495,13 +567,12 @@ __global__ __launch_bounds__(kWave) void celt_shape_kernel(const unsigned char *
             const int lo = shape_edge(H.start), hi = shape_edge(H.end);
             for (int j = lane; j < lo; j += kWave) fo[j] = 0.f;
             for (int i = H.start; i < H.end; i++) {
-                const float g = F.gain[c * 21 + i];
+                const float g = __shfl(laneGain, c * 21 + i);
                 const int e0 = shape_edge(i), e1 = shape_edge(i + 1);
                 for (int j = e0 + lane; j < e1; j += kWave) fo[j] = x[j] * g;
             }
             for (int j = hi + lane; j < kSymN; j += kWave) fo[j] = 0.f;
         }
-        NYQ_WAVE_SYNC();
     }
 }
 

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <condition_variable>
 #include <mutex>
 #include <iostream>
 
@@ -96,14 +97,20 @@ void nqr::OpusDecoder::LoadFromPath(AudioData *data, const std::string &path) {
 // threads -- and only its staging memory is trimmed: the first two keep up to 512 MB of page-locked memory, the others 32 MB.
 // Round 2 kept two and destroyed every further one on return, i.e. with six loading threads four decoders (24 contexts,
 // 48+ HIP streams, pinned arenas) were torn down and rebuilt per Load while the other threads were inside their GPU calls;
-// the one process abort this project has seen happened in exactly that test.  Teardown beyond kMaxIdle
-// still exists, but is serialised with construction (one at a time, g_lifecycle) and no longer part of the steady state.
+// the one process abort this project has seen happened in exactly that test.  A decoder beyond
+// kMaxIdle is RETIRED, not destroyed on the spot: it waits on a list that is drained only by the lease that brings the
+// number of active leases to zero -- no context, stream or pinned arena is ever torn down while another thread may be inside
+// a GPU call (round 4; before, teardown was merely serialised with construction).
 // The pool itself is never destroyed (no HIP call from a static destructor after the runtime has shut down).
 namespace {
 constexpr size_t kMaxIdle = 16;
 struct DecoderPool {
     std::mutex mu;
     std::map<std::vector<int>, std::vector<nyq_host::BatchOpusDecoder *>> idle;   // by device list
+    std::vector<nyq_host::BatchOpusDecoder *> retired;   // surplus decoders waiting for a moment without active leases
+    long active = 0;                         // leases alive (guarded by mu)
+    bool draining = false;                   // the retired decoders are being destroyed: new leases wait (guarded by mu)
+    std::condition_variable drained;
     std::mutex lifecycle;                    // context construction / destruction, one at a time
     std::atomic<long> created{0}, destroyed{0};
 };
@@ -118,7 +125,9 @@ struct DecoderLease {
     explicit DecoderLease(const std::vector<int> &d) : device(d) {
         DecoderPool &P = decoderPool();
         {
-            std::lock_guard<std::mutex> lk(P.mu);
+            std::unique_lock<std::mutex> lk(P.mu);
+            P.drained.wait(lk, [&] { return !P.draining; });
+            P.active++;
             auto &v = P.idle[d];
             if (!v.empty()) {
                 dec = v.back();
@@ -126,10 +135,41 @@ struct DecoderLease {
             }
         }
         if (!dec) {
-            std::lock_guard<std::mutex> lk(P.lifecycle);
-            dec = new nyq_host::BatchOpusDecoder(d);       // (throws: nothing leased, nothing to hand back)
-            P.created++;
+            try {
+                std::lock_guard<std::mutex> lk(P.lifecycle);
+                dec = new nyq_host::BatchOpusDecoder(d);   // (throws: nothing leased, nothing to hand back)
+                P.created++;
+            } catch (...) {
+                release(nullptr);
+                throw;
+            }
         }
+    }
+    // one lease less; the lease that leaves nobody behind destroys what was retired meanwhile
+    static void release(nyq_host::BatchOpusDecoder *surplus) {
+        DecoderPool &P = decoderPool();
+        std::vector<nyq_host::BatchOpusDecoder *> doomed;
+        {
+            std::lock_guard<std::mutex> lk(P.mu);
+            if (surplus) P.retired.push_back(surplus);
+            if (--P.active == 0 && !P.retired.empty()) {
+                doomed.swap(P.retired);
+                P.draining = true;                         // leases that start from here on wait until the teardown is over
+            }
+        }
+        if (doomed.empty()) return;
+        {
+            std::lock_guard<std::mutex> lk(P.lifecycle);
+            for (nyq_host::BatchOpusDecoder *d : doomed) {
+                delete d;
+                P.destroyed++;
+            }
+        }
+        {
+            std::lock_guard<std::mutex> lk(P.mu);
+            P.draining = false;
+        }
+        P.drained.notify_all();
     }
     ~DecoderLease() {                                      // never throws: trim() and the destructor only free
         DecoderPool &P = decoderPool();
@@ -147,11 +187,7 @@ struct DecoderLease {
                 dec = nullptr;
             }
         }
-        if (dec) {
-            std::lock_guard<std::mutex> lk(P.lifecycle);
-            delete dec;
-            P.destroyed++;
-        }
+        release(dec);                                      // (dec != null: beyond kMaxIdle, retired)
     }
     DecoderLease(const DecoderLease &) = delete;
     DecoderLease &operator=(const DecoderLease &) = delete;

@@ -23,12 +23,19 @@ static std::atomic<long> g_calls[kFakeDevices];
 static std::atomic<long> g_created{0}, g_destroyed{0}, g_live{0}, g_allCalls{0};
 // fault injection: every g_failCallEvery-th GPU call / every g_failCreateEvery-th context creation fails (0 = never)
 static std::atomic<long> g_failCallEvery{0}, g_failCreateEvery{0};
+// contexts destroyed while some GPU call of the process was in flight (the lease pool promises none: nqr_surface.cpp)
+static std::atomic<long> g_inFlight{0}, g_destroyedBesideCalls{0};
+struct InFlight {
+    InFlight() { g_inFlight++; }
+    ~InFlight() { g_inFlight--; }
+};
 
 extern "C" {
 
 long fake_gpu_calls(int device) { return device >= 0 && device < kFakeDevices ? g_calls[device].load() : -1; }
 void fake_gpu_counts(long *created, long *destroyed, long *live) { *created = g_created; *destroyed = g_destroyed; *live = g_live; }
 void fake_gpu_fail_every(long calls, long creates) { g_failCallEvery = calls; g_failCreateEvery = creates; }
+long fake_gpu_destroyed_beside_calls(void) { return g_destroyedBesideCalls.load(); }
 
 int nyq_device_count(void) { return kFakeDevices; }
 
@@ -44,6 +51,7 @@ int nyq_ctx_create(nyq_ctx **out, int device) {
 }
 void nyq_ctx_destroy(nyq_ctx *c) {
     if (!c) return;
+    if (g_inFlight.load() > 0) g_destroyedBesideCalls++;
     g_destroyed++;
     g_live--;
     delete c;
@@ -72,6 +80,7 @@ int nyq_celt_frames_to_pcm_mapped(nyq_ctx *ctx, int LM, const float *freq, const
                                   const float *pf_gain, const int *pf_tapset, float *out, const nyq_out_desc *desc, float *state,
                                   size_t nstreams, size_t nframes, int channels, size_t frames_per_stream) {
     const size_t N = (size_t)120 << LM, nsc = nstreams * channels;
+    InFlight guard;
     g_calls[ctx->device]++;
     const long ncall = ++g_allCalls, every = g_failCallEvery.load();
     if (every > 0 && ncall % every == 0) return NYQ_ERR_HIP;      // an injected device failure

@@ -24,6 +24,7 @@
 #include "libnyquist/Decoders.h"
 
 extern "C" void fake_gpu_counts(long *created, long *destroyed, long *live);
+extern "C" long fake_gpu_destroyed_beside_calls(void);
 extern "C" void fake_gpu_fail_every(long calls, long creates);
 namespace nyq_host { extern std::atomic<long> g_failThreadStartIn; }
 
@@ -94,9 +95,13 @@ int main(int argc, char **argv) {
     if (mode == "plain") {
         if (thrown.load() || okLoads.load() != (long)nthreads * reps * (long)files.size()) bad = 1;
         if (c1 - c0 > nthreads || d1 - d0 != 0) bad = 1;   // pooled: at most one decoder per thread, none destroyed
-    } else if (mode == "churn") {                          // more threads than the pool keeps: decoders ARE torn down beside running ones
-        if (thrown.load() || okLoads.load() != (long)nthreads * reps * (long)files.size()) bad = 1;
-        if (c1 - d1 > 16) bad = 1;
+    } else if (mode == "churn") {                          // more threads than the pool keeps: surplus decoders are retired and
+        if (thrown.load() || okLoads.load() != (long)nthreads * reps * (long)files.size()) bad = 1;   // destroyed only while no lease is active
+        if (c1 - d1 > 16 || d1 - d0 == 0) bad = 1;
+        if (fake_gpu_destroyed_beside_calls() != 0) {
+            std::printf("%ld contexts were destroyed while a GPU call was in flight\n", fake_gpu_destroyed_beside_calls());
+            bad = 1;
+        }
     } else {
         if (okLoads.load() == 0) bad = 1;                  // the faults are sparse: most loads get through
     }

@@ -283,3 +283,39 @@ def test_mapped_output_equals_the_dense_output_rearranged(ctx, oracle, lm, ch, f
     got = files.cpu().numpy()
     assert np.array_equal(got, want)
     assert np.array_equal(d_out[3].cpu().numpy(), dense[3])      # the stream without a record, dense as ever
+
+
+@pytest.mark.parametrize("form", [ONE_LAUNCH, TWO_KERNELS])
+def test_unchanged_tap_set_shortcut_on_sb_reverie_parameters(ctx, oracle, form):
+    """From a stream's second frame on, the first 120 samples of every 20 ms frame are filtered with old == current tap
+    set (celt_decoder_clean.c:678-683), where the kernels run the constant filter in place of the reference's cross-fade
+    (nyq_post_pipe.hpp, pipe_comb_call: the weights (1-f) g + f g add up to g).  Pinned here on the REAL parameter sequence
+    of sb-reverie.opus (tests/golden/sb_reverie_pf_params.npz: 7 windows of 160 frames, 76 % of the frames filtered,
+    periods 15 .. 1022) against the oracle, which cross-fades like the reference: an explicit bound on the largest
+    sample difference, not only on the RMS."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "sb_reverie_pf_params.npz"))
+    ns, nf, ch, n = 7, 160, 2, 960
+    idx = ((np.arange(ns) * 1571) % (len(z["pf_pitch"]) - nf))[:, None] + np.arange(nf)[None, :]
+    pitch = z["pf_pitch"][idx].astype(np.int32)
+    gain = z["pf_gain_q"][idx].astype(np.float32) * np.float32(0.09375)
+    taps = z["pf_tapset"][idx].astype(np.int32)
+    tr = z["transient"][idx].astype(np.uint8)
+    same = (pitch[:, 1:] == pitch[:, :-1]) & (gain[:, 1:] == gain[:, :-1]) & (taps[:, 1:] == taps[:, :-1]) & (gain[:, 1:] != 0)
+    assert (gain != 0).mean() > 0.5 and same.sum() > 50         # (plenty of frames on either branch of the shortcut)
+    rng = np.random.default_rng(777)
+    freq = (rng.standard_normal((ns, nf, ch, n)) * 30).astype(np.float32)
+    ov = (rng.standard_normal((ns * ch, 60)) * 30).astype(np.float32)
+    hist = (rng.standard_normal((ns * ch, 1088)) * 30).astype(np.float32)
+    pst = np.stack([[pitch[s, 0], pitch[s, 0], gain[s, 0], gain[s, 0], taps[s, 0], taps[s, 0]] for s in range(ns)]).astype(np.float32)
+    dm = (rng.standard_normal(ns * ch) * 10).astype(np.float32)
+    ctx.set_tables(*oracle.tables()[:2])
+    wp, ws = oracle.celt_synth(3, freq, tr, ov, nthreads=4)
+    want, filt, wst, wdm = oracle.celt_post(3, np.concatenate([hist.reshape(ns, ch, 1088), wp.reshape(ns, ch, nf * n)], axis=2), 1088,
+                                            pitch, gain, taps, pst, dm)
+    out, gst, gov, gh, gdm = _run_chain(ctx, 3, freq, tr, pitch, gain, taps, pst, ov, hist, dm, ch, form=form)
+    peak = float(np.abs(want).max())
+    worst = float(np.abs(out - want).max())
+    print(f"form {form}: largest sample difference {worst:.3e} at a peak of {peak:.3e} ({worst / peak:.2e} of it), rel rms {rel_rms(out, want):.2e}")
+    assert worst <= 4e-6 * peak                                  # (what 4e-6 of full scale is to the file-level PCM tests)
+    assert rel_rms(out, want) <= 2e-6
+    assert np.array_equal(gst, wst)

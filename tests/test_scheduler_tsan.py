@@ -81,8 +81,9 @@ def test_concurrent_loads_lease_pool(san, mode, threads, reps, files):
     ThreadSanitizer and AddressSanitizer.  plain: bit-exact, no decoder torn down; gpu-faults: every 29th GPU call and every
     17th context creation fail -> std::runtime_error out of Load, nothing else, survivors bit-exact, no context leaked;
     thread-faults: thread starts fail on and off -> the batch runs on the threads it gets or throws, no joinable thread is
-    ever destroyed (that is std::terminate -> abort); churn: 22 threads against a pool of 16 -> decoders are torn down
-    beside running ones, still bit-exact."""
+    ever destroyed (that is std::terminate -> abort); churn: 22 threads against a pool of 16 -> the surplus decoders are
+    retired and destroyed only at a moment without active leases (the stand-in counts contexts destroyed while a GPU call is
+    in flight: none), still bit-exact."""
     subprocess.run(["make", "-C", SCHED, "lease"], check=True, stdout=subprocess.DEVNULL)
     e = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66")
     r = subprocess.run([os.path.join(SCHED, f"lease_check_{san}"), mode, str(threads), str(reps)] + [os.path.join(GOLDEN, f) for f in files],
