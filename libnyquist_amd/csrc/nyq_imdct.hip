@@ -829,13 +829,16 @@ static_assert(sizeof(nyq_sym_head) == sizeof(SymHead) && sizeof(nyq_sym_leaf) ==
 
 extern "C" size_t nyq_celt_symbol_bytes(int channels) { return channels == 1 || channels == 2 ? sym_bytes(channels) : 0; }
 
-static int shape_core(nyq_ctx *ctx, const void *d_sym, float *d_freq, size_t nstreams, size_t nframes, int channels, size_t sstride) {
+// sstride / fstride: frames per stream in d_sym / d_freq (0 = nframes: dense)
+static int shape_core(nyq_ctx *ctx, const void *d_sym, float *d_freq, size_t nstreams, size_t nframes, int channels, size_t sstride,
+                      size_t fstride = 0) {
     if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_celt_shape_dev: ctx is NULL");
     if (channels != 1 && channels != 2) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_shape_dev: symbol records carry mono and stereo streams");
     if (nstreams == 0 || nframes == 0) return NYQ_OK;
     if (!d_sym || !d_freq) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_shape_dev: NULL buffer");
     if (sstride == 0) sstride = nframes;
-    if (sstride < nframes) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_shape_dev: sstride is smaller than nframes");
+    if (fstride == 0) fstride = nframes;
+    if (sstride < nframes || fstride < nframes) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_shape_dev: a stride is smaller than nframes");
     const size_t total = nstreams * nframes;
     if (total > (size_t)0x7fffffff) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_shape_dev: more than 2^31 frames in one call");
     NYQ_HIP(ctx, hipSetDevice(ctx->device));
@@ -850,7 +853,7 @@ static int shape_core(nyq_ctx *ctx, const void *d_sym, float *d_freq, size_t nst
     const size_t want = (total + kShapeWaves - 1) / kShapeWaves, resident = (size_t)ctx->cus;
     const unsigned grid = (unsigned)(want < resident ? want : resident);
     hipLaunchKernelGGL(celt_shape_kernel, dim3(grid), dim3(kWave * kShapeWaves), 0, ctx->stream, static_cast<const unsigned char *>(d_sym), d_freq,
-                       ctx->d_pvq, (long)nstreams, (long)nframes, channels, (long)sstride);
+                       ctx->d_pvq, (long)nstreams, (long)nframes, channels, (long)sstride, (long)fstride);
     NYQ_HIP(ctx, hipGetLastError());
     return NYQ_OK;
 }
@@ -1051,6 +1054,8 @@ struct DrainOnExit {
 // of piece k and the download of piece k-1 run at the same time (three streams, events between them).
 constexpr size_t kHostPieceBytes = (size_t)32 << 20;   // of input per piece
 constexpr size_t kHostMaxPieces = 64;
+constexpr size_t kHostWindowBytes = (size_t)24 << 20;  // of input per time window (frames -> PCM calls on few long streams)
+constexpr size_t kHostMaxWindows = 256;
 
 static int imdct_host(nyq_ctx *ctx, int shift, const float *in, const float *carry, size_t carry_rows, float *fin,
                       float *tail, size_t tail_rows, size_t nchains, size_t len, bool chain) {
@@ -1195,7 +1200,8 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
                  n_pf = round16f(nstreams * 6);
     const size_t n_ds = desc ? round16f(nstreams * sizeof(nyq_out_desc) / sizeof(float)) : 0;
     const size_t n_sy = sym ? round16f(nfr * rec / sizeof(float)) : 0;
-    int rc = need_scratch(ctx, (3 * n_x + n_w + 3 * n_p + n_t + n_ov + n_hi + n_de + 2 * n_pf + n_ds + n_sy) * sizeof(float));
+    const size_t n_dw = desc ? kHostMaxWindows * n_ds : 0;           // (the time-window form: a set of records per window)
+    int rc = need_scratch(ctx, (3 * n_x + n_w + 3 * n_p + n_t + n_ov + n_hi + n_de + 2 * n_pf + n_ds + n_sy + n_dw) * sizeof(float));
     if (rc != NYQ_OK) return rc;
     float *d_x = ctx->d_scratch, *d_pcm = d_x + n_x, *d_out = d_pcm + n_x, *d_w = d_out + n_x, *d_pg = d_w + n_w;
     int *d_pp = reinterpret_cast<int *>(d_pg + n_p), *d_pt = d_pp + n_p;
@@ -1219,6 +1225,89 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
     const size_t round_streams = nyq_celt_post_round_chains(ctx) / (size_t)channels;
     if (round_streams >= 32 && per > round_streams) per = per / round_streams * round_streams;
     const size_t npieces = (nstreams + per - 1) / per;
+    // FEW LONG streams (one piece): the call is cut in TIME instead -- windows of W frames (a multiple of 64: the kernels' in-wave
+    // carry chains restart at the same frames as in one launch, bit-identical), upload of window w+1, kernels of window w and
+    // download of window w-1 at the same time; the decoder states travel from window to window in device memory.  This is the
+    // shape of a batch decoder's time slices when the GPU side is what the job waits for.
+    if (npieces == 1 && nframes >= 256) {
+        const size_t frame_in = sym ? rec : (size_t)channels * N * sizeof(float);
+        size_t W = ((kHostWindowBytes / (nstreams * frame_in)) / 64) * 64;
+        if (W < 64) W = 64;
+        const size_t nwin = (nframes + W - 1) / W;
+        if (nwin >= 2 && nwin <= kHostMaxWindows) {
+            rc = need_copy_streams(ctx, 2 * nwin + 1);
+            if (rc != NYQ_OK) return rc;
+            DrainOnExit drain{ctx};
+            hipStream_t hs = ctx->s_h2d, ds = ctx->s_d2h;
+            hipEvent_t ev0 = ctx->ev_pool[2 * nwin];
+            NYQ_HIP(ctx, hipEventRecord(ev0, ctx->stream));
+            NYQ_HIP(ctx, hipStreamWaitEvent(hs, ev0, 0));
+            NYQ_HIP(ctx, hipStreamWaitEvent(ds, ev0, 0));
+            // per-frame parameters, descriptors and the states: small, the whole call's at once
+            if (transient) NYQ_HIP(ctx, copy_rows(d_t, nframes, transient, hstride, nframes, nstreams, hipMemcpyHostToDevice, hs));
+            NYQ_HIP(ctx, copy_rows(d_pg, nframes * 4, pf_gain, hstride * 4, nframes * 4, nstreams, hipMemcpyHostToDevice, hs));
+            NYQ_HIP(ctx, copy_rows(d_pp, nframes * 4, pf_pitch, hstride * 4, nframes * 4, nstreams, hipMemcpyHostToDevice, hs));
+            NYQ_HIP(ctx, copy_rows(d_pt, nframes * 4, pf_tapset, hstride * 4, nframes * 4, nstreams, hipMemcpyHostToDevice, hs));
+            // a window's output records: the stream's with t0 moved to the window's first sample (need_scratch above sized d_ds
+            // for one set; the windows' sets live behind the symbol region: see n_dw)
+            std::vector<nyq_out_desc> wdesc;
+            nyq_out_desc *d_dw = nullptr;
+            if (desc) {
+                wdesc.resize(nwin * nstreams);
+                for (size_t w = 0; w < nwin; w++)
+                    for (size_t k = 0; k < nstreams; k++) {
+                        wdesc[w * nstreams + k] = desc[k];
+                        wdesc[w * nstreams + k].t0 += (long long)(w * W * N);
+                    }
+                d_dw = reinterpret_cast<nyq_out_desc *>(d_pfo + n_pf + n_ds + n_sy);
+                NYQ_HIP(ctx, hipMemcpyAsync(d_dw, wdesc.data(), wdesc.size() * sizeof(nyq_out_desc), hipMemcpyHostToDevice, hs));
+            }
+            if (state) {
+                NYQ_HIP(ctx, hipMemcpyAsync(d_ov, h_ov, nsc * NYQ_HALF_OV * sizeof(float), hipMemcpyHostToDevice, hs));
+                NYQ_HIP(ctx, hipMemcpyAsync(d_hi, h_hi, nsc * kPostHist * sizeof(float), hipMemcpyHostToDevice, hs));
+                NYQ_HIP(ctx, hipMemcpyAsync(d_de, h_de, nsc * sizeof(float), hipMemcpyHostToDevice, hs));
+                NYQ_HIP(ctx, hipMemcpyAsync(d_pfi, h_pf, nstreams * 6 * sizeof(float), hipMemcpyHostToDevice, hs));
+            } else {                                                 // a fresh decoder: zero state, carried between the windows all the same
+                NYQ_HIP(ctx, hipMemsetAsync(d_ov, 0, nsc * NYQ_HALF_OV * sizeof(float), hs));
+                NYQ_HIP(ctx, hipMemsetAsync(d_hi, 0, nsc * kPostHist * sizeof(float), hs));
+                NYQ_HIP(ctx, hipMemsetAsync(d_de, 0, nsc * sizeof(float), hs));
+                NYQ_HIP(ctx, hipMemsetAsync(d_pfi, 0, nstreams * 6 * sizeof(float), hs));
+            }
+            float *pf_a = d_pfi, *pf_b = d_pfo;
+            for (size_t w = 0; w < nwin; w++) {
+                const size_t f0 = w * W, len = nframes - f0 < W ? nframes - f0 : W;
+                hipEvent_t up = ctx->ev_pool[2 * w], done = ctx->ev_pool[2 * w + 1];
+                if (sym) NYQ_HIP(ctx, copy_rows(d_sy + f0 * rec, nframes * rec, sym + f0 * rec, hstride * rec, len * rec, nstreams, hipMemcpyHostToDevice, hs));
+                else NYQ_HIP(ctx, copy_rows(d_x + f0 * channels * N, nframes * channels * N * sizeof(float), freq + f0 * channels * N,
+                                            hstride * channels * N * sizeof(float), len * channels * N * sizeof(float), nstreams, hipMemcpyHostToDevice, hs));
+                NYQ_HIP(ctx, hipEventRecord(up, hs));
+                NYQ_HIP(ctx, hipStreamWaitEvent(ctx->stream, up, 0));
+                if (sym) rc = shape_core(ctx, d_sy + f0 * rec, d_x + f0 * channels * N, nstreams, len, channels, nframes, nframes);
+                if (rc == NYQ_OK)
+                    rc = chain_core(ctx, LM, d_x + f0 * channels * N, transient ? d_t + f0 : nullptr, d_pp + f0, d_pg + f0, d_pt + f0, pf_a, pf_b, d_ov,
+                                    d_hi, d_de, d_out + f0 * N * channels, d_pcm, d_w, nstreams, len, channels, nframes,
+                                    reinterpret_cast<const OutDesc *>(desc ? d_dw + w * nstreams : nullptr));
+                if (rc != NYQ_OK) return rc;                         // (DrainOnExit waits for what is in flight)
+                NYQ_HIP(ctx, hipEventRecord(done, ctx->stream));
+                NYQ_HIP(ctx, hipStreamWaitEvent(ds, done, 0));
+                if (!all_mapped)
+                    NYQ_HIP(ctx, copy_rows(out + f0 * N * channels, hstride * channels * N * sizeof(float), d_out + f0 * N * channels,
+                                           nframes * channels * N * sizeof(float), len * channels * N * sizeof(float), nstreams, hipMemcpyDeviceToHost, ds));
+                float *t = pf_a;
+                pf_a = pf_b;
+                pf_b = t;
+            }
+            if (state) {                                             // (ds is behind the last window's kernels)
+                NYQ_HIP(ctx, hipMemcpyAsync(h_ov, d_ov, nsc * NYQ_HALF_OV * sizeof(float), hipMemcpyDeviceToHost, ds));
+                NYQ_HIP(ctx, hipMemcpyAsync(h_hi, d_hi, nsc * kPostHist * sizeof(float), hipMemcpyDeviceToHost, ds));
+                NYQ_HIP(ctx, hipMemcpyAsync(h_de, d_de, nsc * sizeof(float), hipMemcpyDeviceToHost, ds));
+                NYQ_HIP(ctx, hipMemcpyAsync(h_pf, pf_a, nstreams * 6 * sizeof(float), hipMemcpyDeviceToHost, ds));
+            }
+            if ((rc = wait_blocking(ctx, ds)) != NYQ_OK) return rc;
+            if ((rc = wait_blocking(ctx, ctx->stream)) != NYQ_OK) return rc;
+            return NYQ_OK;
+        }
+    }
     rc = need_copy_streams(ctx, 2 * npieces + 1);
     if (rc != NYQ_OK) return rc;
     DrainOnExit drain{ctx};

@@ -62,6 +62,13 @@ NYQ_HD void st_f4(float *p, f4 v) {
     *reinterpret_cast<f4 *>(p) = v;
 }
 
+// rows per wave-group of the two short transforms (measurement switches: tools/variant_ab.py; see Geo::G)
+#ifndef NYQ_G60
+#define NYQ_G60 16
+#endif
+#ifndef NYQ_G120
+#define NYQ_G120 8
+#endif
 constexpr int kOverlap = 120;   // static_modes_float.h:579
 constexpr int kHalfOv = 60;
 constexpr int kWave = 64;
@@ -77,7 +84,7 @@ struct Geo {
     // rows per wave-group: enough that the radix-15 pass (N2R lanes per row) fills the wavefront and that a
     // group keeps >= 7.5 KB of loads in flight: 4, 8, 8, 16 rows for nfft 480, 240, 120, 60 (16 rows at nfft 120 cost the
     // frame-synthesis kernel its second wave per SIMD: 256 VGPRs)
-    static constexpr int G = N2R == 32 ? 4 : N2R == 4 ? 16 : 8;
+    static constexpr int G = N2R == 32 ? 4 : N2R == 4 ? NYQ_G60 : N2R == 8 ? NYQ_G120 : 8;
     static constexpr int SUBS = G * SLOT / kWave;        // stage sub-iterations per group
     static constexpr int JSETS = SLOT > kWave ? SLOT / kWave : 1;
     static constexpr int S = (N4 % 32 <= 16) ? (N4 - N4 % 32 + 16) : (N4 - N4 % 32 + 48);

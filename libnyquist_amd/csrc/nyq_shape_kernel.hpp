@@ -444,7 +444,7 @@ __device__ __forceinline__ void stage_words(void *dst, const void *src, int byte
 
 __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const unsigned char *__restrict__ sym, float *__restrict__ freq,
                                                                         const unsigned *__restrict__ pvq, long nstreams, long nframes,
-                                                                        int channels, long sstride) {
+                                                                        int channels, long sstride, long fstride) {
 #pragma clang fp contract(off)
     __shared__ __attribute__((aligned(16))) ShapeWaveLds wl[kShapeWaves];
     __shared__ unsigned tab[kPvqInfo + kPvqWords];
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const un
     for (long u = (long)blockIdx.x * kShapeWaves + wv; u < total; u += (long)gridDim.x * kShapeWaves) {
         const long s = u / nframes, f = u - s * nframes;
         const unsigned char *r = sym + ((size_t)s * (size_t)sstride + (size_t)f) * rec;
-        float *out = freq + (size_t)u * (size_t)channels * kSymN;
+        float *out = freq + ((size_t)s * (size_t)fstride + (size_t)f) * (size_t)channels * kSymN;
         const SymHead H = *reinterpret_cast<const SymHead *>(r);
         const int C = channels;
         if (H.flags & 1) {                                           // the host built this frame itself: its freq[] is the body

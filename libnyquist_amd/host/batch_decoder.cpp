@@ -324,6 +324,7 @@ public:
     // 20 ms mono / stereo streams hand SYMBOL records to the GPU (their band shapes are built there); off: freq[] as for every other shape
     bool symbolRecords_ = true;
     bool symbolRecords() const { return symbolRecords_; }
+    bool trace_ = false;
 
     // returns when every file of the sub-batch is decoded (or has its error set); throws if the GPU failed
     void run() {
@@ -332,7 +333,7 @@ public:
         planOutput();
         layout();
         placeOutput();
-        std::chrono::steady_clock::time_point t1;
+        std::chrono::steady_clock::time_point t1, tDecode0;
         {
             // The feeders are joined whichever way this block is left.  If anything throws in here (a feeder that cannot
             // be started, an exception out of a decoding thread) the guard below raises `abort_` first, so that feeders
@@ -361,13 +362,16 @@ public:
             } catch (const std::system_error &e) {
                 if (feeders.size() < (size_t)ndev_) throw std::runtime_error(std::string("cannot start a feeder thread per device: ") + e.what());
             }
+            tDecode0 = std::chrono::steady_clock::now();
             parallelFor(members_.size(), threads_, [&](size_t mi) { decodeFile(members_[mi]); });
             t1 = std::chrono::steady_clock::now();
             guard.armed = false;
             cv_.notify_all();
         }
+        const auto tJoined = std::chrono::steady_clock::now();
         if (!gpuError_.empty()) throw std::runtime_error(gpuError_);
         laterSegments();
+        const auto tLater = std::chrono::steady_clock::now();
         // pass 3 for the files that could not be finished as their pieces completed (later segments, or a stream of
         // the file in a piece that ended after the file's other streams)
         parallelFor(members_.size(), threads_, [&](size_t mi) {
@@ -377,6 +381,14 @@ public:
         });
         cpuSeconds = std::chrono::duration<double>(t1 - tb).count();
         tailSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+        if (trace_) {                                           // NYQ_BATCH_TRACE=1: where a sub-batch's time goes (stderr)
+            auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+                return std::chrono::duration<double, std::milli>(b - a).count();
+            };
+            std::fprintf(stderr, "[nyq batch] %zu files, %zu pieces: set-up %.1f ms, entropy stage %.1f, feeders drained +%.1f, later segments +%.1f, "
+                                 "finish +%.1f\n", members_.size(), pieces_.size(), ms(tb, tDecode0), ms(tDecode0, t1), ms(t1, tJoined),
+                         ms(tJoined, tLater), ms(tLater, std::chrono::steady_clock::now()));
+        }
         for (double b : gpuBusy_) busySeconds += b;
     }
 
@@ -460,8 +472,11 @@ private:
             std::memset(g.pp, 0, q * 4);
             std::memset(g.pt, 0, q * 4);
             std::memset(g.tr, 0, q);
-            // ~24 MB of freq per piece, but never fewer streams than decoding threads: long streams finish in rounds
-            // of `threads` files, and the GPU's post-filter (one sequential wave per channel) wants them together
+            // ~24 MB of input per piece, but never fewer streams than decoding threads: long streams finish in rounds
+            // of `threads` files, and the GPU's post-filter (one sequential wave per channel) wants them together.
+            // (Smaller pieces of long streams -- 4 or 8 streams, more slice chains side by side -- were measured in
+            // round 4: -5 % ... +9 % of the job's wall time, profiles/r04_v_piece_ab.txt; what the job waited for was
+            // the serial upload -> kernels -> download of every slice, now pipelined inside the library call.)
             const size_t per = std::max<size_t>((size_t)std::max(1, threads_), kPieceBytes / std::max<size_t>(1, g.maxF * g.frameBytes));
             for (size_t k0 = 0; k0 < g.ns; k0 += per) {
                 pieces_.emplace_back();
@@ -632,9 +647,17 @@ private:
             Piece &p = pieces_[pi];
             const Group &g = groups_[p.group];
             const size_t myslice = p.nextSlice;
-            const size_t f0 = myslice * p.sliceLen, len = std::min(p.sliceLen, g.maxF - f0);
-            const size_t so = p.k0 * g.maxF + f0;         // first stream of the piece, first frame of the slice
-            const bool last = myslice + 1 == p.nslices;
+            // every slice that is ready goes in this one call: when the GPU side is what the job waits for, the slices pile
+            // up, and inside one call the library pipelines them (upload / kernels / download of consecutive time windows)
+            size_t m = 1;
+            {
+                long avail = (long)g.maxF;
+                for (size_t k = p.k0; k < p.k1; k++) avail = std::min(avail, progress_[g.ids[k]].load(std::memory_order_acquire));
+                while (myslice + m < p.nslices && (long)std::min((myslice + m + 1) * p.sliceLen, g.maxF) <= avail) m++;
+            }
+            const size_t f0 = myslice * p.sliceLen, len = std::min(m * p.sliceLen, g.maxF - f0);
+            const size_t so = p.k0 * g.maxF + f0;         // first stream of the piece, first frame of the slices
+            const bool last = myslice + m == p.nslices;
             bool released = false, ok = false;
             const auto c0 = std::chrono::steady_clock::now();
             try {
@@ -660,7 +683,7 @@ private:
                 // state, which is back on the host) while this thread copies samples out
                 if (!last) {
                     std::lock_guard<std::mutex> lk(mu_);
-                    p.nextSlice++;
+                    p.nextSlice += m;
                     p.inFlight = false;
                     released = true;
                     offer(pi);
@@ -672,7 +695,7 @@ private:
                 handOver(p, f0, len);
                 {
                     std::lock_guard<std::mutex> lk(mu_);
-                    p.appendTurn = myslice + 1;
+                    p.appendTurn = myslice + m;
                 }
                 cvAppend_.notify_all();
                 if (last && p.anyMore) keepStates(ctx, p);
@@ -693,7 +716,7 @@ private:
                 std::unique_lock<std::mutex> lk(mu_);
                 cvAppend_.wait(lk, [&] { return p.appendTurn >= myslice; });   // (earlier slices always get there)
                 if (p.appendTurn == myslice) {              // an error above skipped the hand-over: do not block later slices
-                    p.appendTurn = myslice + 1;
+                    p.appendTurn = myslice + m;
                     cvAppend_.notify_all();
                 }
                 finishFiles = last && ok && gpuError_.empty();   // (after a GPU failure run() throws: no file is finished)
@@ -701,7 +724,7 @@ private:
             if (finishFiles) finishFilesOf(p, which);
             std::lock_guard<std::mutex> lk(mu_);
             if (!released) {
-                p.nextSlice++;
+                p.nextSlice += m;
                 p.inFlight = false;
                 if (p.nextSlice == p.nslices) {
                     if (++finishedPieces_ == pieces_.size()) cv_.notify_all();
@@ -920,6 +943,7 @@ BatchOpusDecoder::BatchOpusDecoder(const std::vector<int> &devices) : devices_(d
         if (v > 0) stagingBudget_ = (size_t)v;
     }
     if (const char *e = std::getenv("NYQ_HOST_SYMBOLS")) symbolRecords_ = std::atoi(e) != 0;   // (A/B switch, read once like the budget)
+    if (const char *e = std::getenv("NYQ_BATCH_TRACE")) trace_ = std::atoi(e) != 0;
     const int ndev = nyq_device_count();
     for (int d : devices_)
         if (d < 0 || d >= ndev)
@@ -1083,6 +1107,7 @@ void BatchOpusDecoder::decodeImpl(const std::vector<const std::vector<uint8_t> *
                 }
         SubBatch sb(jobs, out, members, ctx_.data(), (int)devices_.size(), kFeeders, threads, arenaFn, devArenaFn);
         sb.symbolRecords_ = symbolRecords_;
+        sb.trace_ = trace_;
         sb.run();
         cpuSecs += sb.cpuSeconds;
         tailSecs += sb.tailSeconds;

@@ -79,7 +79,18 @@ def run(ns, nf, cases):
         torch.cuda.synchronize(dev)
         rows = ns * nf * ch
         tail_buf = torch.empty((rows, 60), device=dev)
+        # the verdict's three "slow kernels" on the same bytes: nfft-60 rows (8 x as many rows of an eighth the length), LM 1
+        # frame synthesis (4 x as many 240-sample frames, 2.8 % transient), post-filter of LM 1 frames
+        rows60 = rows * 8
+        tail60 = torch.empty((rows60, 60), device=dev) if "rows60" in (os.environ.get("VAB_OPS") or "") else tail_buf
+        nf1 = nf * 4
+        trans1 = (torch.rand((ns, nf1), generator=g, device=dev) < 0.028).to(torch.uint8)
+        work1 = torch.empty(ctxs[0].celt_synth_work_floats(ns, nf1, ch), device=dev)
+        pitch1, gain1, tap1 = (t.repeat_interleave(4, dim=1).contiguous() for t in (pitch, gain, tap))
         ops = {"imdct_rows": lambda c: c.imdct_batch_dev(0, freq.data_ptr(), 0, pcm.data_ptr(), tail_buf.data_ptr(), rows),
+               "rows60": lambda c: c.imdct_batch_dev(3, freq.data_ptr(), 0, pcm.data_ptr(), tail60.data_ptr(), rows60),
+               "synth1": lambda c: c.celt_synth_dev(1, freq.data_ptr(), trans1.data_ptr(), pcm.data_ptr(), 0, work1.data_ptr(), ns, nf1, ch),
+               "post1": lambda c: c.celt_post_dev(1, pcm.data_ptr(), pitch1.data_ptr(), gain1.data_ptr(), tap1.data_ptr(), 0, 0, 0, 0, out.data_ptr(), ns, nf1, ch),
                "synth": lambda c: c.celt_synth_dev(3, freq.data_ptr(), trans.data_ptr(), pcm.data_ptr(), 0, work.data_ptr(), ns, nf, ch),
                "post": lambda c: c.celt_post_dev(3, pcm.data_ptr(), pitch.data_ptr(), gain.data_ptr(), tap.data_ptr(), 0, 0, 0, 0, out.data_ptr(), ns, nf, ch),
                "chain": lambda c: c.celt_chain_dev(3, freq.data_ptr(), trans.data_ptr(), pitch.data_ptr(), gain.data_ptr(), tap.data_ptr(), 0, 0, 0, 0, 0,
