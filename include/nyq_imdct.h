@@ -227,9 +227,14 @@ int nyq_device_dup_channel(nyq_ctx *ctx, float *d_base, int cstride, int src_slo
  * a short program of vector operations, the band gains) and nyq_celt_shape_dev builds freq[] from them on the device, one
  * wavefront per frame.  20 ms frames (LM 3), mono or stereo.  One frame = one record of nyq_celt_symbol_bytes(channels):
  *     nyq_sym_head | float gain[42] (2^(energy + mean) per band, channel-major) | nyq_sym_op ops[113] | nyq_sym_vec vecs[44] |
- *     body: nyq_sym_leaf leaves[.. 96 * channels]  --  or, with NYQ_SYM_HOST_FREQ, float freq[channels * 960]
- * A record of zeros is a silent frame.  Offsets inside a frame are in floats of X (channel c at c * 960). */
-#define NYQ_SYM_HOST_FREQ 1          /* flags: the body holds freq[] computed on the host (anti-collapse frames, overlong leaf lists) */
+ *     body: nyq_sym_leaf leaves[nleaves] (+ float level[42] with NYQ_SYM_ANTI_COLLAPSE)  --  or, with NYQ_SYM_HOST_FREQ,
+ *           float freq[channels * 960]
+ * A record of zeros is a silent frame.  Offsets inside a frame are in floats of X (channel c at c * 960).  head.channels is
+ * what the PACKET codes (the TOC's stereo flag); where it differs from the stream's `channels` the device duplicates the one
+ * coded channel or mixes the two down, as celt_decoder_clean.c:648-652 does. */
+#define NYQ_SYM_HOST_FREQ 1          /* flags: the body holds freq[] computed on the host (overlong leaf lists, frames that are not 20 ms) */
+#define NYQ_SYM_ANTI_COLLAPSE 2      /* flags: float level[42] (channel-major) follows the leaves: short blocks of a transient frame that
+                                        received nothing are filled with noise at that level, then the band is renormalised (bands.c:258-351) */
 #define NYQ_SYM_MAX_OPS   113
 #define NYQ_SYM_MAX_VECS  44
 typedef struct nyq_sym_head {

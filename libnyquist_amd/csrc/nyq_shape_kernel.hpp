@@ -294,6 +294,10 @@ struct ShapeFrame {                  // (all in the wave's LDS slice)
 __device__ __forceinline__ void shape_vector(const ShapeFrame &F, const SymVec v, float *X, float *norm, float *norm2, float *work,
                                              float *tmp, unsigned &seed, int lane) {
 #pragma clang fp contract(off)
+    if (v.n < 2 || v.n > 176 || v.x < 0 || v.x + v.n > 2 * kSymN || v.recombine > 3 || v.time_divide > 3 || v.b_tree < 1 || v.b_tree > 16 ||
+        v.b_in < 1 || v.b_in > 8 || v.leaf0 < 0 || v.leaf1 < v.leaf0 || v.leaf1 - v.leaf0 > 16 || v.leaf1 > kSymMaxLeaves || v.band > 20 ||
+        v.fill_hi > 21 || v.fold + v.n > kShapeNorm / 2 || v.out + v.n > kShapeNorm / 2)
+        return;                                                      // (not a vector the entropy stage can have written)
     float *x = X + v.x;
     const int n = v.n, recombine = v.recombine, timeDivide = v.time_divide, Btree = v.b_tree;
     const bool longBlocks = v.b_in == 1;
@@ -312,7 +316,11 @@ __device__ __forceinline__ void shape_vector(const ShapeFrame &F, const SymVec v
     for (int l = v.leaf0; l < v.leaf1; l++) {
         const SymLeaf &lf = F.leaves[l];
         unsigned lcm, kind = 0;
-        if (lf.kind == 0) {
+        const bool sane = lf.off >= 0 && lf.n >= 1 && lf.off + lf.n <= n && lf.fold_off + lf.n <= n && lf.blocks >= 1 && lf.blocks <= 16 &&
+                          lf.shift <= 15;
+        if (!sane) {
+            lcm = 0;                                                 // (a damaged record: the leaf is left alone)
+        } else if (lf.kind == 0) {
             lcm = F.leafCm[l];
         } else {
             unsigned fill = 0;
@@ -460,16 +468,22 @@ __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const un
         const unsigned char *r = sym + ((size_t)s * (size_t)sstride + (size_t)f) * rec;
         float *out = freq + ((size_t)s * (size_t)fstride + (size_t)f) * (size_t)channels * kSymN;
         const SymHead H = *reinterpret_cast<const SymHead *>(r);
-        const int C = channels;
+        const int CC = channels;                                     // the stream's channels: the layout of freq[]
         if (H.flags & 1) {                                           // the host built this frame itself: its freq[] is the body
             const float4 *b4 = reinterpret_cast<const float4 *>(r + kSymBodyOff);
             float4 *o4 = reinterpret_cast<float4 *>(out);
-            for (int j = lane; j < C * kSymN / 4; j += kWave) o4[j] = b4[j];
+            for (int j = lane; j < CC * kSymN / 4; j += kWave) o4[j] = b4[j];
             continue;
         }
         if (H.nops == 0) {                                           // a record of zeros: a silent (or padding) frame
             float4 *o4 = reinterpret_cast<float4 *>(out);
-            for (int j = lane; j < C * kSymN / 4; j += kWave) o4[j] = float4{0.f, 0.f, 0.f, 0.f};
+            for (int j = lane; j < CC * kSymN / 4; j += kWave) o4[j] = float4{0.f, 0.f, 0.f, 0.f};
+            continue;
+        }
+        const int C = H.channels == 2 ? 2 : 1;                       // what the packet codes
+        if (H.start > 20 || H.end > 21 || H.start > H.end) {         // (a damaged head: a silent frame)
+            float4 *o4 = reinterpret_cast<float4 *>(out);
+            for (int j = lane; j < CC * kSymN / 4; j += kWave) o4[j] = float4{0.f, 0.f, 0.f, 0.f};
             continue;
         }
         const int nleaves = H.nleaves < kSymMaxLeaves ? H.nleaves : kSymMaxLeaves;
@@ -493,8 +507,12 @@ __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const un
         for (int l = lane; l < nleaves && !NYQ_SHAPE_DBG_NO_A; l += kWave) {
             const SymLeaf &lf = L.leaves[l];
             if (lf.kind != 0) continue;
-            unsigned cm;
-            lane_pulse_leaf(tab, lf, X, H.spread, &cm);
+            // (records come from the host's entropy stage; a damaged one must still leave every loop of this kernel bounded:
+            // a leaf that cannot be a leaf is skipped)
+            const bool sane = lf.n >= 2 && lf.n <= 176 && lf.k >= 1 && lf.k <= 176 && lf.blocks >= 1 && lf.blocks <= 16 && lf.abs >= 0 &&
+                              lf.abs + lf.n <= 2 * kSymN;
+            unsigned cm = 0;
+            if (sane) lane_pulse_leaf(tab, lf, X, H.spread, &cm);
             L.leafCm[l] = (unsigned short)cm;
         }
         NYQ_WAVE_SYNC();
@@ -502,9 +520,11 @@ __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const un
         for (int q = 0; q < nops && !NYQ_SHAPE_DBG_NO_B; q++) {
             const SymOp o = F.ops[q];
             switch (o.kind) {
-            case 0: shape_vector(F, F.vecs[o.a], X, norm, norm2, work, tmp, seed, lane); break;
+            case 0:
+                if (o.a >= 0 && o.a < nvecs) shape_vector(F, F.vecs[o.a], X, norm, norm2, work, tmp, seed, lane);
+                break;
             case 1:
-                if (lane == 0) {
+                if (lane == 0 && o.a >= 0 && o.a < 2 * kSymN && o.b < kShapeNorm / 2 && o.band <= 20) {
                     X[o.a] = o.f0;
                     if (o.b >= 0) (o.n ? norm2 : norm)[o.b] = o.f0;
                     L.masks[o.band] |= 1;
@@ -513,7 +533,7 @@ __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const un
                 NYQ_WAVE_SYNC();
                 break;
             case 2:
-                if (lane == 0) {
+                if (lane == 0 && o.a >= 0 && o.b >= 0 && o.a + 2 <= 2 * kSymN && o.b + 2 <= 2 * kSymN) {
                     float *x = X + o.a, *y = X + o.b;
                     const int sign = (o.n & 1) ? -1 : 1;
                     float *x2 = (o.n & 2) ? y : x, *y2 = (o.n & 2) ? x : y;
@@ -528,6 +548,7 @@ __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const un
                 NYQ_WAVE_SYNC();
                 break;
             case 3: {                                                // mid / side -> left / right (bands.c:391-441)
+                if (o.a < 0 || o.b < 0 || o.n < 0 || o.a + o.n > 2 * kSymN || o.b + o.n > 2 * kSymN) break;
                 float *x = X + o.a, *y = X + o.b;
                 const float mid = o.f0;
                 float a = 0.f, b = 0.f;
@@ -551,27 +572,66 @@ __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const un
                 break;
             }
             case 4:
+                if (o.a < 0 || o.n < 0 || o.a + o.n > 2 * kSymN) break;
                 for (int j = lane; j < o.n; j += kWave) X[o.a + j] = -X[o.a + j];
                 NYQ_WAVE_SYNC();
                 break;
             default:
+                if (o.a > kShapeNorm / 2) break;
                 for (int j = lane; j < o.a; j += kWave) norm[j] = .5f * (norm[j] + norm2[j]);
                 NYQ_WAVE_SYNC();
                 break;
             }
         }
-        // denormalise_bands: every band times its gain, zeros below `start` and above `end`
-        for (int c = 0; c < C; c++) {
-            float *fo = out + c * kSymN;
-            const float *x = X + c * kSymN;
-            const int lo = shape_edge(H.start), hi = shape_edge(H.end);
-            for (int j = lane; j < lo; j += kWave) fo[j] = 0.f;
+        // anti-collapse (bands.c:258-351): short blocks of a transient frame that received nothing get noise at the level the
+        // host computed from the energies, then the band is renormalised; the generator goes on from where the fills left it
+        if (H.flags & 2) {
+            const float *level = reinterpret_cast<const float *>(r + kSymBodyOff + (size_t)nleaves * sizeof(SymLeaf));
+            const float laneLevel = lane < 2 * 21 ? level[lane] : 0.f;
             for (int i = H.start; i < H.end; i++) {
-                const float g = __shfl(laneGain, c * 21 + i);
-                const int e0 = shape_edge(i), e1 = shape_edge(i + 1);
-                for (int j = e0 + lane; j < e1; j += kWave) fo[j] = x[j] * g;
+                const int e0 = shape_edge(i), n0 = (shape_edge(i + 1) - e0) >> 3;
+                for (int c = 0; c < C; c++) {
+                    const unsigned m = L.masks[c * 21 + i];
+                    if ((m & 0xFFu) == 0xFFu) continue;
+                    const float rl = __shfl(laneLevel, c * 21 + i);
+                    float *x = X + c * kSymN + e0;
+                    for (int k = 0; k < 8; k++) {
+                        if (m >> k & 1) continue;
+                        for (int j = lane; j < n0; j += kWave) x[(j << 3) + k] = (lcg_jump(seed, j + 1) & 0x8000u) ? rl : -rl;
+                        seed = lcg_jump(seed, n0);
+                    }
+                    NYQ_WAVE_SYNC();
+                    float e = 0.f;
+                    for (int j = lane; j < 8 * n0; j += kWave) e += x[j] * x[j];
+                    const float g = 1.f / sqrtf(wave_sum(e) + 1e-15f);
+                    for (int j = lane; j < 8 * n0; j += kWave) x[j] = g * x[j];
+                    NYQ_WAVE_SYNC();
+                }
             }
+        }
+        // denormalise_bands: every band times its gain, zeros below `start` and above `end`; a packet that codes one channel
+        // of a stereo stream is played on both, one that codes two for a mono stream is mixed down
+        const int lo = shape_edge(H.start), hi = shape_edge(H.end);
+        for (int c = 0; c < CC; c++) {
+            float *fo = out + c * kSymN;
+            for (int j = lane; j < lo; j += kWave) fo[j] = 0.f;
             for (int j = hi + lane; j < kSymN; j += kWave) fo[j] = 0.f;
+        }
+        for (int i = H.start; i < H.end; i++) {
+            const int e0 = shape_edge(i), e1 = shape_edge(i + 1);
+            const float g0 = __shfl(laneGain, i), g1 = __shfl(laneGain, 21 + i);
+            for (int j = e0 + lane; j < e1; j += kWave) {
+                const float a = X[j] * g0;
+                if (C == CC) {
+                    out[j] = a;
+                    if (C == 2) out[kSymN + j] = X[kSymN + j] * g1;
+                } else if (C == 1) {
+                    out[j] = a;
+                    out[kSymN + j] = a;
+                } else {
+                    out[j] = .5f * (a + X[kSymN + j] * g1);
+                }
+            }
         }
     }
 }

@@ -1202,7 +1202,9 @@ int CeltDecoder::decodeFrame(const uint8_t *data, int len, int frameSize, float 
     shaper.plan(start, end, C == 2, plan, transient ? M : 0, tfRes, len * (8 << kBitRes) - antiCollapseRsv);   // phase 1: symbols
     const int antiCollapseOn = antiCollapseRsv > 0 ? (int)dec.bits(1) : 0;
     // phase 2 (floats) here, or -- symbol records -- on the GPU, unless the frame needs what the record does not carry
-    const bool asSymbols = record && !silence && !antiCollapseOn && C == CC && LM == 3 && scratch_.nleaves <= 96 * C;
+    // (room in the body: the leaves, and the anti-collapse levels behind them)
+    const bool asSymbols = record && !silence && LM == 3 &&
+                           (size_t)scratch_.nleaves * sizeof(nyq_sym_leaf) + 2 * kBands * sizeof(float) <= (size_t)CC * N * sizeof(float);
     if (!asSymbols) {
         shaper.resolve(masks);                                            // phase 1b: pulse vectors, collapse masks, fill decisions
         shaper.build(X, start, &rng_);                                    // phase 2: floats
@@ -1222,10 +1224,10 @@ int CeltDecoder::decodeFrame(const uint8_t *data, int len, int frameSize, float 
     }
     // ---- anti-collapse: short blocks that received nothing get noise at the level of the quieter of the two previous
     // frames (bands.c:258-351) ----
-    if (antiCollapseOn) {
-        uint32_t seed = rng_;
+    // the level of that noise per (channel, band): from the energies alone -- the GPU fills the blocks (it has the masks)
+    float collapseLevel[2 * kBands];
+    if (antiCollapseOn)
         for (int i = start; i < end; i++) {
-            const int n0 = K.width[i];
             const int depth = (1 + plan.shape[i]) / K.bins[i];
             const float thresh = .5f * exp2Ref(-.125f * depth);
             const float sqrt1 = 1.f / std::sqrt((float)K.bins[i]);
@@ -1238,7 +1240,15 @@ int CeltDecoder::decodeFrame(const uint8_t *data, int len, int frameSize, float 
                 const float ediff = std::max(0.f, E[c * kBands + i] - std::min(p1, p2));
                 float r = 2.f * exp2Ref(-ediff);
                 if (LM == 3) r *= 1.41421356f;
-                r = std::min(thresh, r) * sqrt1;
+                collapseLevel[c * kBands + i] = std::min(thresh, r) * sqrt1;
+            }
+        }
+    if (antiCollapseOn && !asSymbols) {
+        uint32_t seed = rng_;
+        for (int i = start; i < end; i++) {
+            const int n0 = K.width[i];
+            for (int c = 0; c < C; c++) {
+                const float r = collapseLevel[c * kBands + i];
                 float *x = X + c * N + K.first[i];
                 bool touched = false;
                 for (int k = 0; k < M; k++) {
@@ -1277,6 +1287,10 @@ int CeltDecoder::decodeFrame(const uint8_t *data, int len, int frameSize, float 
         std::memcpy(record + kSymOpsOff, scratch_.ops, sizeof(nyq_sym_op) * (size_t)scratch_.nops);
         std::memcpy(record + kSymVecsOff, scratch_.vecs, sizeof(nyq_sym_vec) * (size_t)scratch_.nvecs);
         std::memcpy(record + kSymBodyOff, scratch_.leaves, sizeof(nyq_sym_leaf) * (size_t)scratch_.nleaves);
+        if (antiCollapseOn) {
+            H->flags |= NYQ_SYM_ANTI_COLLAPSE;
+            std::memcpy(record + kSymBodyOff + sizeof(nyq_sym_leaf) * (size_t)scratch_.nleaves, collapseLevel, sizeof collapseLevel);
+        }
     } else {
         if (record) {
             nyq_sym_head *H = reinterpret_cast<nyq_sym_head *>(record);
@@ -1293,7 +1307,7 @@ int CeltDecoder::decodeFrame(const uint8_t *data, int len, int frameSize, float 
             std::memset(f + K.first[effEnd], 0, sizeof(float) * (size_t)(N - K.first[effEnd]));
         }
     }
-    if (!silence || !record) {
+    if (!asSymbols && (!silence || !record)) {                           // (a symbol record leaves this to the device)
         if (CC == 2 && C == 1) std::memcpy(freq + N, freq, sizeof(float) * N);
         if (CC == 1 && C == 2)
             for (int i = 0; i < N; i++) freqOut[i] = .5f * (freq[i] + freq[N + i]);

@@ -98,3 +98,36 @@ def test_symbols_to_pcm_equals_the_freq_path(host, ctx):
     want = ctx.celt_frames_to_pcm(3, freq[None, :nf], tr[None], pp[None], gain[None, :nf], pt[None], 2)
     got = ctx.celt_symbols_to_pcm(sym[:nf], tr.astype(np.uint8), pp.astype(np.int32), gain[:nf], pt.astype(np.int32), 1, nf, 2)
     assert np.abs(got - want).max() <= 1e-6                   # samples are in [-1, 1)
+
+
+@pytest.mark.timeout(90)
+def test_damaged_records_leave_the_kernel_bounded(host, ctx):
+    """Records come from this project's own entropy stage, but the C ABI takes them from any caller: with bytes of the
+    operation list, the vector records and the leaves overwritten at random, nyq_celt_shape_dev must still return (every
+    loop of the kernel is bounded by a checked field; what it writes for such a frame is unspecified, the frames beside it
+    are untouched)."""
+    import torch
+    raw = open(os.path.join(GOLDEN, "short.opus"), "rb").read()
+    rc, sym, flags, gain, rng, info = symbols(host, raw, 400, 2)
+    nf = int(info[2])
+    assert rc == 0 and nf == 220
+    good = sym[:nf].copy()
+    bad = good.copy()
+    r = np.random.default_rng(5)
+    for f in range(0, nf, 2):                                  # every other frame damaged, the others as decoded
+        for _ in range(40):
+            pos = int(r.integers(32, bad.shape[1]))
+            bad[f, pos] = r.integers(0, 256)
+        if f % 8 == 0:
+            bad[f, 200:3072] = r.integers(0, 256, 2872, dtype=np.uint8)          # operations and vectors: noise
+        if f % 8 == 4:
+            bad[f, 3072:3072 + 4000] = r.integers(0, 256, 4000, dtype=np.uint8)  # leaves: noise
+    dev = torch.device("cuda", 0)
+    d_good, d_bad = torch.from_numpy(good).to(dev), torch.from_numpy(bad).to(dev)
+    want = torch.zeros((nf, 2, 960), device=dev)
+    got = torch.zeros((nf, 2, 960), device=dev)
+    torch.cuda.synchronize(dev)
+    ctx.celt_shape_dev(d_good.data_ptr(), want.data_ptr(), 1, nf, 2)
+    ctx.celt_shape_dev(d_bad.data_ptr(), got.data_ptr(), 1, nf, 2)
+    ctx.synchronize()
+    assert torch.equal(got[1::2], want[1::2])
