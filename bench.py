@@ -110,6 +110,49 @@ def cpu_share():
     return n
 
 
+def band_shapes_leg(ctx, dev, rep=8):
+    """The entropy stage's two halves on real packets (tests/golden/sb-reverie.opus, 11184 stereo 20 ms frames): the host half
+    that reads every bit of a frame and stops at the symbol record (one thread, frames/s), and the device half that builds
+    freq[] from the records (celt_shape_kernel, `rep` copies of the stream in one launch)."""
+    import torch
+    H = ctypes.CDLL(os.path.join(ROOT, "libnyquist_amd", "libnyquist_host.so"))
+    H.nyqh_symbol_bytes.argtypes = [ctypes.c_int]
+    H.nyqh_symbol_bytes.restype = ctypes.c_long
+    u8 = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+    i32 = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+    f32 = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+    u32 = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+    i64 = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+    H.nyqh_decode_to_symbols.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_long, u8, i32, f32, u32, i64]
+    raw = open(os.path.join(ROOT, "tests", "golden", "sb-reverie.opus"), "rb").read()
+    cap, rec = 11200, int(H.nyqh_symbol_bytes(2))
+    sym = np.zeros((cap, rec), np.uint8)
+    flags, gain, rng, info = np.zeros((cap, 4), np.int32), np.zeros(cap, np.float32), np.zeros(cap, np.uint32), np.zeros(8, np.int64)
+    best_host = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        if H.nyqh_decode_to_symbols(raw, len(raw), cap, sym, flags, gain, rng, info) != 0:
+            raise RuntimeError("nyqh_decode_to_symbols failed")
+        best_host = min(best_host, time.perf_counter() - t0)
+    nf = int(info[2])
+    d_sym = torch.from_numpy(sym[:nf]).to(dev).repeat(rep, 1).contiguous()
+    d_freq = torch.empty((rep * nf, 2, 960), device=dev)
+    torch.cuda.synchronize(dev)
+    best = 1e9
+    for _ in range(6):
+        t0 = time.perf_counter()
+        ctx.celt_shape_dev(d_sym.data_ptr(), d_freq.data_ptr(), rep, nf, 2)
+        ctx.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    n = rep * nf
+    return {"file": "sb-reverie.opus", "frames": nf, "frames_built_on_the_host": int(info[6]), "record_bytes": rec,
+            "host_symbol_stage_frames_per_sec_per_thread": nf / best_host, "host_symbol_stage_includes": "Ogg + packet parsing, one thread",
+            "device_frames_per_launch": n, "device_ms_per_launch": best * 1e3, "device_frames_per_sec": n / best,
+            "device_GBps_records_in_plus_freq_out": n * (rec + 7680) / best / 1e9,
+            "note": "latency-bound integer / LDS work (DESIGN 4.10), not a roofline kernel: what matters is device_frames_per_sec against "
+                    "host threads x host_symbol_stage_frames_per_sec_per_thread"}
+
+
 def opus_file_decode_leg(count=256, fname="short.opus", n=421930, threads=None, device=0, channels=2):
     """File-level decode of `count` copies of tests/golden/<fname> (short.opus: 220 stereo 20 ms CELT frames + one
     closing 2.5 ms frame, 123 kbit/s; sb-reverie.opus: 11184 frames = 224 s, BASELINE config 4's file) as ONE
@@ -528,6 +571,10 @@ def main():
                 # BASELINE config 5's shape: 7.1 surround (8 channels in 5 elementary streams, 3 coupled; the corpus file made
                 # with the reference's surround encoder stands in for Rachel8ch.opus, which the reference mount lacks): channel
                 # mapping, trim and gain happen in the kernels' store phase, one download per file (row f3)
+                try:
+                    file_leg["band_shapes_on_device"] = band_shapes_leg(ctx, dev)
+                except Exception as e:  # noqa: BLE001
+                    file_leg["band_shapes_on_device"] = {"error": str(e)}
                 file_leg["surround_7_1"] = opus_file_decode_leg(128, os.path.join("corpus", "surround71_20ms_320k.opus"), 384000, threads=thr,
                                                                 device=local_rank, channels=8)
         except Exception as e:

@@ -225,10 +225,11 @@ int nyq_device_dup_channel(nyq_ctx *ctx, float *d_base, int cstride, int src_slo
  * merging) and denormalise_bands (bands.c:192-256) -- needs no bit of the stream once the SYMBOLS are known.  The host's
  * entropy stage therefore stops at the symbols (the codeword of every pulse vector, the leaves of every band's split tree,
  * a short program of vector operations, the band gains) and nyq_celt_shape_dev builds freq[] from them on the device, one
- * wavefront per frame.  20 ms frames (LM 3), mono or stereo.  One frame = one record of nyq_celt_symbol_bytes(channels):
- *     nyq_sym_head | float gain[42] (2^(energy + mean) per band, channel-major) | nyq_sym_op ops[113] | nyq_sym_vec vecs[44] |
- *     body: nyq_sym_leaf leaves[nleaves] (+ float level[42] with NYQ_SYM_ANTI_COLLAPSE)  --  or, with NYQ_SYM_HOST_FREQ,
- *           float freq[channels * 960]
+ * wavefront per frame.  20 ms frames (LM 3), mono or stereo.  One frame = one record, at most nyq_celt_symbol_bytes(channels)
+ * bytes (the slot of the fixed-stride forms), laid out compactly:
+ *     nyq_sym_head | float gain[42] (2^(energy + mean) per band, channel-major) | nyq_sym_op ops[nops] | nyq_sym_vec vecs[nvecs] |
+ *     nyq_sym_leaf leaves[nleaves] (+ float level[42] with NYQ_SYM_ANTI_COLLAPSE)
+ *     --  or, with NYQ_SYM_HOST_FREQ:  nyq_sym_head | float freq[channels * 960]
  * A record of zeros is a silent frame.  Offsets inside a frame are in floats of X (channel c at c * 960).  head.channels is
  * what the PACKET codes (the TOC's stereo flag); where it differs from the stream's `channels` the device duplicates the one
  * coded channel or mixes the two down, as celt_decoder_clean.c:648-652 does. */
@@ -341,6 +342,16 @@ int nyq_celt_symbols_to_pcm_mapped(nyq_ctx *ctx, const void *sym, const unsigned
                                    const int *pf_pitch, const float *pf_gain, const int *pf_tapset,
                                    float *out, const nyq_out_desc *desc, float *state, size_t nstreams, size_t nframes,
                                    int channels, size_t frames_per_stream);
+
+/* The same with the records PACKED back to back (a record is as long as its content: head, gains, nops operations, nvecs
+ * vectors, nleaves leaves [, levels] rounded up to 16 bytes -- about half a slot on music): stream s's records start at
+ * (char *)sym + s * stream_bytes, frame f of the call at 16 * offsets[s * (frames_per_stream + 1) + f] bytes from there and ends where
+ * frame f + 1 begins (so `offsets` has one entry more per stream than frames; for a time slice pass the pointer to the slice's
+ * first entry, `sym` unchanged).  offsets == NULL: slots, as above. */
+int nyq_celt_symbols_packed_to_pcm_mapped(nyq_ctx *ctx, const void *sym, const unsigned int *offsets, size_t stream_bytes,
+                                          const unsigned char *transient, const int *pf_pitch, const float *pf_gain,
+                                          const int *pf_tapset, float *out, const nyq_out_desc *desc, float *state,
+                                          size_t nstreams, size_t nframes, int channels, size_t frames_per_stream);
 
 /* ---- the reference's operator boundary, kept verbatim ------------------- */
 /* cuda/mdct_cuda.hpp:89-91 (impl mdct_cuda.cu:314-392).  Host pointers, caller-owned.

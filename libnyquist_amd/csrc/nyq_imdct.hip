@@ -830,8 +830,10 @@ static_assert(sizeof(nyq_sym_head) == sizeof(SymHead) && sizeof(nyq_sym_leaf) ==
 extern "C" size_t nyq_celt_symbol_bytes(int channels) { return channels == 1 || channels == 2 ? sym_bytes(channels) : 0; }
 
 // sstride / fstride: frames per stream in d_sym / d_freq (0 = nframes: dense)
+// d_off: records packed back to back inside each stream's region of sstride slots, d_off[stream * ostride + frame] = byte offset
+// of the frame's record from the region's start; null: one record per slot of nyq_celt_symbol_bytes
 static int shape_core(nyq_ctx *ctx, const void *d_sym, float *d_freq, size_t nstreams, size_t nframes, int channels, size_t sstride,
-                      size_t fstride = 0) {
+                      size_t fstride = 0, const unsigned *d_off = nullptr, size_t ostride = 0) {
     if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_celt_shape_dev: ctx is NULL");
     if (channels != 1 && channels != 2) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_shape_dev: symbol records carry mono and stereo streams");
     if (nstreams == 0 || nframes == 0) return NYQ_OK;
@@ -853,7 +855,7 @@ static int shape_core(nyq_ctx *ctx, const void *d_sym, float *d_freq, size_t nst
     const size_t want = (total + kShapeWaves - 1) / kShapeWaves, resident = (size_t)ctx->cus;
     const unsigned grid = (unsigned)(want < resident ? want : resident);
     hipLaunchKernelGGL(celt_shape_kernel, dim3(grid), dim3(kWave * kShapeWaves), 0, ctx->stream, static_cast<const unsigned char *>(d_sym), d_freq,
-                       ctx->d_pvq, (long)nstreams, (long)nframes, channels, (long)sstride, (long)fstride);
+                       ctx->d_pvq, (long)nstreams, (long)nframes, channels, (long)sstride, (long)fstride, d_off, (long)(ostride ? ostride : nframes));
     NYQ_HIP(ctx, hipGetLastError());
     return NYQ_OK;
 }
@@ -1174,12 +1176,29 @@ static hipError_t copy_rows(void *dst, size_t dpitch, const void *src, size_t sp
 
 // desc: per-stream destinations (HOST array of nstreams records whose `base` are DEVICE pointers) or null.  A stream with a
 // destination is written there by the kernels and is not downloaded; when EVERY stream has one, `out` may be null.
+// Packed symbol records, host -> device: the bytes of frames [f0, f0 + len) of every stream are one contiguous range per
+// stream, at a different place in each.  One launch moves them all (a workgroup row per stream reads the page-locked host
+// memory over PCIe): per-stream hipMemcpyAsync calls -- 16 small copies per time window -- ran one after the other at 18 GB/s
+// and kept the windows of a call from overlapping (profiles/r04_ae_*).
+__global__ __launch_bounds__(256) void gather_records_kernel(unsigned char *__restrict__ dst, size_t dst_stream_bytes,
+                                                             const unsigned char *__restrict__ src, size_t src_stream_bytes,
+                                                             const unsigned *__restrict__ rel16, const unsigned *__restrict__ first16,
+                                                             long ostride, long f0, long len) {
+    const long k = blockIdx.y;
+    const size_t lo = (size_t)rel16[k * ostride + f0] * 16, hi = (size_t)rel16[k * ostride + f0 + len] * 16;
+    const uint4 *s = reinterpret_cast<const uint4 *>(src + (size_t)k * src_stream_bytes + (size_t)first16[k] * 16 + lo);
+    uint4 *d = reinterpret_cast<uint4 *>(dst + (size_t)k * dst_stream_bytes + lo);
+    const size_t n = (hi - lo) / 16;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
+}
+
 // sym: the host input is symbol records (nyq_celt_symbol_bytes(channels) per frame) in place of freq[]: uploaded to their own
 // scratch region, turned into freq[] by the shape kernel on the context stream, then the same chain.
 static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const unsigned char *transient,
                               const int *pf_pitch, const float *pf_gain, const int *pf_tapset, float *out,
                               float *state, size_t nstreams, size_t nframes, int channels, size_t hstride,
-                              const nyq_out_desc *desc = nullptr, const unsigned char *sym = nullptr) {
+                              const nyq_out_desc *desc = nullptr, const unsigned char *sym = nullptr, const unsigned *offsets = nullptr,
+                              size_t sym_stream_bytes = 0) {
     if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm: ctx is NULL");
     if (LM < 0 || LM > 3) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm: LM must be 0..3");
     if (channels < 1 || channels > 255) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm: channels must be 1..255");
@@ -1201,7 +1220,8 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
     const size_t n_ds = desc ? round16f(nstreams * sizeof(nyq_out_desc) / sizeof(float)) : 0;
     const size_t n_sy = sym ? round16f(nfr * rec / sizeof(float)) : 0;
     const size_t n_dw = desc ? kHostMaxWindows * n_ds : 0;           // (the time-window form: a set of records per window)
-    int rc = need_scratch(ctx, (3 * n_x + n_w + 3 * n_p + n_t + n_ov + n_hi + n_de + 2 * n_pf + n_ds + n_sy + n_dw) * sizeof(float));
+    const size_t n_of = offsets ? round16f(nfr + 2 * nstreams) : 0;  // packed records: nframes + 1 device offsets per stream, its first
+    int rc = need_scratch(ctx, (3 * n_x + n_w + 3 * n_p + n_t + n_ov + n_hi + n_de + 2 * n_pf + n_ds + n_sy + n_dw + n_of) * sizeof(float));
     if (rc != NYQ_OK) return rc;
     float *d_x = ctx->d_scratch, *d_pcm = d_x + n_x, *d_out = d_pcm + n_x, *d_w = d_out + n_x, *d_pg = d_w + n_w;
     int *d_pp = reinterpret_cast<int *>(d_pg + n_p), *d_pt = d_pp + n_p;
@@ -1210,6 +1230,45 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
           *d_pfi = d_de + n_de, *d_pfo = d_pfi + n_pf;
     nyq_out_desc *d_ds = desc ? reinterpret_cast<nyq_out_desc *>(d_pfo + n_pf) : nullptr;
     unsigned char *d_sy = sym ? reinterpret_cast<unsigned char *>(d_pfo + n_pf + n_ds) : nullptr;
+    unsigned *d_of = offsets ? reinterpret_cast<unsigned *>(d_pfo + n_pf + n_ds + n_sy + n_dw) : nullptr;
+    // Packed records (offsets[stream][hstride + 1], 16-byte units from the stream's base sym + stream * stream_bytes): on the device a
+    // stream keeps a region of nframes slots and its records sit packed from the region's start; up_sym uploads frames
+    // [f0, f0 + len) of streams [s0, s0 + cnt) -- one copy per stream -- or, for slots, one strided copy
+    std::vector<unsigned> h_off;                                     // [nstreams][nframes + 1] relative, then [nstreams] first
+    const size_t ostr = nframes + 1;
+    unsigned *d_first = d_of ? d_of + nstreams * ostr : nullptr;
+    const unsigned char *sym_dev = nullptr;                          // the host records as the device sees them (page-locked memory)
+    if (offsets) {
+        h_off.resize(nstreams * ostr + nstreams);
+        for (size_t k = 0; k < nstreams; k++) {
+            const unsigned *o = offsets + k * (hstride + 1);
+            for (size_t f = 0; f <= nframes; f++) h_off[k * ostr + f] = o[f] - o[0];
+            h_off[nstreams * ostr + k] = o[0];
+            if ((size_t)(o[nframes] - o[0]) * 16 > nframes * rec) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_symbols_to_pcm_mapped: a stream's records exceed nframes slots");
+        }
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, const_cast<unsigned char *>(sym), 0) == hipSuccess) sym_dev = static_cast<const unsigned char *>(dp);
+        else (void)hipGetLastError();                                // (ordinary memory: per-stream copies below)
+    }
+    auto up_sym = [&](size_t s0, size_t cnt, size_t f0, size_t len, hipStream_t hs) -> hipError_t {
+        if (!offsets)
+            return copy_rows(d_sy + (s0 * nframes + f0) * rec, nframes * rec, sym + (s0 * hstride + f0) * rec, hstride * rec, len * rec, cnt,
+                             hipMemcpyHostToDevice, hs);
+        if (sym_dev) {                                               // (behind the offset tables' upload on the same stream)
+            hipLaunchKernelGGL(gather_records_kernel, dim3(24, (unsigned)cnt), dim3(256), 0, hs, d_sy + s0 * nframes * rec, nframes * rec,
+                               sym_dev + s0 * sym_stream_bytes, sym_stream_bytes, d_of + s0 * ostr, d_first + s0, (long)ostr, (long)f0, (long)len);
+            return hipGetLastError();
+        }
+        for (size_t k = s0; k < s0 + cnt; k++) {
+            const unsigned *o = offsets + k * (hstride + 1);
+            const size_t lo = (size_t)o[f0] * 16, hi = (size_t)o[f0 + len] * 16;
+            if (hi == lo) continue;
+            hipError_t e = hipMemcpyAsync(d_sy + k * nframes * rec + (lo - (size_t)o[0] * 16), sym + k * sym_stream_bytes + lo, hi - lo,
+                                          hipMemcpyHostToDevice, hs);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    };
     float *h_ov = state, *h_hi = state ? h_ov + nsc * NYQ_HALF_OV : nullptr, *h_de = state ? h_hi + nsc * kPostHist : nullptr,
           *h_pf = state ? h_de + nsc : nullptr;
     // pieces of whole streams: upload of piece k+1, kernels of piece k, download of piece k-1 at the same time
@@ -1262,6 +1321,7 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
                 d_dw = reinterpret_cast<nyq_out_desc *>(d_pfo + n_pf + n_ds + n_sy);
                 NYQ_HIP(ctx, hipMemcpyAsync(d_dw, wdesc.data(), wdesc.size() * sizeof(nyq_out_desc), hipMemcpyHostToDevice, hs));
             }
+            if (offsets) NYQ_HIP(ctx, hipMemcpyAsync(d_of, h_off.data(), h_off.size() * sizeof(unsigned), hipMemcpyHostToDevice, hs));
             if (state) {
                 NYQ_HIP(ctx, hipMemcpyAsync(d_ov, h_ov, nsc * NYQ_HALF_OV * sizeof(float), hipMemcpyHostToDevice, hs));
                 NYQ_HIP(ctx, hipMemcpyAsync(d_hi, h_hi, nsc * kPostHist * sizeof(float), hipMemcpyHostToDevice, hs));
@@ -1277,12 +1337,13 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
             for (size_t w = 0; w < nwin; w++) {
                 const size_t f0 = w * W, len = nframes - f0 < W ? nframes - f0 : W;
                 hipEvent_t up = ctx->ev_pool[2 * w], done = ctx->ev_pool[2 * w + 1];
-                if (sym) NYQ_HIP(ctx, copy_rows(d_sy + f0 * rec, nframes * rec, sym + f0 * rec, hstride * rec, len * rec, nstreams, hipMemcpyHostToDevice, hs));
+                if (sym) NYQ_HIP(ctx, up_sym(0, nstreams, f0, len, hs));
                 else NYQ_HIP(ctx, copy_rows(d_x + f0 * channels * N, nframes * channels * N * sizeof(float), freq + f0 * channels * N,
                                             hstride * channels * N * sizeof(float), len * channels * N * sizeof(float), nstreams, hipMemcpyHostToDevice, hs));
                 NYQ_HIP(ctx, hipEventRecord(up, hs));
                 NYQ_HIP(ctx, hipStreamWaitEvent(ctx->stream, up, 0));
-                if (sym) rc = shape_core(ctx, d_sy + f0 * rec, d_x + f0 * channels * N, nstreams, len, channels, nframes, nframes);
+                if (sym) rc = shape_core(ctx, offsets ? d_sy : d_sy + f0 * rec, d_x + f0 * channels * N, nstreams, len, channels, nframes, nframes,
+                                         offsets ? d_of + f0 : nullptr, ostr);
                 if (rc == NYQ_OK)
                     rc = chain_core(ctx, LM, d_x + f0 * channels * N, transient ? d_t + f0 : nullptr, d_pp + f0, d_pg + f0, d_pt + f0, pf_a, pf_b, d_ov,
                                     d_hi, d_de, d_out + f0 * N * channels, d_pcm, d_w, nstreams, len, channels, nframes,
@@ -1327,8 +1388,12 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
         const size_t xw = nframes * channels * N * sizeof(float), xp = hstride * channels * N * sizeof(float);
         (void)xn;
         (void)fn;
-        if (sym) NYQ_HIP(ctx, copy_rows(d_sy + fo * rec, nframes * rec, sym + hf * rec, hstride * rec, nframes * rec, cnt, hipMemcpyHostToDevice, hs));
-        else NYQ_HIP(ctx, copy_rows(d_x + xo, xw, freq + hx, xp, xw, cnt, hipMemcpyHostToDevice, hs));
+        if (sym) {
+            if (offsets && k == 0) NYQ_HIP(ctx, hipMemcpyAsync(d_of, h_off.data(), h_off.size() * sizeof(unsigned), hipMemcpyHostToDevice, hs));
+            NYQ_HIP(ctx, up_sym(s0, cnt, 0, nframes, hs));
+        } else {
+            NYQ_HIP(ctx, copy_rows(d_x + xo, xw, freq + hx, xp, xw, cnt, hipMemcpyHostToDevice, hs));
+        }
         if (transient) NYQ_HIP(ctx, copy_rows(d_t + fo, nframes, transient + hf, hstride, nframes, cnt, hipMemcpyHostToDevice, hs));
         NYQ_HIP(ctx, copy_rows(d_pg + fo, nframes * 4, pf_gain + hf, hstride * 4, nframes * 4, cnt, hipMemcpyHostToDevice, hs));
         NYQ_HIP(ctx, copy_rows(d_pp + fo, nframes * 4, pf_pitch + hf, hstride * 4, nframes * 4, cnt, hipMemcpyHostToDevice, hs));
@@ -1342,7 +1407,7 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
         }
         NYQ_HIP(ctx, hipEventRecord(up, hs));
         NYQ_HIP(ctx, hipStreamWaitEvent(ctx->stream, up, 0));
-        if (sym && (rc = shape_core(ctx, d_sy + fo * rec, d_x + xo, cnt, nframes, channels, nframes)) != NYQ_OK) {
+        if (sym && (rc = shape_core(ctx, d_sy + fo * rec, d_x + xo, cnt, nframes, channels, nframes, 0, offsets ? d_of + s0 * ostr : nullptr, ostr)) != NYQ_OK) {
             (void)hipStreamSynchronize(hs);
             (void)hipStreamSynchronize(ctx->stream);
             (void)hipStreamSynchronize(ds);
@@ -1394,11 +1459,19 @@ extern "C" int nyq_celt_frames_to_pcm_mapped(nyq_ctx *ctx, int LM, const float *
 extern "C" int nyq_celt_symbols_to_pcm_mapped(nyq_ctx *ctx, const void *sym, const unsigned char *transient, const int *pf_pitch,
                                               const float *pf_gain, const int *pf_tapset, float *out, const nyq_out_desc *desc,
                                               float *state, size_t nstreams, size_t nframes, int channels, size_t frames_per_stream) {
+    return nyq_celt_symbols_packed_to_pcm_mapped(ctx, sym, nullptr, 0, transient, pf_pitch, pf_gain, pf_tapset, out, desc, state, nstreams,
+                                                 nframes, channels, frames_per_stream);
+}
+
+extern "C" int nyq_celt_symbols_packed_to_pcm_mapped(nyq_ctx *ctx, const void *sym, const unsigned *offsets, size_t stream_bytes,
+                                                     const unsigned char *transient, const int *pf_pitch, const float *pf_gain,
+                                                     const int *pf_tapset, float *out, const nyq_out_desc *desc, float *state,
+                                                     size_t nstreams, size_t nframes, int channels, size_t frames_per_stream) {
     if (ctx && frames_per_stream < nframes)
         return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_symbols_to_pcm_mapped: frames_per_stream is smaller than nframes");
     if (ctx && !sym) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_symbols_to_pcm_mapped: NULL buffer");
     return frames_to_pcm_core(ctx, 3, nullptr, transient, pf_pitch, pf_gain, pf_tapset, out, state, nstreams, nframes, channels,
-                              frames_per_stream, desc, static_cast<const unsigned char *>(sym));
+                              frames_per_stream, desc, static_cast<const unsigned char *>(sym), offsets, stream_bytes);
 }
 
 extern "C" int nyq_celt_frames_to_pcm_window(nyq_ctx *ctx, int LM, const float *freq, const unsigned char *transient,

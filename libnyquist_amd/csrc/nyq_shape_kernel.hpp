@@ -54,11 +54,14 @@ struct SymOp {
 };
 constexpr int kSymMaxOps = 113, kSymMaxVecs = 44;
 constexpr int kSymN = 960;                                           // bins per channel (LM 3)
-constexpr int kSymFixed = 32 + 42 * 4 + kSymMaxOps * 16 + kSymMaxVecs * 24;   // 3064
-constexpr int kSymBodyOff = (kSymFixed + 15) & ~15;                  // 3072
+// a record is COMPACT: head | gain[42] | ops[nops] | vecs[nvecs] | leaves[nleaves] | (anti-collapse) level[42], or head | freq[];
+// the slot of the fixed-stride form (sym_bytes) holds the largest record the entropy stage writes
+constexpr int kSymOpsOff = 32 + 42 * 4;                              // 200
+constexpr int kSymFreqOff = 32;
+constexpr int kSymSlotFixed = 3072;
 constexpr int kSymMaxLeaves = 192;                                   // 96 per channel: what the body holds
 constexpr int kPvqDim = 178;                                         // U(n, k) for n, k < 178 (the widest band has 176 bins)
-__host__ __device__ inline size_t sym_bytes(int channels) { return (size_t)kSymBodyOff + (size_t)channels * kSymN * 4; }
+__host__ __device__ inline size_t sym_bytes(int channels) { return (size_t)kSymSlotFixed + (size_t)channels * kSymN * 4; }
 
 constexpr int kShapeNorm = 2 * 800;                                  // fold memory: two channels x bins below the last band
 constexpr int kShapeLdsFloats = 2 * kSymN + kShapeNorm + 192 + 192;
@@ -452,7 +455,8 @@ __device__ __forceinline__ void stage_words(void *dst, const void *src, int byte
 
 __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const unsigned char *__restrict__ sym, float *__restrict__ freq,
                                                                         const unsigned *__restrict__ pvq, long nstreams, long nframes,
-                                                                        int channels, long sstride, long fstride) {
+                                                                        int channels, long sstride, long fstride,
+                                                                        const unsigned *__restrict__ offsets, long ostride) {
 #pragma clang fp contract(off)
     __shared__ __attribute__((aligned(16))) ShapeWaveLds wl[kShapeWaves];
     __shared__ unsigned tab[kPvqInfo + kPvqWords];
@@ -465,12 +469,14 @@ __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const un
     const long total = nstreams * nframes;
     for (long u = (long)blockIdx.x * kShapeWaves + wv; u < total; u += (long)gridDim.x * kShapeWaves) {
         const long s = u / nframes, f = u - s * nframes;
-        const unsigned char *r = sym + ((size_t)s * (size_t)sstride + (size_t)f) * rec;
+        // where the frame's record is: packed back to back inside its stream's region (offsets[stream * ostride + frame], 16-byte
+        // units from the region's start) or in slots of sym_bytes; a stream's region is sstride slots long either way
+        const unsigned char *r = sym + (size_t)s * (size_t)sstride * rec + (offsets ? (size_t)offsets[s * ostride + f] * 16 : (size_t)f * rec);
         float *out = freq + ((size_t)s * (size_t)fstride + (size_t)f) * (size_t)channels * kSymN;
         const SymHead H = *reinterpret_cast<const SymHead *>(r);
         const int CC = channels;                                     // the stream's channels: the layout of freq[]
         if (H.flags & 1) {                                           // the host built this frame itself: its freq[] is the body
-            const float4 *b4 = reinterpret_cast<const float4 *>(r + kSymBodyOff);
+            const float4 *b4 = reinterpret_cast<const float4 *>(r + kSymFreqOff);
             float4 *o4 = reinterpret_cast<float4 *>(out);
             for (int j = lane; j < CC * kSymN / 4; j += kWave) o4[j] = b4[j];
             continue;
@@ -481,7 +487,8 @@ __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const un
             continue;
         }
         const int C = H.channels == 2 ? 2 : 1;                       // what the packet codes
-        if (H.start > 20 || H.end > 21 || H.start > H.end) {         // (a damaged head: a silent frame)
+        if (H.start > 20 || H.end > 21 || H.start > H.end || H.nops > kSymMaxOps || H.nvecs > kSymMaxVecs || H.nleaves > kSymMaxLeaves) {
+            // (a damaged head -- its counts would place the record's parts outside the record: a silent frame)
             float4 *o4 = reinterpret_cast<float4 *>(out);
             for (int j = lane; j < CC * kSymN / 4; j += kWave) o4[j] = float4{0.f, 0.f, 0.f, 0.f};
             continue;
@@ -490,9 +497,11 @@ __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const un
         const int nops = H.nops < kSymMaxOps ? H.nops : kSymMaxOps, nvecs = H.nvecs < kSymMaxVecs ? H.nvecs : kSymMaxVecs;
         const float laneGain = lane < 2 * 21 ? reinterpret_cast<const float *>(r + 32)[lane] : 0.f;   // lane c * 21 + band
         NYQ_WAVE_SYNC();                                             // (the previous frame's last reads of this slice)
-        stage_words(L.ops, r + 32 + 42 * 4, nops * (int)sizeof(SymOp), lane);
-        stage_words(L.vecs, r + 32 + 42 * 4 + kSymMaxOps * (int)sizeof(SymOp), nvecs * (int)sizeof(SymVec), lane);
-        stage_words(L.leaves, r + kSymBodyOff, nleaves * (int)sizeof(SymLeaf), lane);
+        // (the record's own counts place its parts; the clamped ones bound what is staged)
+        const unsigned char *rvecs = r + kSymOpsOff + (size_t)H.nops * sizeof(SymOp), *rleaves = rvecs + (size_t)H.nvecs * sizeof(SymVec);
+        stage_words(L.ops, r + kSymOpsOff, nops * (int)sizeof(SymOp), lane);
+        stage_words(L.vecs, rvecs, nvecs * (int)sizeof(SymVec), lane);
+        stage_words(L.leaves, rleaves, nleaves * (int)sizeof(SymLeaf), lane);
         if (lane < 2 * 21) L.masks[lane] = 0;
         NYQ_WAVE_SYNC();
         ShapeFrame F;
@@ -586,7 +595,7 @@ __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const un
         // anti-collapse (bands.c:258-351): short blocks of a transient frame that received nothing get noise at the level the
         // host computed from the energies, then the band is renormalised; the generator goes on from where the fills left it
         if (H.flags & 2) {
-            const float *level = reinterpret_cast<const float *>(r + kSymBodyOff + (size_t)nleaves * sizeof(SymLeaf));
+            const float *level = reinterpret_cast<const float *>(rleaves + (size_t)H.nleaves * sizeof(SymLeaf));
             const float laneLevel = lane < 2 * 21 ? level[lane] : 0.f;
             for (int i = H.start; i < H.end; i++) {
                 const int e0 = shape_edge(i), n0 = (shape_edge(i + 1) - e0) >> 3;

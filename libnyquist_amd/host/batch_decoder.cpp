@@ -64,6 +64,8 @@ struct StreamFrames {
     uint8_t *in0 = nullptr;
     size_t frameBytes = 0;
     bool symbols = false;
+    uint32_t *off0 = nullptr;           // symbols: frame i's record at in0 + 16 * off0[i] (off0[i + 1] = its end)
+    bool packed = true;                 // ... back to back (a record is as long as its content), or one per slot of frameBytes
     uint8_t *tr0 = nullptr;
     int *pp0 = nullptr, *pt0 = nullptr;
     float *pg0 = nullptr;
@@ -156,7 +158,8 @@ void entropyDecode(FileJob &job, OnSlice &&onSlice) {
                 CeltFrame info;
                 int rc;
                 if (!L && s.symbols) {
-                    rc = decs[k].decodeSymbols(fr.first, fr.second, pf.frameSize, s.in0 + (size_t)i * s.frameBytes, info);
+                    rc = decs[k].decodeSymbols(fr.first, fr.second, pf.frameSize, s.in0 + (size_t)s.off0[i] * 16, info);
+                    s.off0[i + 1] = s.off0[i] + (uint32_t)((s.packed ? info.recordBytes : s.frameBytes) / 16);
                 } else {
                     float *dst = L ? L->freq.data() + (size_t)i * s.channels * N : reinterpret_cast<float *>(s.in0 + (size_t)i * s.frameBytes);
                     rc = decs[k].decode(fr.first, fr.second, pf.frameSize, dst, info);
@@ -187,6 +190,7 @@ struct Group {
     size_t frameBytes = 0;              // of GPU input per frame: freq[ch][N] or a symbol record
     std::vector<size_t> ids;            // flattened stream indices, slot order
     uint8_t *in = nullptr;
+    uint32_t *off = nullptr;            // symbols: [ns][maxF + 1] record offsets (16-byte units) inside each stream's maxF * frameBytes region
     float *out = nullptr, *pg = nullptr;
     int *pp = nullptr, *pt = nullptr;
     uint8_t *tr = nullptr;
@@ -324,6 +328,7 @@ public:
     // 20 ms mono / stereo streams hand SYMBOL records to the GPU (their band shapes are built there); off: freq[] as for every other shape
     bool symbolRecords_ = true;
     bool symbolRecords() const { return symbolRecords_; }
+    bool packedRecords_ = false;        // records back to back (half the upload) or one per slot (one strided copy per window)
     bool trace_ = false;
 
     // returns when every file of the sub-batch is decoded (or has its error set); throws if the GPU failed
@@ -452,7 +457,8 @@ private:
         for (Group &g : groups_) {
             g.ns = g.ids.size();
             const size_t x = g.ns * g.maxF * g.ch * g.N * sizeof(float), q = g.ns * g.maxF;
-            bytes[(size_t)g.dev] += align256(q * g.frameBytes) + (g.mapped ? 0 : 1) * align256(x) + 3 * align256(q * 4) + align256(q);   // (mapped: no dense output)
+            bytes[(size_t)g.dev] += align256(q * g.frameBytes) + (g.mapped ? 0 : 1) * align256(x) + 3 * align256(q * 4) + align256(q) +   // (mapped: no dense output)
+                                    (g.symbols ? align256(g.ns * (g.maxF + 1) * 4) : 0);
         }
         std::vector<char *> bases((size_t)ndev_, nullptr);
         for (int d = 0; d < ndev_; d++)
@@ -462,6 +468,8 @@ private:
             char *&base = bases[(size_t)g.dev];
             const size_t x = g.ns * g.maxF * g.ch * g.N * sizeof(float), q = g.ns * g.maxF;
             g.in = (uint8_t *)base; base += align256(q * g.frameBytes);
+            g.off = nullptr;
+            if (g.symbols) { g.off = (uint32_t *)base; base += align256(g.ns * (g.maxF + 1) * 4); }
             g.out = nullptr;
             if (!g.mapped) { g.out = (float *)base; base += align256(x); }
             g.pg = (float *)base; base += align256(q * 4);
@@ -504,6 +512,9 @@ private:
                 s.in0 = g.in + k * g.maxF * g.frameBytes;
                 s.frameBytes = g.frameBytes;
                 s.symbols = g.symbols;
+                s.off0 = g.symbols ? g.off + k * (g.maxF + 1) : nullptr;
+                s.packed = packedRecords_;
+                if (s.off0) s.off0[0] = 0;
                 s.tr0 = g.tr + k * g.maxF;
                 s.pp0 = g.pp + k * g.maxF;
                 s.pt0 = g.pt + k * g.maxF;
@@ -603,7 +614,14 @@ private:
         for (StreamFrames &s : job.subs) {
             const Group &g = groups_[s.group];
             const size_t have = job.error.empty() ? (size_t)s.plan[0].nframes : 0;   // a failed file plays as silence
-            std::memset(s.in0 + have * g.frameBytes, 0, (g.maxF - have) * g.frameBytes);   // (a record of zeros is a silent frame too)
+            if (s.symbols) {                                    // padding: records of a zero head (silent frames), 32 bytes each
+                for (size_t f = have; f < g.maxF; f++) {
+                    std::memset(s.in0 + (size_t)s.off0[f] * 16, 0, 32);
+                    s.off0[f + 1] = s.off0[f] + (uint32_t)(s.packed ? 2 : s.frameBytes / 16);
+                }
+            } else {
+                std::memset(s.in0 + have * g.frameBytes, 0, (g.maxF - have) * g.frameBytes);
+            }
             if (!job.error.empty()) {
                 std::memset(s.tr0, 0, g.maxF);
                 std::memset(s.pp0, 0, g.maxF * 4);
@@ -666,11 +684,14 @@ private:
                 // device buffer: channel slot, pre-skip / end trim and header gain are in the record
                 std::vector<nyq_out_desc> desc(g.mapped ? p.k1 - p.k0 : 0);
                 for (size_t k = p.k0; k < p.k1 && g.mapped; k++) desc[k - p.k0] = recordOf(g.ids[k], (int64_t)(f0 * g.N));
-                const uint8_t *in = g.in + so * g.frameBytes;
+                const uint8_t *in = g.symbols ? g.in + p.k0 * g.maxF * g.frameBytes : g.in + so * g.frameBytes;   // (packed: the streams' bases)
                 float *out = g.mapped ? nullptr : g.out + so * g.ch * g.N, *state = p.state.empty() ? nullptr : p.state.data();
                 if (g.symbols) {
-                    rc = nyq_celt_symbols_to_pcm_mapped(ctx, in, g.tr + so, g.pp + so, g.pg + so, g.pt + so, out, g.mapped ? desc.data() : nullptr,
-                                                        state, p.k1 - p.k0, len, g.ch, g.maxF);
+                    rc = packedRecords_ ? nyq_celt_symbols_packed_to_pcm_mapped(ctx, in, g.off + p.k0 * (g.maxF + 1) + f0, g.maxF * g.frameBytes,
+                                                                                g.tr + so, g.pp + so, g.pg + so, g.pt + so, out,
+                                                                                g.mapped ? desc.data() : nullptr, state, p.k1 - p.k0, len, g.ch, g.maxF)
+                                        : nyq_celt_symbols_to_pcm_mapped(ctx, g.in + so * g.frameBytes, g.tr + so, g.pp + so, g.pg + so, g.pt + so, out,
+                                                                         g.mapped ? desc.data() : nullptr, state, p.k1 - p.k0, len, g.ch, g.maxF);
                 } else if (g.mapped) {
                     rc = nyq_celt_frames_to_pcm_mapped(ctx, g.LM, reinterpret_cast<const float *>(in), g.tr + so, g.pp + so, g.pg + so, g.pt + so,
                                                        nullptr, desc.data(), state, p.k1 - p.k0, len, g.ch, g.maxF);
@@ -766,8 +787,8 @@ private:
             if ((size_t)s.plan[0].nframes != g.maxF) {
                 std::vector<float> out1((size_t)s.plan[0].nframes * g.N * g.ch);
                 const size_t nf0 = (size_t)s.plan[0].nframes;
-                if ((g.symbols ? nyq_celt_symbols_to_pcm_mapped(ctx, s.in0, s.tr0, s.pp0, s.pg0, s.pt0, out1.data(), nullptr, st1.data(), 1, nf0,
-                                                                g.ch, nf0)
+                if ((g.symbols ? nyq_celt_symbols_packed_to_pcm_mapped(ctx, s.in0, s.off0, 0, s.tr0, s.pp0, s.pg0, s.pt0, out1.data(), nullptr,
+                                                                       st1.data(), 1, nf0, g.ch, g.maxF)
                                : nyq_celt_frames_to_pcm(ctx, g.LM, reinterpret_cast<const float *>(s.in0), s.tr0, s.pp0, s.pg0, s.pt0, out1.data(),
                                                         st1.data(), 1, nf0, g.ch)) != NYQ_OK)
                     throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(ctx));
@@ -944,6 +965,7 @@ BatchOpusDecoder::BatchOpusDecoder(const std::vector<int> &devices) : devices_(d
     }
     if (const char *e = std::getenv("NYQ_HOST_SYMBOLS")) symbolRecords_ = std::atoi(e) != 0;   // (A/B switch, read once like the budget)
     if (const char *e = std::getenv("NYQ_BATCH_TRACE")) trace_ = std::atoi(e) != 0;
+    if (const char *e = std::getenv("NYQ_HOST_PACKED")) packedRecords_ = std::atoi(e) != 0;
     const int ndev = nyq_device_count();
     for (int d : devices_)
         if (d < 0 || d >= ndev)
@@ -1107,6 +1129,7 @@ void BatchOpusDecoder::decodeImpl(const std::vector<const std::vector<uint8_t> *
                 }
         SubBatch sb(jobs, out, members, ctx_.data(), (int)devices_.size(), kFeeders, threads, arenaFn, devArenaFn);
         sb.symbolRecords_ = symbolRecords_;
+        sb.packedRecords_ = packedRecords_;
         sb.trace_ = trace_;
         sb.run();
         cpuSecs += sb.cpuSeconds;

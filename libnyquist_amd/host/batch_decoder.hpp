@@ -89,6 +89,7 @@ private:
     std::vector<int> devices_;
     size_t stagingBudget_ = (size_t)6 << 30;
     bool symbolRecords_ = true;
+    bool packedRecords_ = false;              // NYQ_HOST_PACKED=1 at construction: symbol records packed back to back
     bool trace_ = false;                      // NYQ_BATCH_TRACE=1 at construction: per-sub-batch timing on stderr
     std::vector<void *> ctx_;                 // nyq_ctx*, device d's feeders at [d * kFeeders, (d + 1) * kFeeders)
     std::vector<Arena> arenas_;

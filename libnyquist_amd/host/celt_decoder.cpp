@@ -1038,11 +1038,13 @@ int CeltDecoder::decode(const uint8_t *data, int len, int frameSize, float *freq
     return decodeFrame(data, len, frameSize, freqOut, nullptr, info);
 }
 
-// layout of a symbol record (include/nyq_imdct.h): head | gain[42] | ops[113] | vecs[44] | (16-byte aligned) body
+// layout of a symbol record (include/nyq_imdct.h), COMPACT: head | gain[42] | ops[nops] | vecs[nvecs] | leaves[nleaves] |
+// (anti-collapse) level[42], rounded up to 16 bytes -- or head | freq[channels * 960] for a frame built on the host.
+// A record never exceeds symbolBytes(channels) = the slot of the fixed-stride form.
 namespace {
 constexpr size_t kSymGainOff = sizeof(nyq_sym_head), kSymOpsOff = kSymGainOff + 2 * kBands * sizeof(float),
-                 kSymVecsOff = kSymOpsOff + NYQ_SYM_MAX_OPS * sizeof(nyq_sym_op),
-                 kSymBodyOff = (kSymVecsOff + NYQ_SYM_MAX_VECS * sizeof(nyq_sym_vec) + 15) & ~(size_t)15;
+                 kSymFreqOff = sizeof(nyq_sym_head);
+constexpr size_t kSymSlotFixed = 3072;                                    // slot = 3072 + channels * 3840 bytes
 static_assert(sizeof(nyq_sym_head) == 32 && sizeof(nyq_sym_leaf) == 40 && sizeof(nyq_sym_vec) == 24 && sizeof(nyq_sym_op) == 16, "record layout");
 static_assert(sizeof(CeltDecoder::Scratch::LeafSlot) == sizeof(nyq_sym_leaf) && sizeof(CeltDecoder::Scratch::VecSlot) == sizeof(nyq_sym_vec) &&
                   sizeof(CeltDecoder::Scratch::OpSlot) == sizeof(nyq_sym_op),
@@ -1050,12 +1052,12 @@ static_assert(sizeof(CeltDecoder::Scratch::LeafSlot) == sizeof(nyq_sym_leaf) && 
 static_assert(sizeof(CeltDecoder::Scratch::ops) / sizeof(nyq_sym_op) == NYQ_SYM_MAX_OPS && sizeof(CeltDecoder::Scratch::vecs) / sizeof(nyq_sym_vec) == NYQ_SYM_MAX_VECS, "record capacity");
 }  // namespace
 
-size_t CeltDecoder::symbolBytes(int channels) { return kSymBodyOff + (size_t)channels * 960 * sizeof(float); }
+size_t CeltDecoder::symbolBytes(int channels) { return kSymSlotFixed + (size_t)channels * 960 * sizeof(float); }
 
 int CeltDecoder::decodeSymbols(const uint8_t *data, int len, int frameSize, void *record, CeltFrame &info) {
     if (!record || frameSize != 960) return -1;
     uint8_t *r = static_cast<uint8_t *>(record);
-    return decodeFrame(data, len, frameSize, reinterpret_cast<float *>(r + kSymBodyOff), r, info);
+    return decodeFrame(data, len, frameSize, reinterpret_cast<float *>(r + kSymFreqOff), r, info);
 }
 
 int CeltDecoder::decodeFrame(const uint8_t *data, int len, int frameSize, float *freqOut, uint8_t *record, CeltFrame &info) {
@@ -1197,15 +1199,16 @@ int CeltDecoder::decodeFrame(const uint8_t *data, int len, int frameSize, float 
     // ---- band shapes ----
     uint8_t masks[2][kBands];
     float *X = scratch_.X;
-    std::memset(X, 0, sizeof(float) * (size_t)C * N);
     BandShaper shaper{m, K, dec, scratch_, LM, C, N, spread, plan.intensity};
     shaper.plan(start, end, C == 2, plan, transient ? M : 0, tfRes, len * (8 << kBitRes) - antiCollapseRsv);   // phase 1: symbols
     const int antiCollapseOn = antiCollapseRsv > 0 ? (int)dec.bits(1) : 0;
     // phase 2 (floats) here, or -- symbol records -- on the GPU, unless the frame needs what the record does not carry
-    // (room in the body: the leaves, and the anti-collapse levels behind them)
-    const bool asSymbols = record && !silence && LM == 3 &&
-                           (size_t)scratch_.nleaves * sizeof(nyq_sym_leaf) + 2 * kBands * sizeof(float) <= (size_t)CC * N * sizeof(float);
+    // (room in the slot; 192 leaves is what the device stages)
+    const size_t symBytes = kSymOpsOff + sizeof(nyq_sym_op) * (size_t)scratch_.nops + sizeof(nyq_sym_vec) * (size_t)scratch_.nvecs +
+                            sizeof(nyq_sym_leaf) * (size_t)scratch_.nleaves + (antiCollapseOn ? 2 * kBands * sizeof(float) : 0);
+    const bool asSymbols = record && !silence && LM == 3 && scratch_.nleaves <= 192 && symBytes <= symbolBytes(CC);
     if (!asSymbols) {
+        std::memset(X, 0, sizeof(float) * (size_t)C * N);
         shaper.resolve(masks);                                            // phase 1b: pulse vectors, collapse masks, fill decisions
         shaper.build(X, start, &rng_);                                    // phase 2: floats
     }
@@ -1267,8 +1270,12 @@ int CeltDecoder::decodeFrame(const uint8_t *data, int len, int frameSize, float 
     // ---- denormalisation: every band times 2^(energy + mean) (bands.c:192-256), silence, band limits, channel layout ----
     if (silence) {
         for (int i = 0; i < C * kBands; i++) E[i] = -28.f;
-        if (record) std::memset(record, 0, sizeof(nyq_sym_head));         // (a record without operations is a silent frame)
-        else std::memset(freq, 0, sizeof(float) * (size_t)std::max(CC, C) * N);
+        if (record) {
+            std::memset(record, 0, sizeof(nyq_sym_head));                 // (a record without operations is a silent frame)
+            info.recordBytes = sizeof(nyq_sym_head);
+        } else {
+            std::memset(freq, 0, sizeof(float) * (size_t)std::max(CC, C) * N);
+        }
     } else if (asSymbols) {
         nyq_sym_head *H = reinterpret_cast<nyq_sym_head *>(record);
         std::memset(H, 0, sizeof *H);
@@ -1284,13 +1291,19 @@ int CeltDecoder::decodeFrame(const uint8_t *data, int len, int frameSize, float 
         float *gain = reinterpret_cast<float *>(record + kSymGainOff);
         for (int c = 0; c < C; c++)
             for (int i = start; i < effEnd; i++) gain[c * kBands + i] = exp2Ref(E[i + c * kBands] + m.eMeans[i]);
-        std::memcpy(record + kSymOpsOff, scratch_.ops, sizeof(nyq_sym_op) * (size_t)scratch_.nops);
-        std::memcpy(record + kSymVecsOff, scratch_.vecs, sizeof(nyq_sym_vec) * (size_t)scratch_.nvecs);
-        std::memcpy(record + kSymBodyOff, scratch_.leaves, sizeof(nyq_sym_leaf) * (size_t)scratch_.nleaves);
+        uint8_t *w = record + kSymOpsOff;
+        std::memcpy(w, scratch_.ops, sizeof(nyq_sym_op) * (size_t)scratch_.nops);
+        w += sizeof(nyq_sym_op) * (size_t)scratch_.nops;
+        std::memcpy(w, scratch_.vecs, sizeof(nyq_sym_vec) * (size_t)scratch_.nvecs);
+        w += sizeof(nyq_sym_vec) * (size_t)scratch_.nvecs;
+        std::memcpy(w, scratch_.leaves, sizeof(nyq_sym_leaf) * (size_t)scratch_.nleaves);
+        w += sizeof(nyq_sym_leaf) * (size_t)scratch_.nleaves;
         if (antiCollapseOn) {
             H->flags |= NYQ_SYM_ANTI_COLLAPSE;
-            std::memcpy(record + kSymBodyOff + sizeof(nyq_sym_leaf) * (size_t)scratch_.nleaves, collapseLevel, sizeof collapseLevel);
+            std::memcpy(w, collapseLevel, sizeof collapseLevel);
+            w += sizeof collapseLevel;
         }
+        info.recordBytes = ((size_t)(w - record) + 15) & ~(size_t)15;
     } else {
         if (record) {
             nyq_sym_head *H = reinterpret_cast<nyq_sym_head *>(record);
@@ -1298,6 +1311,7 @@ int CeltDecoder::decodeFrame(const uint8_t *data, int len, int frameSize, float 
             H->flags = NYQ_SYM_HOST_FREQ;
             H->channels = (unsigned char)CC;
             H->lm = (unsigned char)LM;
+            info.recordBytes = kSymFreqOff + sizeof(float) * (size_t)CC * N;
         }
         for (int c = 0; c < C; c++) {
             float *f = freq + c * N;

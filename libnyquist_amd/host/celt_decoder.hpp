@@ -23,6 +23,7 @@ struct CeltFrame {
     float pfGain = 0.f;         // postfilter_gain
     int pfTapset = 0;           // postfilter_tapset
     uint32_t rangeFinal = 0;    // dec->rng after the frame (st->rng), the spec's conformance hook
+    size_t recordBytes = 0;     // decodeSymbols(): length of the (compact) record written, a multiple of 16
     // freq[channels][120 << LM] is written to the caller's buffer by CeltDecoder::decode()
 };
 

@@ -90,8 +90,16 @@ done:
 // nyqh_symbol_bytes(channels) bytes each; the dump ends at the first frame that is not 20 ms (-12 if the very first); info[6] = frames that carry host-built freq[]
 // (NYQ_SYM_HOST_FREQ) instead of symbols.  A test hook: the GPU's band shapes against decode()'s.
 long nyqh_symbol_bytes(int channels) { return (long)CeltDecoder::symbolBytes(channels); }
+// offsets16 != NULL: the records are written PACKED back to back (frame i at records + 16 * offsets16[i], max_frames + 1
+// entries; `records` must hold max_frames slots all the same); NULL: one record per slot
+int nyqh_decode_to_symbols_packed(const unsigned char *file, long size, long max_frames, unsigned char *records, unsigned *offsets16,
+                                  int *flags, float *pf_gain, unsigned *range, long *info);
 int nyqh_decode_to_symbols(const unsigned char *file, long size, long max_frames, unsigned char *records, int *flags, float *pf_gain,
                            unsigned *range, long *info) {
+    return nyqh_decode_to_symbols_packed(file, size, max_frames, records, nullptr, flags, pf_gain, range, info);
+}
+int nyqh_decode_to_symbols_packed(const unsigned char *file, long size, long max_frames, unsigned char *records, unsigned *offsets16,
+                                  int *flags, float *pf_gain, unsigned *range, long *info) {
     OggOpusFile f;
     try {
         f = parseOggOpus(file, (size_t)size);
@@ -116,9 +124,11 @@ int nyqh_decode_to_symbols(const unsigned char *file, long size, long max_frames
         for (const auto &fr : pf.frames) {
             if (nframes >= max_frames) goto done;
             CeltFrame info1;
-            unsigned char *r = records + (size_t)nframes * rec;
+            if (offsets16 && nframes == 0) offsets16[0] = 0;
+            unsigned char *r = offsets16 ? records + (size_t)offsets16[nframes] * 16 : records + (size_t)nframes * rec;
             const int rc = dec.decodeSymbols(fr.first, fr.second, pf.frameSize, r, info1);
             if (rc < 0) return rc;
+            if (offsets16) offsets16[nframes + 1] = offsets16[nframes] + (unsigned)(info1.recordBytes / 16);
             hostBuilt += reinterpret_cast<const nyq_sym_head *>(r)->flags & NYQ_SYM_HOST_FREQ;
             flags[4 * nframes + 0] = info1.transient;
             flags[4 * nframes + 1] = info1.pfPitch;

@@ -123,18 +123,20 @@ int nyq_celt_frames_to_pcm_mapped(nyq_ctx *ctx, int LM, const float *freq, const
 // stale, misplaced or half written changes the output.  (Bytes the entropy stage leaves undefined -- unused slots -- are not
 // read, as the real kernel does not read them.)
 size_t nyq_celt_symbol_bytes(int channels) { return channels == 1 || channels == 2 ? (size_t)3072 + (size_t)channels * 3840 : 0; }
-int nyq_celt_symbols_to_pcm_mapped(nyq_ctx *ctx, const void *sym, const unsigned char *transient, const int *pf_pitch, const float *pf_gain,
-                                   const int *pf_tapset, float *out, const nyq_out_desc *desc, float *state, size_t nstreams, size_t nframes,
-                                   int channels, size_t frames_per_stream) {
+int nyq_celt_symbols_packed_to_pcm_mapped(nyq_ctx *ctx, const void *sym, const unsigned int *offsets, size_t stream_bytes,
+                                          const unsigned char *transient, const int *pf_pitch, const float *pf_gain, const int *pf_tapset,
+                                          float *out, const nyq_out_desc *desc, float *state, size_t nstreams, size_t nframes, int channels,
+                                          size_t frames_per_stream) {
     const size_t rec = nyq_celt_symbol_bytes(channels), per = (size_t)channels * 960;
     float *freq = (float *)std::malloc(sizeof(float) * nstreams * frames_per_stream * per);
     for (size_t s = 0; s < nstreams; s++)
         for (size_t f = 0; f < nframes; f++) {
-            const unsigned char *r = (const unsigned char *)sym + (s * frames_per_stream + f) * rec;
+            const unsigned char *r = offsets ? (const unsigned char *)sym + s * stream_bytes + (size_t)offsets[s * (frames_per_stream + 1) + f] * 16
+                                             : (const unsigned char *)sym + (s * frames_per_stream + f) * rec;
             float *x = freq + (s * frames_per_stream + f) * per;
             const nyq_sym_head *H = (const nyq_sym_head *)r;
             if (H->flags & NYQ_SYM_HOST_FREQ) {
-                std::memcpy(x, r + 3072, sizeof(float) * per);
+                std::memcpy(x, r + 32, sizeof(float) * per);
                 continue;
             }
             unsigned h = 2166136261u;
@@ -144,9 +146,7 @@ int nyq_celt_symbols_to_pcm_mapped(nyq_ctx *ctx, const void *sym, const unsigned
             mix(H, sizeof *H);
             if (H->nops) {
                 for (int c = 0; c < H->channels; c++) mix(r + 32 + 4 * (c * 21 + H->start), 4 * (size_t)(H->end - H->start));
-                mix(r + 200, sizeof(nyq_sym_op) * H->nops);
-                mix(r + 200 + 16 * NYQ_SYM_MAX_OPS, sizeof(nyq_sym_vec) * H->nvecs);
-                mix(r + 3072, sizeof(nyq_sym_leaf) * H->nleaves);
+                mix(r + 200, sizeof(nyq_sym_op) * H->nops + sizeof(nyq_sym_vec) * H->nvecs + sizeof(nyq_sym_leaf) * H->nleaves);
             }
             for (size_t k = 0; k < per; k++) x[k] = H->nops ? (float)((h >> (k % 13)) & 0xff) * (1.f / 64) : 0.f;
         }
@@ -154,6 +154,12 @@ int nyq_celt_symbols_to_pcm_mapped(nyq_ctx *ctx, const void *sym, const unsigned
                                                  channels, frames_per_stream);
     std::free(freq);
     return rc;
+}
+int nyq_celt_symbols_to_pcm_mapped(nyq_ctx *ctx, const void *sym, const unsigned char *transient, const int *pf_pitch, const float *pf_gain,
+                                   const int *pf_tapset, float *out, const nyq_out_desc *desc, float *state, size_t nstreams, size_t nframes,
+                                   int channels, size_t frames_per_stream) {
+    return nyq_celt_symbols_packed_to_pcm_mapped(ctx, sym, nullptr, 0, transient, pf_pitch, pf_gain, pf_tapset, out, desc, state, nstreams,
+                                                 nframes, channels, frames_per_stream);
 }
 
 int nyq_celt_frames_to_pcm_window(nyq_ctx *ctx, int LM, const float *freq, const unsigned char *transient, const int *pf_pitch,

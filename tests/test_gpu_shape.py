@@ -47,6 +47,32 @@ def symbols(H, raw, max_frames, channels):
     return rc, sym, flags, gain, rng, info
 
 
+def test_packed_records_equal_slotted_records(host, ctx):
+    """Records packed back to back (what the batch decoder stages: a record is as long as its content) through
+    nyq_celt_symbols_packed_to_pcm_mapped against the same records one per slot: bit for bit, on a length that takes the
+    time-window path (sb-reverie's first 1500 frames) and on a short one; the packed form is about half the bytes."""
+    u8 = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+    u32 = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+    host.nyqh_decode_to_symbols_packed.argtypes = [C.c_char_p, C.c_long, C.c_long, u8, u32] + list(host.nyqh_decode_to_freq.argtypes[4:])
+    for name, cap in (("sb-reverie.opus", 1500), ("short.opus", 220)):
+        raw = open(os.path.join(GOLDEN, name), "rb").read()
+        rc, sym, flags, gain, rng, info = symbols(host, raw, cap, 2)
+        nf = int(info[2])
+        assert rc == 0 and nf == cap
+        packed = np.zeros_like(sym)
+        off = np.zeros(cap + 1, np.uint32)
+        flags2, gain2, rng2, info2 = np.zeros((cap, 4), np.int32), np.zeros(cap, np.float32), np.zeros(cap, np.uint32), np.zeros(8, np.int64)
+        assert host.nyqh_decode_to_symbols_packed(raw, len(raw), cap, packed, off, flags2, gain2, rng2, info2) == 0
+        assert int(info2[2]) == nf and np.array_equal(rng, rng2)
+        used = int(off[nf]) * 16
+        assert 0.3 * sym[:nf].size <= used <= 0.7 * sym[:nf].size
+        tr, pp, pt = (np.ascontiguousarray(flags[:nf, k]) for k in range(3))
+        args = (tr.astype(np.uint8), pp.astype(np.int32), gain[:nf].copy(), pt.astype(np.int32))
+        want = ctx.celt_symbols_to_pcm(sym[:nf], *args, 1, nf, 2)
+        got = ctx.celt_symbols_packed_to_pcm(packed, off, packed.size, *args, 1, nf, 2)
+        assert np.array_equal(got, want)
+
+
 def test_record_size_is_one_number_on_both_sides(host, ctx):
     for ch in (1, 2):
         assert host.nyqh_symbol_bytes(ch) == ctx.lib.nyq_celt_symbol_bytes(ch) == 3072 + ch * 3840
