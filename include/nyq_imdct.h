@@ -271,11 +271,15 @@ typedef struct nyq_sym_op {          /* kinds: 0 vector a | 1 single X[a] = f0 (
     short a, b, n;
     float f0, f1;
 } nyq_sym_op;                        /* 16 bytes */
-size_t nyq_celt_symbol_bytes(int channels);
+size_t nyq_celt_symbol_bytes(int channels);                 /* the slot of a 20 ms frame */
+size_t nyq_celt_symbol_bytes_lm(int channels, int LM);      /* ... of a frame of 120 << LM samples */
 /* d_sym [nstreams][sstride frames][record] -> d_freq [nstreams][nframes][channels][960] (dense); sstride = frames per stream
  * in d_sym (0 = nframes).  Asynchronous on the context stream. */
 int nyq_celt_shape_dev(nyq_ctx *ctx, const void *d_sym, float *d_freq, size_t nstreams, size_t nframes, int channels,
                        size_t sstride);
+/* the same for frames of 120 << LM samples: slots of nyq_celt_symbol_bytes_lm, d_freq [nstreams][nframes][channels][120 << LM] */
+int nyq_celt_shape_lm_dev(nyq_ctx *ctx, int LM, const void *d_sym, float *d_freq, size_t nstreams, size_t nframes, int channels,
+                          size_t sstride);
 
 /* libvorbis' mdct_backward (third_party/libvorbis/src/mdct.c:397-491) on `batch` rows: n/2 coefficients
  * in, n samples out per row, n a power of two in 64..8192 (every Vorbis block size).
@@ -336,9 +340,9 @@ int nyq_celt_frames_to_pcm_mapped(nyq_ctx *ctx, int LM, const float *freq, const
                                   float *out, const nyq_out_desc *desc, float *state, size_t nstreams, size_t nframes,
                                   int channels, size_t frames_per_stream);
 
-/* The same with SYMBOL records in place of freq[] (LM 3; `sym` [nstreams][frames_per_stream][nyq_celt_symbol_bytes]): the
+/* The same with SYMBOL records in place of freq[] (`sym` [nstreams][frames_per_stream][nyq_celt_symbol_bytes_lm(channels, LM)]): the
  * band shapes are built on the device (nyq_celt_shape_dev), then the chain runs as above.  desc may be NULL (dense `out`). */
-int nyq_celt_symbols_to_pcm_mapped(nyq_ctx *ctx, const void *sym, const unsigned char *transient,
+int nyq_celt_symbols_to_pcm_mapped(nyq_ctx *ctx, int LM, const void *sym, const unsigned char *transient,
                                    const int *pf_pitch, const float *pf_gain, const int *pf_tapset,
                                    float *out, const nyq_out_desc *desc, float *state, size_t nstreams, size_t nframes,
                                    int channels, size_t frames_per_stream);
@@ -348,7 +352,7 @@ int nyq_celt_symbols_to_pcm_mapped(nyq_ctx *ctx, const void *sym, const unsigned
  * (char *)sym + s * stream_bytes, frame f of the call at 16 * offsets[s * (frames_per_stream + 1) + f] bytes from there and ends where
  * frame f + 1 begins (so `offsets` has one entry more per stream than frames; for a time slice pass the pointer to the slice's
  * first entry, `sym` unchanged).  offsets == NULL: slots, as above. */
-int nyq_celt_symbols_packed_to_pcm_mapped(nyq_ctx *ctx, const void *sym, const unsigned int *offsets, size_t stream_bytes,
+int nyq_celt_symbols_packed_to_pcm_mapped(nyq_ctx *ctx, int LM, const void *sym, const unsigned int *offsets, size_t stream_bytes,
                                           const unsigned char *transient, const int *pf_pitch, const float *pf_gain,
                                           const int *pf_tapset, float *out, const nyq_out_desc *desc, float *state,
                                           size_t nstreams, size_t nframes, int channels, size_t frames_per_stream);

@@ -30,7 +30,7 @@ EXPORTS = [
     "nyq_celt_chain_fused_supported", "nyq_celt_chain_dev", "nyq_device_copy_forms", "nyq_device_copy_form_name", "nyq_device_copy_dev",
     "nyq_celt_chain_mapped_dev", "nyq_device_alloc", "nyq_device_free", "nyq_device_zero", "nyq_device_download", "nyq_device_dup_channel",
     "nyq_celt_frames_to_pcm_mapped", "nyq_celt_symbol_bytes", "nyq_celt_shape_dev", "nyq_celt_symbols_to_pcm_mapped",
-    "nyq_celt_symbols_packed_to_pcm_mapped",
+    "nyq_celt_symbols_packed_to_pcm_mapped", "nyq_celt_symbol_bytes_lm", "nyq_celt_shape_lm_dev",
     "nyq_celt_frames_to_pcm", "nyq_celt_frames_to_pcm_window", "nyq_celt_state_floats", "nyq_vorbis_imdct_batch_dev", "nyq_vorbis_imdct_batch",
     "nyq_ifft_batch", "nyq_imdct_batch", "nyq_imdct_chain", "nyq_host_alloc", "nyq_host_free",
     "processMDCTCuda", "processMDCTCudaB1C2", "processMDCTCudaB8C2", "cleanupCudaBuffers", "printCudaVersion", "nyq_shim_set_error_handler",
@@ -151,8 +151,11 @@ def load(path=None):
     L.nyq_celt_symbol_bytes.argtypes = [i]
     L.nyq_celt_symbol_bytes.restype = sz
     L.nyq_celt_shape_dev.argtypes = [vp, vp, vp, sz, sz, i, sz]
-    L.nyq_celt_symbols_to_pcm_mapped.argtypes = [vp] + [vp] * 8 + [sz, sz, i, sz]
-    L.nyq_celt_symbols_packed_to_pcm_mapped.argtypes = [vp, vp, vp, sz] + [vp] * 7 + [sz, sz, i, sz]
+    L.nyq_celt_symbols_to_pcm_mapped.argtypes = [vp, i] + [vp] * 8 + [sz, sz, i, sz]
+    L.nyq_celt_symbols_packed_to_pcm_mapped.argtypes = [vp, i, vp, vp, sz] + [vp] * 7 + [sz, sz, i, sz]
+    L.nyq_celt_symbol_bytes_lm.argtypes = [i, i]
+    L.nyq_celt_symbol_bytes_lm.restype = sz
+    L.nyq_celt_shape_lm_dev.argtypes = [vp, i, vp, vp, sz, sz, i, sz]
     L.nyq_device_copy_forms.restype = i
     L.nyq_device_copy_form_name.argtypes = [i]
     L.nyq_device_copy_form_name.restype = C.c_char_p
@@ -353,14 +356,14 @@ class Context:
                                              V(d_pf_state_in), V(d_pf_state_out), V(d_overlap), V(d_hist), V(d_deemph),
                                              V(d_out), V(d_pcm), V(d_work), nstreams, nframes, channels))
 
-    def celt_shape_dev(self, d_sym, d_freq, nstreams, nframes, channels, sstride=0):
-        """symbol records -> freq[] (the band shapes of 20 ms frames built on the device)."""
-        self._ck(self.lib.nyq_celt_shape_dev(self.h, C.c_void_p(d_sym), C.c_void_p(d_freq), nstreams, nframes, channels, sstride))
+    def celt_shape_dev(self, d_sym, d_freq, nstreams, nframes, channels, sstride=0, lm=3):
+        """symbol records -> freq[] (the band shapes of frames of 120 << lm samples built on the device)."""
+        self._ck(self.lib.nyq_celt_shape_lm_dev(self.h, lm, C.c_void_p(d_sym), C.c_void_p(d_freq), nstreams, nframes, channels, sstride))
 
-    def celt_symbols_to_pcm(self, sym, transient, pf_pitch, pf_gain, pf_tapset, nstreams, nframes, channels, state=None):
-        """host symbol records [nstreams][nframes][nyq_celt_symbol_bytes] -> interleaved PCM [nstreams][nframes * 960][channels]"""
-        out = np.empty((nstreams, nframes * 960, channels), np.float32)
-        self._ck(self.lib.nyq_celt_symbols_to_pcm_mapped(self.h, _np(sym), _np(transient), _np(pf_pitch), _np(pf_gain), _np(pf_tapset),
+    def celt_symbols_to_pcm(self, sym, transient, pf_pitch, pf_gain, pf_tapset, nstreams, nframes, channels, state=None, lm=3):
+        """host symbol records [nstreams][nframes][nyq_celt_symbol_bytes_lm] -> interleaved PCM [nstreams][nframes * (120 << lm)][channels]"""
+        out = np.empty((nstreams, nframes * (120 << lm), channels), np.float32)
+        self._ck(self.lib.nyq_celt_symbols_to_pcm_mapped(self.h, lm, _np(sym), _np(transient), _np(pf_pitch), _np(pf_gain), _np(pf_tapset),
                                                         _np(out), None, _np(state), nstreams, nframes, channels, nframes))
         return out
 
@@ -368,7 +371,7 @@ class Context:
                                    state=None):
         """the same with records packed back to back: offsets uint32 [nstreams][nframes + 1], 16-byte units from each stream's base"""
         out = np.empty((nstreams, nframes * 960, channels), np.float32)
-        self._ck(self.lib.nyq_celt_symbols_packed_to_pcm_mapped(self.h, _np(sym), _np(offsets), stream_bytes, _np(transient), _np(pf_pitch),
+        self._ck(self.lib.nyq_celt_symbols_packed_to_pcm_mapped(self.h, 3, _np(sym), _np(offsets), stream_bytes, _np(transient), _np(pf_pitch),
                                                                _np(pf_gain), _np(pf_tapset), _np(out), None, _np(state), nstreams, nframes,
                                                                channels, nframes))
         return out

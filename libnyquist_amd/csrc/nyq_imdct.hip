@@ -828,14 +828,18 @@ static_assert(sizeof(nyq_sym_head) == sizeof(SymHead) && sizeof(nyq_sym_leaf) ==
               "nyq_sym_* (C ABI) and nyq::Sym* (kernel) are one layout");
 
 extern "C" size_t nyq_celt_symbol_bytes(int channels) { return channels == 1 || channels == 2 ? sym_bytes(channels) : 0; }
+extern "C" size_t nyq_celt_symbol_bytes_lm(int channels, int LM) {
+    return (channels == 1 || channels == 2) && LM >= 0 && LM <= 3 ? sym_bytes(channels, LM) : 0;
+}
 
 // sstride / fstride: frames per stream in d_sym / d_freq (0 = nframes: dense)
 // d_off: records packed back to back inside each stream's region of sstride slots, d_off[stream * ostride + frame] = byte offset
 // of the frame's record from the region's start; null: one record per slot of nyq_celt_symbol_bytes
 static int shape_core(nyq_ctx *ctx, const void *d_sym, float *d_freq, size_t nstreams, size_t nframes, int channels, size_t sstride,
-                      size_t fstride = 0, const unsigned *d_off = nullptr, size_t ostride = 0) {
+                      size_t fstride = 0, const unsigned *d_off = nullptr, size_t ostride = 0, int LM = 3) {
     if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_celt_shape_dev: ctx is NULL");
     if (channels != 1 && channels != 2) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_shape_dev: symbol records carry mono and stereo streams");
+    if (LM < 0 || LM > 3) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_shape_dev: LM must be 0..3");
     if (nstreams == 0 || nframes == 0) return NYQ_OK;
     if (!d_sym || !d_freq) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_shape_dev: NULL buffer");
     if (sstride == 0) sstride = nframes;
@@ -855,7 +859,7 @@ static int shape_core(nyq_ctx *ctx, const void *d_sym, float *d_freq, size_t nst
     const size_t want = (total + kShapeWaves - 1) / kShapeWaves, resident = (size_t)ctx->cus;
     const unsigned grid = (unsigned)(want < resident ? want : resident);
     hipLaunchKernelGGL(celt_shape_kernel, dim3(grid), dim3(kWave * kShapeWaves), 0, ctx->stream, static_cast<const unsigned char *>(d_sym), d_freq,
-                       ctx->d_pvq, (long)nstreams, (long)nframes, channels, (long)sstride, (long)fstride, d_off, (long)(ostride ? ostride : nframes));
+                       ctx->d_pvq, (long)nstreams, (long)nframes, channels, (long)sstride, (long)fstride, d_off, (long)(ostride ? ostride : nframes), LM);
     NYQ_HIP(ctx, hipGetLastError());
     return NYQ_OK;
 }
@@ -863,6 +867,10 @@ static int shape_core(nyq_ctx *ctx, const void *d_sym, float *d_freq, size_t nst
 extern "C" int nyq_celt_shape_dev(nyq_ctx *ctx, const void *d_sym, float *d_freq, size_t nstreams, size_t nframes, int channels,
                                   size_t sstride) {
     return shape_core(ctx, d_sym, d_freq, nstreams, nframes, channels, sstride);
+}
+extern "C" int nyq_celt_shape_lm_dev(nyq_ctx *ctx, int LM, const void *d_sym, float *d_freq, size_t nstreams, size_t nframes, int channels,
+                                     size_t sstride) {
+    return shape_core(ctx, d_sym, d_freq, nstreams, nframes, channels, sstride, 0, nullptr, 0, LM);
 }
 
 extern "C" void *nyq_device_alloc(nyq_ctx *ctx, size_t bytes) {
@@ -1208,8 +1216,8 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
     if ((!freq && !sym) || !pf_pitch || !pf_gain || !pf_tapset || (!out && !all_mapped))
         return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm: NULL buffer");
     if (desc && channels > 2) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm_mapped: output descriptors serve mono and stereo streams");
-    if (sym && (LM != 3 || channels > 2)) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_symbols_to_pcm_mapped: symbol records carry 20 ms mono and stereo frames");
-    const size_t rec = sym ? sym_bytes(channels) : 0;
+    if (sym && channels > 2) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_symbols_to_pcm_mapped: symbol records carry mono and stereo streams");
+    const size_t rec = sym ? sym_bytes(channels, LM) : 0;
     NYQ_HIP(ctx, hipSetDevice(ctx->device));
     const size_t N = (size_t)120 << LM, nsc = nstreams * (size_t)channels, nfr = nstreams * nframes;
     const size_t n_x = round16f(nsc * nframes * N), n_w = round16f(nyq_celt_synth_work_floats(nstreams, nframes, channels)),
@@ -1343,7 +1351,7 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
                 NYQ_HIP(ctx, hipEventRecord(up, hs));
                 NYQ_HIP(ctx, hipStreamWaitEvent(ctx->stream, up, 0));
                 if (sym) rc = shape_core(ctx, offsets ? d_sy : d_sy + f0 * rec, d_x + f0 * channels * N, nstreams, len, channels, nframes, nframes,
-                                         offsets ? d_of + f0 : nullptr, ostr);
+                                         offsets ? d_of + f0 : nullptr, ostr, LM);
                 if (rc == NYQ_OK)
                     rc = chain_core(ctx, LM, d_x + f0 * channels * N, transient ? d_t + f0 : nullptr, d_pp + f0, d_pg + f0, d_pt + f0, pf_a, pf_b, d_ov,
                                     d_hi, d_de, d_out + f0 * N * channels, d_pcm, d_w, nstreams, len, channels, nframes,
@@ -1407,7 +1415,7 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
         }
         NYQ_HIP(ctx, hipEventRecord(up, hs));
         NYQ_HIP(ctx, hipStreamWaitEvent(ctx->stream, up, 0));
-        if (sym && (rc = shape_core(ctx, d_sy + fo * rec, d_x + xo, cnt, nframes, channels, nframes, 0, offsets ? d_of + s0 * ostr : nullptr, ostr)) != NYQ_OK) {
+        if (sym && (rc = shape_core(ctx, d_sy + fo * rec, d_x + xo, cnt, nframes, channels, nframes, 0, offsets ? d_of + s0 * ostr : nullptr, ostr, LM)) != NYQ_OK) {
             (void)hipStreamSynchronize(hs);
             (void)hipStreamSynchronize(ctx->stream);
             (void)hipStreamSynchronize(ds);
@@ -1456,21 +1464,21 @@ extern "C" int nyq_celt_frames_to_pcm_mapped(nyq_ctx *ctx, int LM, const float *
                               frames_per_stream, desc);
 }
 
-extern "C" int nyq_celt_symbols_to_pcm_mapped(nyq_ctx *ctx, const void *sym, const unsigned char *transient, const int *pf_pitch,
+extern "C" int nyq_celt_symbols_to_pcm_mapped(nyq_ctx *ctx, int LM, const void *sym, const unsigned char *transient, const int *pf_pitch,
                                               const float *pf_gain, const int *pf_tapset, float *out, const nyq_out_desc *desc,
                                               float *state, size_t nstreams, size_t nframes, int channels, size_t frames_per_stream) {
-    return nyq_celt_symbols_packed_to_pcm_mapped(ctx, sym, nullptr, 0, transient, pf_pitch, pf_gain, pf_tapset, out, desc, state, nstreams,
+    return nyq_celt_symbols_packed_to_pcm_mapped(ctx, LM, sym, nullptr, 0, transient, pf_pitch, pf_gain, pf_tapset, out, desc, state, nstreams,
                                                  nframes, channels, frames_per_stream);
 }
 
-extern "C" int nyq_celt_symbols_packed_to_pcm_mapped(nyq_ctx *ctx, const void *sym, const unsigned *offsets, size_t stream_bytes,
+extern "C" int nyq_celt_symbols_packed_to_pcm_mapped(nyq_ctx *ctx, int LM, const void *sym, const unsigned *offsets, size_t stream_bytes,
                                                      const unsigned char *transient, const int *pf_pitch, const float *pf_gain,
                                                      const int *pf_tapset, float *out, const nyq_out_desc *desc, float *state,
                                                      size_t nstreams, size_t nframes, int channels, size_t frames_per_stream) {
     if (ctx && frames_per_stream < nframes)
         return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_symbols_to_pcm_mapped: frames_per_stream is smaller than nframes");
     if (ctx && !sym) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_symbols_to_pcm_mapped: NULL buffer");
-    return frames_to_pcm_core(ctx, 3, nullptr, transient, pf_pitch, pf_gain, pf_tapset, out, state, nstreams, nframes, channels,
+    return frames_to_pcm_core(ctx, LM, nullptr, transient, pf_pitch, pf_gain, pf_tapset, out, state, nstreams, nframes, channels,
                               frames_per_stream, desc, static_cast<const unsigned char *>(sym), offsets, stream_bytes);
 }
 

@@ -53,7 +53,7 @@ struct SymOp {
     float f0, f1;
 };
 constexpr int kSymMaxOps = 113, kSymMaxVecs = 44;
-constexpr int kSymN = 960;                                           // bins per channel (LM 3)
+constexpr int kSymN = 960;                                           // bins per channel of a 20 ms frame (LM 3); 120 << LM in general
 // a record is COMPACT: head | gain[42] | ops[nops] | vecs[nvecs] | leaves[nleaves] | (anti-collapse) level[42], or head | freq[];
 // the slot of the fixed-stride form (sym_bytes) holds the largest record the entropy stage writes
 constexpr int kSymOpsOff = 32 + 42 * 4;                              // 200
@@ -61,7 +61,14 @@ constexpr int kSymFreqOff = 32;
 constexpr int kSymSlotFixed = 3072;
 constexpr int kSymMaxLeaves = 192;                                   // 96 per channel: what the body holds
 constexpr int kPvqDim = 178;                                         // U(n, k) for n, k < 178 (the widest band has 176 bins)
-__host__ __device__ inline size_t sym_bytes(int channels) { return (size_t)kSymSlotFixed + (size_t)channels * kSymN * 4; }
+// slot of a frame of 120 << LM samples: the 20 ms slot, 5/8 of it at 10 ms, and a floor below that (the fixed parts, a
+// leaf or two per vector: short frames spend their bits on fewer, not smaller, records); never less than head + freq[]
+__host__ __device__ inline size_t sym_bytes(int channels, int LM = 3) {
+    const size_t full = (size_t)kSymSlotFixed + (size_t)channels * kSymN * 4;
+    const size_t floor_ = LM == 3 ? 0 : (size_t)2048 * (size_t)channels + 512;
+    const size_t scaled = LM == 3 ? full : LM == 2 ? full * 5 / 8 : full >> (3 - LM);
+    return ((scaled > floor_ ? scaled : floor_) + 15) & ~(size_t)15;
+}
 
 constexpr int kShapeNorm = 2 * 800;                                  // fold memory: two channels x bins below the last band
 constexpr int kShapeLdsFloats = 2 * kSymN + kShapeNorm + 192 + 192;
@@ -420,10 +427,10 @@ __device__ __forceinline__ void shape_vector(const ShapeFrame &F, const SymVec v
     }
 }
 
-// band edges of the 48 kHz mode at 20 ms (modes.c:41-44 times 8)
-__device__ __forceinline__ int shape_edge(int i) {
-    const short e[22] = {0, 8, 16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 272, 320, 384, 480, 624, 800};
-    return e[i];
+// band edges of the 48 kHz mode (modes.c:41-44) at 120 << LM samples per frame
+__device__ __forceinline__ int shape_edge(int i, int LM) {
+    const short e[22] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 34, 40, 48, 60, 78, 100};
+    return e[i] << LM;
 }
 
 // measurement switches (tools/shape_time.py builds variants with them; the product defines none)
@@ -456,7 +463,7 @@ __device__ __forceinline__ void stage_words(void *dst, const void *src, int byte
 __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const unsigned char *__restrict__ sym, float *__restrict__ freq,
                                                                         const unsigned *__restrict__ pvq, long nstreams, long nframes,
                                                                         int channels, long sstride, long fstride,
-                                                                        const unsigned *__restrict__ offsets, long ostride) {
+                                                                        const unsigned *__restrict__ offsets, long ostride, int LM) {
 #pragma clang fp contract(off)
     __shared__ __attribute__((aligned(16))) ShapeWaveLds wl[kShapeWaves];
     __shared__ unsigned tab[kPvqInfo + kPvqWords];
@@ -465,32 +472,33 @@ __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const un
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
     ShapeWaveLds &L = wl[wv];
     float *X = L.f, *norm = L.f + 2 * kSymN, *work = norm + kShapeNorm, *tmp = work + 192;
-    const size_t rec = sym_bytes(channels);
+    const size_t rec = sym_bytes(channels, LM);
+    const int N = 120 << LM;                                         // bins per channel
     const long total = nstreams * nframes;
     for (long u = (long)blockIdx.x * kShapeWaves + wv; u < total; u += (long)gridDim.x * kShapeWaves) {
         const long s = u / nframes, f = u - s * nframes;
         // where the frame's record is: packed back to back inside its stream's region (offsets[stream * ostride + frame], 16-byte
         // units from the region's start) or in slots of sym_bytes; a stream's region is sstride slots long either way
         const unsigned char *r = sym + (size_t)s * (size_t)sstride * rec + (offsets ? (size_t)offsets[s * ostride + f] * 16 : (size_t)f * rec);
-        float *out = freq + ((size_t)s * (size_t)fstride + (size_t)f) * (size_t)channels * kSymN;
+        float *out = freq + ((size_t)s * (size_t)fstride + (size_t)f) * (size_t)channels * N;
         const SymHead H = *reinterpret_cast<const SymHead *>(r);
         const int CC = channels;                                     // the stream's channels: the layout of freq[]
         if (H.flags & 1) {                                           // the host built this frame itself: its freq[] is the body
             const float4 *b4 = reinterpret_cast<const float4 *>(r + kSymFreqOff);
             float4 *o4 = reinterpret_cast<float4 *>(out);
-            for (int j = lane; j < CC * kSymN / 4; j += kWave) o4[j] = b4[j];
+            for (int j = lane; j < CC * N / 4; j += kWave) o4[j] = b4[j];
             continue;
         }
         if (H.nops == 0) {                                           // a record of zeros: a silent (or padding) frame
             float4 *o4 = reinterpret_cast<float4 *>(out);
-            for (int j = lane; j < CC * kSymN / 4; j += kWave) o4[j] = float4{0.f, 0.f, 0.f, 0.f};
+            for (int j = lane; j < CC * N / 4; j += kWave) o4[j] = float4{0.f, 0.f, 0.f, 0.f};
             continue;
         }
         const int C = H.channels == 2 ? 2 : 1;                       // what the packet codes
-        if (H.start > 20 || H.end > 21 || H.start > H.end || H.nops > kSymMaxOps || H.nvecs > kSymMaxVecs || H.nleaves > kSymMaxLeaves) {
+        if (H.lm != LM || H.start > 20 || H.end > 21 || H.start > H.end || H.nops > kSymMaxOps || H.nvecs > kSymMaxVecs || H.nleaves > kSymMaxLeaves) {
             // (a damaged head -- its counts would place the record's parts outside the record: a silent frame)
             float4 *o4 = reinterpret_cast<float4 *>(out);
-            for (int j = lane; j < CC * kSymN / 4; j += kWave) o4[j] = float4{0.f, 0.f, 0.f, 0.f};
+            for (int j = lane; j < CC * N / 4; j += kWave) o4[j] = float4{0.f, 0.f, 0.f, 0.f};
             continue;
         }
         const int nleaves = H.nleaves < kSymMaxLeaves ? H.nleaves : kSymMaxLeaves;
@@ -510,7 +518,7 @@ __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const un
         F.leaves = L.leaves;
         F.leafCm = L.leafCm;
         F.masks = L.masks;
-        float *norm2 = norm + (shape_edge(20) - shape_edge(H.start));
+        float *norm2 = norm + (shape_edge(20, LM) - shape_edge(H.start, LM));
         unsigned seed = H.seed;
         // pass A: every pulse leaf of the frame, a leaf per lane
         for (int l = lane; l < nleaves && !NYQ_SHAPE_DBG_NO_A; l += kWave) {
@@ -598,47 +606,47 @@ __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const un
             const float *level = reinterpret_cast<const float *>(rleaves + (size_t)H.nleaves * sizeof(SymLeaf));
             const float laneLevel = lane < 2 * 21 ? level[lane] : 0.f;
             for (int i = H.start; i < H.end; i++) {
-                const int e0 = shape_edge(i), n0 = (shape_edge(i + 1) - e0) >> 3;
+                const int e0 = shape_edge(i, LM), n0 = (shape_edge(i + 1, LM) - e0) >> LM, M = 1 << LM;
                 for (int c = 0; c < C; c++) {
                     const unsigned m = L.masks[c * 21 + i];
-                    if ((m & 0xFFu) == 0xFFu) continue;
+                    if ((m & ((1u << M) - 1)) == (1u << M) - 1) continue;           // every block of the band received something
                     const float rl = __shfl(laneLevel, c * 21 + i);
-                    float *x = X + c * kSymN + e0;
-                    for (int k = 0; k < 8; k++) {
+                    float *x = X + c * N + e0;
+                    for (int k = 0; k < M; k++) {
                         if (m >> k & 1) continue;
-                        for (int j = lane; j < n0; j += kWave) x[(j << 3) + k] = (lcg_jump(seed, j + 1) & 0x8000u) ? rl : -rl;
+                        for (int j = lane; j < n0; j += kWave) x[(j << LM) + k] = (lcg_jump(seed, j + 1) & 0x8000u) ? rl : -rl;
                         seed = lcg_jump(seed, n0);
                     }
                     NYQ_WAVE_SYNC();
                     float e = 0.f;
-                    for (int j = lane; j < 8 * n0; j += kWave) e += x[j] * x[j];
+                    for (int j = lane; j < M * n0; j += kWave) e += x[j] * x[j];
                     const float g = 1.f / sqrtf(wave_sum(e) + 1e-15f);
-                    for (int j = lane; j < 8 * n0; j += kWave) x[j] = g * x[j];
+                    for (int j = lane; j < M * n0; j += kWave) x[j] = g * x[j];
                     NYQ_WAVE_SYNC();
                 }
             }
         }
         // denormalise_bands: every band times its gain, zeros below `start` and above `end`; a packet that codes one channel
         // of a stereo stream is played on both, one that codes two for a mono stream is mixed down
-        const int lo = shape_edge(H.start), hi = shape_edge(H.end);
+        const int lo = shape_edge(H.start, LM), hi = shape_edge(H.end, LM);
         for (int c = 0; c < CC; c++) {
-            float *fo = out + c * kSymN;
+            float *fo = out + c * N;
             for (int j = lane; j < lo; j += kWave) fo[j] = 0.f;
-            for (int j = hi + lane; j < kSymN; j += kWave) fo[j] = 0.f;
+            for (int j = hi + lane; j < N; j += kWave) fo[j] = 0.f;
         }
         for (int i = H.start; i < H.end; i++) {
-            const int e0 = shape_edge(i), e1 = shape_edge(i + 1);
+            const int e0 = shape_edge(i, LM), e1 = shape_edge(i + 1, LM);
             const float g0 = __shfl(laneGain, i), g1 = __shfl(laneGain, 21 + i);
             for (int j = e0 + lane; j < e1; j += kWave) {
                 const float a = X[j] * g0;
                 if (C == CC) {
                     out[j] = a;
-                    if (C == 2) out[kSymN + j] = X[kSymN + j] * g1;
+                    if (C == 2) out[N + j] = X[N + j] * g1;
                 } else if (C == 1) {
                     out[j] = a;
-                    out[kSymN + j] = a;
+                    out[N + j] = a;
                 } else {
-                    out[j] = .5f * (a + X[kSymN + j] * g1);
+                    out[j] = .5f * (a + X[N + j] * g1);
                 }
             }
         }

@@ -443,8 +443,8 @@ private:
                 groups_.back().N = (size_t)120 << std::get<1>(key);
                 groups_.back().dev = dev;
                 groups_.back().mapped = mapped;
-                groups_.back().symbols = symbolRecords() && groups_.back().LM == 3 && groups_.back().ch <= 2;
-                groups_.back().frameBytes = groups_.back().symbols ? nyq_celt_symbol_bytes(groups_.back().ch)
+                groups_.back().symbols = symbolRecords() && groups_.back().ch <= 2;
+                groups_.back().frameBytes = groups_.back().symbols ? nyq_celt_symbol_bytes_lm(groups_.back().ch, groups_.back().LM)
                                                                    : (size_t)groups_.back().ch * groups_.back().N * sizeof(float);
             }
             Group &g = groups_[it->second];
@@ -687,10 +687,10 @@ private:
                 const uint8_t *in = g.symbols ? g.in + p.k0 * g.maxF * g.frameBytes : g.in + so * g.frameBytes;   // (packed: the streams' bases)
                 float *out = g.mapped ? nullptr : g.out + so * g.ch * g.N, *state = p.state.empty() ? nullptr : p.state.data();
                 if (g.symbols) {
-                    rc = packedRecords_ ? nyq_celt_symbols_packed_to_pcm_mapped(ctx, in, g.off + p.k0 * (g.maxF + 1) + f0, g.maxF * g.frameBytes,
+                    rc = packedRecords_ ? nyq_celt_symbols_packed_to_pcm_mapped(ctx, g.LM, in, g.off + p.k0 * (g.maxF + 1) + f0, g.maxF * g.frameBytes,
                                                                                 g.tr + so, g.pp + so, g.pg + so, g.pt + so, out,
                                                                                 g.mapped ? desc.data() : nullptr, state, p.k1 - p.k0, len, g.ch, g.maxF)
-                                        : nyq_celt_symbols_to_pcm_mapped(ctx, g.in + so * g.frameBytes, g.tr + so, g.pp + so, g.pg + so, g.pt + so, out,
+                                        : nyq_celt_symbols_to_pcm_mapped(ctx, g.LM, g.in + so * g.frameBytes, g.tr + so, g.pp + so, g.pg + so, g.pt + so, out,
                                                                          g.mapped ? desc.data() : nullptr, state, p.k1 - p.k0, len, g.ch, g.maxF);
                 } else if (g.mapped) {
                     rc = nyq_celt_frames_to_pcm_mapped(ctx, g.LM, reinterpret_cast<const float *>(in), g.tr + so, g.pp + so, g.pg + so, g.pt + so,
@@ -787,7 +787,7 @@ private:
             if ((size_t)s.plan[0].nframes != g.maxF) {
                 std::vector<float> out1((size_t)s.plan[0].nframes * g.N * g.ch);
                 const size_t nf0 = (size_t)s.plan[0].nframes;
-                if ((g.symbols ? nyq_celt_symbols_packed_to_pcm_mapped(ctx, s.in0, s.off0, 0, s.tr0, s.pp0, s.pg0, s.pt0, out1.data(), nullptr,
+                if ((g.symbols ? nyq_celt_symbols_packed_to_pcm_mapped(ctx, g.LM, s.in0, s.off0, 0, s.tr0, s.pp0, s.pg0, s.pt0, out1.data(), nullptr,
                                                                        st1.data(), 1, nf0, g.ch, g.maxF)
                                : nyq_celt_frames_to_pcm(ctx, g.LM, reinterpret_cast<const float *>(s.in0), s.tr0, s.pp0, s.pg0, s.pt0, out1.data(),
                                                         st1.data(), 1, nf0, g.ch)) != NYQ_OK)
@@ -1085,7 +1085,7 @@ void BatchOpusDecoder::decodeImpl(const std::vector<const std::vector<uint8_t> *
             size_t bytes = 0;
             for (const auto &kv : shape) {
                 const size_t pcm = (size_t)kv.first.first * ((size_t)120 << kv.first.second) * sizeof(float);
-                const size_t in = symbolRecords_ && kv.first.second == 3 && kv.first.first <= 2 ? nyq_celt_symbol_bytes(kv.first.first) : pcm;
+                const size_t in = symbolRecords_ && kv.first.first <= 2 ? nyq_celt_symbol_bytes_lm(kv.first.first, kv.first.second) : pcm;
                 bytes += kv.second.first * kv.second.second * (in + pcm);
             }
             return bytes;

@@ -1052,10 +1052,16 @@ static_assert(sizeof(CeltDecoder::Scratch::LeafSlot) == sizeof(nyq_sym_leaf) && 
 static_assert(sizeof(CeltDecoder::Scratch::ops) / sizeof(nyq_sym_op) == NYQ_SYM_MAX_OPS && sizeof(CeltDecoder::Scratch::vecs) / sizeof(nyq_sym_vec) == NYQ_SYM_MAX_VECS, "record capacity");
 }  // namespace
 
-size_t CeltDecoder::symbolBytes(int channels) { return kSymSlotFixed + (size_t)channels * 960 * sizeof(float); }
+// (= nyq_celt_symbol_bytes_lm: an eighth of the 20 ms slot per LM step, never less than the fixed parts plus a leaf per vector)
+size_t CeltDecoder::symbolBytes(int channels, int LM) {
+    const size_t full = kSymSlotFixed + (size_t)channels * 960 * sizeof(float);
+    const size_t floor_ = LM == 3 ? 0 : (size_t)2048 * (size_t)channels + 512;
+    const size_t scaled = LM == 3 ? full : LM == 2 ? full * 5 / 8 : full >> (3 - LM);
+    return (std::max(scaled, floor_) + 15) & ~(size_t)15;
+}
 
 int CeltDecoder::decodeSymbols(const uint8_t *data, int len, int frameSize, void *record, CeltFrame &info) {
-    if (!record || frameSize != 960) return -1;
+    if (!record) return -1;
     uint8_t *r = static_cast<uint8_t *>(record);
     return decodeFrame(data, len, frameSize, reinterpret_cast<float *>(r + kSymFreqOff), r, info);
 }
@@ -1206,7 +1212,7 @@ int CeltDecoder::decodeFrame(const uint8_t *data, int len, int frameSize, float 
     // (room in the slot; 192 leaves is what the device stages)
     const size_t symBytes = kSymOpsOff + sizeof(nyq_sym_op) * (size_t)scratch_.nops + sizeof(nyq_sym_vec) * (size_t)scratch_.nvecs +
                             sizeof(nyq_sym_leaf) * (size_t)scratch_.nleaves + (antiCollapseOn ? 2 * kBands * sizeof(float) : 0);
-    const bool asSymbols = record && !silence && LM == 3 && scratch_.nleaves <= 192 && symBytes <= symbolBytes(CC);
+    const bool asSymbols = record && !silence && scratch_.nleaves <= 192 && symBytes <= symbolBytes(CC, LM);
     if (!asSymbols) {
         std::memset(X, 0, sizeof(float) * (size_t)C * N);
         shaper.resolve(masks);                                            // phase 1b: pulse vectors, collapse masks, fill decisions

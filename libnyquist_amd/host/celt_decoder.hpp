@@ -37,12 +37,11 @@ public:
     // freq: channels() * frameSize floats, channel-major (celt_decoder_clean.c:620-652).
     // Returns 0, or a negative OPUS_* style code (-1 bad arg, -3 internal, -4 corrupt).
     int decode(const uint8_t *data, int len, int frameSize, float *freq, CeltFrame &info);
-    // The same frame as a SYMBOL record for the GPU (include/nyq_imdct.h: nyq_celt_symbol_bytes(channels()) bytes, 20 ms
-    // frames): the bit-serial work only -- the band shapes are built from the record by nyq_celt_shape_dev.  Frames the
-    // record cannot carry (anti-collapse, a channel count that differs from the decoder's, an overlong leaf list) are
-    // finished here and travel as freq[] inside the record (NYQ_SYM_HOST_FREQ).
+    // The same frame as a SYMBOL record for the GPU (include/nyq_imdct.h: at most symbolBytes(channels(), LM) bytes): the
+    // bit-serial work only -- the band shapes are built from the record by nyq_celt_shape_dev.  A frame whose record would
+    // not fit its slot (an overlong leaf list) is finished here and travels as freq[] inside the record (NYQ_SYM_HOST_FREQ).
     int decodeSymbols(const uint8_t *data, int len, int frameSize, void *record, CeltFrame &info);
-    static size_t symbolBytes(int channels);        // = nyq_celt_symbol_bytes (computed here: the entropy stage needs no GPU library)
+    static size_t symbolBytes(int channels, int LM = 3);   // = nyq_celt_symbol_bytes_lm (computed here: the entropy stage needs no GPU library)
     int channels() const { return channels_; }
 
     // Working memory of a frame, owned by the decoder (no allocation on the decode path): the normalised coefficients of

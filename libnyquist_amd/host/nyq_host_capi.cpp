@@ -87,9 +87,10 @@ done:
 }
 
 // The same walk with the entropy stage stopping at the SYMBOLS (CeltDecoder::decodeSymbols): records[max_frames] of
-// nyqh_symbol_bytes(channels) bytes each; the dump ends at the first frame that is not 20 ms (-12 if the very first); info[6] = frames that carry host-built freq[]
+// nyqh_symbol_bytes_lm(channels, LM of the first frame) bytes each; the dump ends at the first frame of another size; info[6] = frames that carry host-built freq[]
 // (NYQ_SYM_HOST_FREQ) instead of symbols.  A test hook: the GPU's band shapes against decode()'s.
 long nyqh_symbol_bytes(int channels) { return (long)CeltDecoder::symbolBytes(channels); }
+long nyqh_symbol_bytes_lm(int channels, int LM) { return (long)CeltDecoder::symbolBytes(channels, LM); }
 // offsets16 != NULL: the records are written PACKED back to back (frame i at records + 16 * offsets16[i], max_frames + 1
 // entries; `records` must hold max_frames slots all the same); NULL: one record per slot
 int nyqh_decode_to_symbols_packed(const unsigned char *file, long size, long max_frames, unsigned char *records, unsigned *offsets16,
@@ -108,17 +109,20 @@ int nyqh_decode_to_symbols_packed(const unsigned char *file, long size, long max
     }
     if (f.head.mappingFamily != 0 || f.head.channels < 1 || f.head.channels > 2) return -11;
     const int CC = f.head.channels;
-    const size_t rec = CeltDecoder::symbolBytes(CC);
+    size_t rec = 0;
+    int frameSize = 0, LM = 0;
     CeltDecoder dec(CC);
     long nframes = 0, hostBuilt = 0;
     for (const auto &pkt : f.packets) {
         PacketFrames pf;
         if (!parseOpusPacket(pkt.data(), (int)pkt.size(), pf)) return -10;
         if (pf.config < 16) return -11;
-        if (pf.frameSize != 960) {
-            if (nframes == 0) return -12;
-            goto done;                                   // a different frame size ends this fixed-shape dump
+        if (frameSize == 0) {
+            frameSize = pf.frameSize;
+            for (LM = 0; (120 << LM) != frameSize; LM++) {}
+            rec = CeltDecoder::symbolBytes(CC, LM);
         }
+        if (pf.frameSize != frameSize) goto done;        // a different frame size ends this fixed-shape dump
         dec.setEndBand(pf.bandwidthEnd);
         dec.setStreamChannels(pf.stereo ? 2 : 1);
         for (const auto &fr : pf.frames) {
@@ -143,10 +147,11 @@ done:
     info[0] = CC;
     info[1] = f.head.preSkip;
     info[2] = nframes;
-    info[3] = 960;
+    info[3] = frameSize;
     info[4] = (long)f.lastGranule;
     info[5] = (long)f.packets.size();
     info[6] = hostBuilt;
+    info[7] = (long)rec;
     return 0;
 }
 

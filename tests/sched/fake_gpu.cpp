@@ -122,12 +122,18 @@ int nyq_celt_frames_to_pcm_mapped(nyq_ctx *ctx, int LM, const float *freq, const
 // leaves, or the host-built freq[]) spread over a freq[] buffer, which then goes through the call above -- so a record that is
 // stale, misplaced or half written changes the output.  (Bytes the entropy stage leaves undefined -- unused slots -- are not
 // read, as the real kernel does not read them.)
-size_t nyq_celt_symbol_bytes(int channels) { return channels == 1 || channels == 2 ? (size_t)3072 + (size_t)channels * 3840 : 0; }
-int nyq_celt_symbols_packed_to_pcm_mapped(nyq_ctx *ctx, const void *sym, const unsigned int *offsets, size_t stream_bytes,
+size_t nyq_celt_symbol_bytes_lm(int channels, int LM) {
+    if ((channels != 1 && channels != 2) || LM < 0 || LM > 3) return 0;
+    const size_t full = (size_t)3072 + (size_t)channels * 3840, floor_ = LM == 3 ? 0 : (size_t)2048 * channels + 512;
+    const size_t scaled = LM == 3 ? full : LM == 2 ? full * 5 / 8 : full >> (3 - LM);
+    return ((scaled > floor_ ? scaled : floor_) + 15) & ~(size_t)15;
+}
+size_t nyq_celt_symbol_bytes(int channels) { return nyq_celt_symbol_bytes_lm(channels, 3); }
+int nyq_celt_symbols_packed_to_pcm_mapped(nyq_ctx *ctx, int LM, const void *sym, const unsigned int *offsets, size_t stream_bytes,
                                           const unsigned char *transient, const int *pf_pitch, const float *pf_gain, const int *pf_tapset,
                                           float *out, const nyq_out_desc *desc, float *state, size_t nstreams, size_t nframes, int channels,
                                           size_t frames_per_stream) {
-    const size_t rec = nyq_celt_symbol_bytes(channels), per = (size_t)channels * 960;
+    const size_t rec = nyq_celt_symbol_bytes_lm(channels, LM), per = (size_t)channels * ((size_t)120 << LM);
     float *freq = (float *)std::malloc(sizeof(float) * nstreams * frames_per_stream * per);
     for (size_t s = 0; s < nstreams; s++)
         for (size_t f = 0; f < nframes; f++) {
@@ -150,15 +156,15 @@ int nyq_celt_symbols_packed_to_pcm_mapped(nyq_ctx *ctx, const void *sym, const u
             }
             for (size_t k = 0; k < per; k++) x[k] = H->nops ? (float)((h >> (k % 13)) & 0xff) * (1.f / 64) : 0.f;
         }
-    const int rc = nyq_celt_frames_to_pcm_mapped(ctx, 3, freq, transient, pf_pitch, pf_gain, pf_tapset, out, desc, state, nstreams, nframes,
+    const int rc = nyq_celt_frames_to_pcm_mapped(ctx, LM, freq, transient, pf_pitch, pf_gain, pf_tapset, out, desc, state, nstreams, nframes,
                                                  channels, frames_per_stream);
     std::free(freq);
     return rc;
 }
-int nyq_celt_symbols_to_pcm_mapped(nyq_ctx *ctx, const void *sym, const unsigned char *transient, const int *pf_pitch, const float *pf_gain,
+int nyq_celt_symbols_to_pcm_mapped(nyq_ctx *ctx, int LM, const void *sym, const unsigned char *transient, const int *pf_pitch, const float *pf_gain,
                                    const int *pf_tapset, float *out, const nyq_out_desc *desc, float *state, size_t nstreams, size_t nframes,
                                    int channels, size_t frames_per_stream) {
-    return nyq_celt_symbols_packed_to_pcm_mapped(ctx, sym, nullptr, 0, transient, pf_pitch, pf_gain, pf_tapset, out, desc, state, nstreams,
+    return nyq_celt_symbols_packed_to_pcm_mapped(ctx, LM, sym, nullptr, 0, transient, pf_pitch, pf_gain, pf_tapset, out, desc, state, nstreams,
                                                  nframes, channels, frames_per_stream);
 }
 

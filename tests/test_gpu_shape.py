@@ -1,7 +1,8 @@
-"""GPU tier: the band shapes of 20 ms CELT frames built ON THE DEVICE from symbol records (nyq_celt_shape_dev,
+"""GPU tier: the band shapes of CELT frames built ON THE DEVICE from symbol records (nyq_celt_shape_lm_dev,
 nyq_shape_kernel.hpp) against the host entropy stage's own freq[] (CeltDecoder::decode -- itself pinned to the reference
-decoder by tests/test_opus_corpus.py and tests/test_host_decoder.py on the CPU tier): every 20 ms file of the corpus and
-the two bundled files, every frame; then the whole way to PCM (nyq_celt_symbols_to_pcm_mapped) against the freq[] path."""
+decoder by tests/test_opus_corpus.py and tests/test_host_decoder.py on the CPU tier): every one-stream file of the corpus
+(2.5 / 5 / 10 / 20 ms frames) and the two bundled files, every frame; then the whole way to PCM
+(nyq_celt_symbols_to_pcm_mapped) against the freq[] path."""
 import ctypes as C
 import glob
 import os
@@ -14,7 +15,8 @@ from test_host_decoder import entropy_decode, load_host
 
 pytestmark = pytest.mark.gpu
 
-FILES = sorted(p for p in glob.glob(os.path.join(GOLDEN, "corpus", "*20ms*.opus")) if "surround" not in p) + \
+FILES = sorted(p for p in glob.glob(os.path.join(GOLDEN, "corpus", "*.opus"))
+               if not os.path.basename(p).startswith(("surround", "unsupported_"))) + \
     [os.path.join(GOLDEN, "short.opus"), os.path.join(GOLDEN, "sb-reverie.opus")]
 
 
@@ -23,6 +25,8 @@ def host():
     H = load_host()
     H.nyqh_symbol_bytes.argtypes = [C.c_int]
     H.nyqh_symbol_bytes.restype = C.c_long
+    H.nyqh_symbol_bytes_lm.argtypes = [C.c_int, C.c_int]
+    H.nyqh_symbol_bytes_lm.restype = C.c_long
     u8 = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
     H.nyqh_decode_to_symbols.argtypes = [C.c_char_p, C.c_long, C.c_long, u8] + list(H.nyqh_decode_to_freq.argtypes[4:])
     return H
@@ -36,8 +40,8 @@ def ctx():
     c.close()
 
 
-def symbols(H, raw, max_frames, channels):
-    rec = H.nyqh_symbol_bytes(channels)
+def symbols(H, raw, max_frames, channels, lm=3):
+    rec = H.nyqh_symbol_bytes_lm(channels, lm)
     sym = np.zeros((max_frames, rec), np.uint8)
     flags = np.zeros((max_frames, 4), np.int32)
     gain = np.zeros(max_frames, np.float32)
@@ -76,21 +80,26 @@ def test_packed_records_equal_slotted_records(host, ctx):
 def test_record_size_is_one_number_on_both_sides(host, ctx):
     for ch in (1, 2):
         assert host.nyqh_symbol_bytes(ch) == ctx.lib.nyq_celt_symbol_bytes(ch) == 3072 + ch * 3840
-    assert ctx.lib.nyq_celt_symbol_bytes(3) == 0
+        for lm in range(4):
+            n = host.nyqh_symbol_bytes_lm(ch, lm)
+            assert n == ctx.lib.nyq_celt_symbol_bytes_lm(ch, lm) and n % 16 == 0 and n >= 32 + ch * (120 << lm) * 4
+    assert ctx.lib.nyq_celt_symbol_bytes(3) == 0 and ctx.lib.nyq_celt_symbol_bytes_lm(2, 4) == 0
 
 
 @pytest.mark.parametrize("path", FILES, ids=lambda p: os.path.basename(p)[:-5])
 def test_device_band_shapes_equal_the_host_entropy_stage(host, ctx, path):
     import torch
     raw = open(path, "rb").read()
-    cap = 12000
-    rc, freq, flags, gain, rng, info = entropy_decode(host, raw, max_frames=cap, channels=2, n=960)
+    rc, _, _, _, _, info = entropy_decode(host, raw, max_frames=4, channels=2, n=960)     # (first: the file's shape)
     assert rc == 0
-    ch, nf = int(info[0]), int(info[2])
-    if ch == 1:                                               # (entropy_decode's buffer was shaped for two channels)
-        rc, freq, flags, gain, rng, info = entropy_decode(host, raw, max_frames=cap, channels=1, n=960)
+    ch, n = int(info[0]), int(info[3])
+    lm = {120: 0, 240: 1, 480: 2, 960: 3}[n]
+    cap = 12000 if "reverie" in path else 4200
+    rc, freq, flags, gain, rng, info = entropy_decode(host, raw, max_frames=cap, channels=ch, n=n)
+    assert rc == 0
+    nf = int(info[2])
     freq = freq[:nf]
-    rc, sym, flags2, gain2, rng2, info2 = symbols(host, raw, cap, ch)
+    rc, sym, flags2, gain2, rng2, info2 = symbols(host, raw, cap, ch, lm)
     assert rc == 0 and int(info2[2]) == nf
     assert np.array_equal(rng[:nf], rng2[:nf]) and np.array_equal(flags[:nf], flags2[:nf])
     host_built = int(info2[6])
@@ -100,9 +109,9 @@ def test_device_band_shapes_equal_the_host_entropy_stage(host, ctx, path):
         assert host_built <= nf // 20                         # music: a few percent
     dev = torch.device("cuda", 0)
     d_sym = torch.from_numpy(sym[:nf]).to(dev)
-    d_freq = torch.full((nf, ch, 960), float("nan"), device=dev)
+    d_freq = torch.full((nf, ch, n), float("nan"), device=dev)
     torch.cuda.synchronize(dev)
-    ctx.celt_shape_dev(d_sym.data_ptr(), d_freq.data_ptr(), 1, nf, ch)
+    ctx.celt_shape_dev(d_sym.data_ptr(), d_freq.data_ptr(), 1, nf, ch, lm=lm)
     ctx.synchronize()
     got = d_freq.cpu().numpy()
     assert np.isfinite(got).all()
