@@ -6,10 +6,13 @@
 //     band widths, the eleven allocation rows already scaled to 1/8 bits, thresholds, trim slopes, caps;
 //   * BitPlan    -- the frame's bit allocation from those tables (rows bisection, interpolation, band skipping,
 //     PVQ / fine-energy split), no per-band recomputation of mode arithmetic;
-//   * BandShaper -- a band's shape in TWO phases: the split tree is walked with an explicit stack (no recursion) reading
-//     angles and pulse vectors into a flat list of leaves (integers only), then the leaves are turned into
-//     coefficients by the vector kernels of celt_synth.hpp (spreading rotations of sibling leaves run in lockstep);
-//     the fold source is prepared lazily, only when some leaf of the band actually folds;
+//   * BandShaper -- a frame's band shapes in THREE phases.  1, symbols: every split tree is walked with an explicit stack (no
+//     recursion) reading angles and the CODEWORDS of the pulse vectors into a flat program (vectors / leaves / operations,
+//     integers only); the fill masks, which depend on pulse vectors not yet unranked, are carried as their images under each
+//     input bit.  1b, resolve(): pulse vectors from their codewords, collapse masks, what becomes of the leaves without pulses.
+//     2, build(): the program's floats by the vector kernels of celt_synth.hpp (spreading rotations of sibling leaves in
+//     lockstep; the fold source is prepared lazily).  decodeSymbols() stops after phase 1 and packs the program into a symbol
+//     record (include/nyq_imdct.h): phases 1b and 2 then run on the GPU (csrc/nyq_shape_kernel.hpp);
 //   * pulse vectors are unranked on 32-bit rows of the U(n, k) table;
 //   * all working memory lives in the decoder object (no heap traffic per frame).
 // Reference line numbers (third_party/opus/celt/) mark the clauses of the reference a block answers to.
