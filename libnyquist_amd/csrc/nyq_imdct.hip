@@ -851,6 +851,7 @@ static int shape_core(nyq_ctx *ctx, const void *d_sym, float *d_freq, size_t nst
     if (!ctx->d_pvq) {
         std::vector<unsigned> table((size_t)kPvqInfo + kPvqWords);
         if (pvq_table_build(table.data()) != kPvqWords) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_shape_dev: pulse-vector table has an unexpected size");
+        table.push_back(0);                                          // (behind the table: the launch's frame counter)
         NYQ_HIP(ctx, hipMalloc(&ctx->d_pvq, table.size() * sizeof(unsigned)));
         NYQ_HIP(ctx, hipMemcpy(ctx->d_pvq, table.data(), table.size() * sizeof(unsigned), hipMemcpyHostToDevice));
     }
@@ -858,8 +859,19 @@ static int shape_core(nyq_ctx *ctx, const void *d_sym, float *d_freq, size_t nst
     // is staged into LDS once per workgroup
     const size_t want = (total + kShapeWaves - 1) / kShapeWaves, resident = (size_t)ctx->cus;
     const unsigned grid = (unsigned)(want < resident ? want : resident);
-    hipLaunchKernelGGL(celt_shape_kernel, dim3(grid), dim3(kWave * kShapeWaves), 0, ctx->stream, static_cast<const unsigned char *>(d_sym), d_freq,
-                       ctx->d_pvq, (long)nstreams, (long)nframes, channels, (long)sstride, (long)fstride, d_off, (long)(ostride ? ostride : nframes), LM);
+    unsigned *d_next = ctx->d_pvq + kPvqInfo + kPvqWords;            // launches of one context are ordered on its stream
+    NYQ_HIP(ctx, hipMemsetAsync(d_next, 0, sizeof(unsigned), ctx->stream));
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kWave * kShapeWaves), 0, ctx->stream, static_cast<const unsigned char *>(d_sym), d_freq,
+                           ctx->d_pvq, (long)nstreams, (long)nframes, channels, (long)sstride, (long)fstride, d_off, (long)(ostride ? ostride : nframes),
+                           d_next);
+    };
+    switch (LM) {
+    case 0: launch(celt_shape_kernel<0>); break;
+    case 1: launch(celt_shape_kernel<1>); break;
+    case 2: launch(celt_shape_kernel<2>); break;
+    default: launch(celt_shape_kernel<3>); break;
+    }
     NYQ_HIP(ctx, hipGetLastError());
     return NYQ_OK;
 }

@@ -306,7 +306,8 @@ __device__ __forceinline__ void shape_vector(const ShapeFrame &F, const SymVec v
 #pragma clang fp contract(off)
     if (v.n < 2 || v.n > 176 || v.x < 0 || v.x + v.n > 2 * kSymN || v.recombine > 3 || v.time_divide > 3 || v.b_tree < 1 || v.b_tree > 16 ||
         v.b_in < 1 || v.b_in > 8 || v.leaf0 < 0 || v.leaf1 < v.leaf0 || v.leaf1 - v.leaf0 > 16 || v.leaf1 > kSymMaxLeaves || v.band > 20 ||
-        v.fill_hi > 21 || v.fold + v.n > kShapeNorm / 2 || v.out + v.n > kShapeNorm / 2)
+        v.fill_hi > 21 || v.fold + v.n > kShapeNorm / 2 || v.out + v.n > kShapeNorm / 2 || (int)v.nb_tree * (int)v.b_tree != (int)v.n ||
+        v.n % v.b_in != 0 || (v.b_in >> v.recombine) < 1 || ((int)v.b_tree << v.recombine) > 16)
         return;                                                      // (not a vector the entropy stage can have written)
     float *x = X + v.x;
     const int n = v.n, recombine = v.recombine, timeDivide = v.time_divide, Btree = v.b_tree;
@@ -446,9 +447,8 @@ __device__ __forceinline__ int shape_edge(int i, int LM) {
 constexpr int kShapeWaves = NYQ_SHAPE_WAVES;                         // frames side by side in a workgroup (they share the table)
 struct ShapeWaveLds {
     float f[kShapeLdsFloats];                                        // X | fold memory | two work vectors
-    SymLeaf leaves[kSymMaxLeaves];                                   // the frame's record, staged
-    SymOp ops[kSymMaxOps];
-    SymVec vecs[kSymMaxVecs];
+    // the frame's operations, vectors and leaves, staged as they lie in the record (one contiguous range)
+    unsigned rec[(kSymMaxOps * sizeof(SymOp) + kSymMaxVecs * sizeof(SymVec) + kSymMaxLeaves * sizeof(SymLeaf)) / 4];
     unsigned short leafCm[kSymMaxLeaves];
     unsigned char masks[2 * 21 + 6];
 };
@@ -460,10 +460,12 @@ __device__ __forceinline__ void stage_words(void *dst, const void *src, int byte
     for (int w = lane; w < bytes / 4; w += kWave) d[w] = s[w];
 }
 
+template <int LM>   // frames of 120 << LM samples (an instance per size: band edges, block counts and strides are constants)
 __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const unsigned char *__restrict__ sym, float *__restrict__ freq,
                                                                         const unsigned *__restrict__ pvq, long nstreams, long nframes,
                                                                         int channels, long sstride, long fstride,
-                                                                        const unsigned *__restrict__ offsets, long ostride, int LM) {
+                                                                        const unsigned *__restrict__ offsets, long ostride,
+                                                                        unsigned *__restrict__ next_frame) {
 #pragma clang fp contract(off)
     __shared__ __attribute__((aligned(16))) ShapeWaveLds wl[kShapeWaves];
     __shared__ unsigned tab[kPvqInfo + kPvqWords];
@@ -473,9 +475,16 @@ __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const un
     ShapeWaveLds &L = wl[wv];
     float *X = L.f, *norm = L.f + 2 * kSymN, *work = norm + kShapeNorm, *tmp = work + 192;
     const size_t rec = sym_bytes(channels, LM);
-    const int N = 120 << LM;                                         // bins per channel
+    constexpr int N = 120 << LM;                                     // bins per channel
     const long total = nstreams * nframes;
-    for (long u = (long)blockIdx.x * kShapeWaves + wv; u < total; u += (long)gridDim.x * kShapeWaves) {
+    // Frames are handed out by a counter (zeroed before the launch), not dealt in advance: a transient frame costs several
+    // times a plain one, and a wave that drew three of them would be what the launch waits for.  Every wave leaves the
+    // loop at the first index beyond the last frame.
+    for (;;) {
+        unsigned fetched = 0;
+        if (lane == 0) fetched = atomicAdd(next_frame, 1u);
+        const long u = (long)__builtin_amdgcn_readfirstlane(fetched);
+        if (u >= total) break;
         const long s = u / nframes, f = u - s * nframes;
         // where the frame's record is: packed back to back inside its stream's region (offsets[stream * ostride + frame], 16-byte
         // units from the region's start) or in slots of sym_bytes; a stream's region is sstride slots long either way
@@ -505,24 +514,26 @@ __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const un
         const int nops = H.nops < kSymMaxOps ? H.nops : kSymMaxOps, nvecs = H.nvecs < kSymMaxVecs ? H.nvecs : kSymMaxVecs;
         const float laneGain = lane < 2 * 21 ? reinterpret_cast<const float *>(r + 32)[lane] : 0.f;   // lane c * 21 + band
         NYQ_WAVE_SYNC();                                             // (the previous frame's last reads of this slice)
-        // (the record's own counts place its parts; the clamped ones bound what is staged)
-        const unsigned char *rvecs = r + kSymOpsOff + (size_t)H.nops * sizeof(SymOp), *rleaves = rvecs + (size_t)H.nvecs * sizeof(SymVec);
-        stage_words(L.ops, r + kSymOpsOff, nops * (int)sizeof(SymOp), lane);
-        stage_words(L.vecs, rvecs, nvecs * (int)sizeof(SymVec), lane);
-        stage_words(L.leaves, rleaves, nleaves * (int)sizeof(SymLeaf), lane);
+        // (the counts were checked against their bounds above: the three parts are one contiguous range of the record)
+        const int bops = nops * (int)sizeof(SymOp), bvecs = nvecs * (int)sizeof(SymVec), bleaves = nleaves * (int)sizeof(SymLeaf);
+        const unsigned char *rleaves = r + kSymOpsOff + bops + bvecs;
+        stage_words(L.rec, r + kSymOpsOff, bops + bvecs + bleaves, lane);
+        const SymOp *Lops = reinterpret_cast<const SymOp *>(L.rec);
+        const SymVec *Lvecs = reinterpret_cast<const SymVec *>(L.rec + bops / 4);
+        const SymLeaf *Lleaves = reinterpret_cast<const SymLeaf *>(L.rec + (bops + bvecs) / 4);
         if (lane < 2 * 21) L.masks[lane] = 0;
         NYQ_WAVE_SYNC();
         ShapeFrame F;
-        F.ops = L.ops;
-        F.vecs = L.vecs;
-        F.leaves = L.leaves;
+        F.ops = Lops;
+        F.vecs = Lvecs;
+        F.leaves = Lleaves;
         F.leafCm = L.leafCm;
         F.masks = L.masks;
         float *norm2 = norm + (shape_edge(20, LM) - shape_edge(H.start, LM));
         unsigned seed = H.seed;
         // pass A: every pulse leaf of the frame, a leaf per lane
         for (int l = lane; l < nleaves && !NYQ_SHAPE_DBG_NO_A; l += kWave) {
-            const SymLeaf &lf = L.leaves[l];
+            const SymLeaf &lf = Lleaves[l];
             if (lf.kind != 0) continue;
             // (records come from the host's entropy stage; a damaged one must still leave every loop of this kernel bounded:
             // a leaf that cannot be a leaf is skipped)

@@ -146,7 +146,10 @@ def test_damaged_records_leave_the_kernel_bounded(host, ctx):
     rc, sym, flags, gain, rng, info = symbols(host, raw, 400, 2)
     nf = int(info[2])
     assert rc == 0 and nf == 220
-    good = sym[:nf].copy()
+    # 32 copies of the stream in one launch: 7040 frames over the resident grid, so every wave goes through several frames,
+    # damaged ones and sound ones in turn (what a damaged frame leaves behind in its wave's working set must not matter)
+    good = np.tile(sym[:nf], (32, 1))
+    nf *= 32
     bad = good.copy()
     r = np.random.default_rng(5)
     for f in range(0, nf, 2):                                  # every other frame damaged, the others as decoded
@@ -156,7 +159,7 @@ def test_damaged_records_leave_the_kernel_bounded(host, ctx):
         if f % 8 == 0:
             bad[f, 200:3072] = r.integers(0, 256, 2872, dtype=np.uint8)          # operations and vectors: noise
         if f % 8 == 4:
-            bad[f, 3072:3072 + 4000] = r.integers(0, 256, 4000, dtype=np.uint8)  # leaves: noise
+            bad[f, 3072:3072 + 4000] = r.integers(0, 256, 4000, dtype=np.uint8)  # further in: noise
     dev = torch.device("cuda", 0)
     d_good, d_bad = torch.from_numpy(good).to(dev), torch.from_numpy(bad).to(dev)
     want = torch.zeros((nf, 2, 960), device=dev)
