@@ -304,11 +304,6 @@ struct ShapeFrame {                  // (all in the wave's LDS slice)
 __device__ __forceinline__ void shape_vector(const ShapeFrame &F, const SymVec v, float *X, float *norm, float *norm2, float *work,
                                              float *tmp, unsigned &seed, int lane) {
 #pragma clang fp contract(off)
-    if (v.n < 2 || v.n > 176 || v.x < 0 || v.x + v.n > 2 * kSymN || v.recombine > 3 || v.time_divide > 3 || v.b_tree < 1 || v.b_tree > 16 ||
-        v.b_in < 1 || v.b_in > 8 || v.leaf0 < 0 || v.leaf1 < v.leaf0 || v.leaf1 - v.leaf0 > 16 || v.leaf1 > kSymMaxLeaves || v.band > 20 ||
-        v.fill_hi > 21 || v.fold + v.n > kShapeNorm / 2 || v.out + v.n > kShapeNorm / 2 || (int)v.nb_tree * (int)v.b_tree != (int)v.n ||
-        v.n % v.b_in != 0 || (v.b_in >> v.recombine) < 1 || ((int)v.b_tree << v.recombine) > 16)
-        return;                                                      // (not a vector the entropy stage can have written)
     float *x = X + v.x;
     const int n = v.n, recombine = v.recombine, timeDivide = v.time_divide, Btree = v.b_tree;
     const bool longBlocks = v.b_in == 1;
@@ -327,11 +322,7 @@ __device__ __forceinline__ void shape_vector(const ShapeFrame &F, const SymVec v
     for (int l = v.leaf0; l < v.leaf1; l++) {
         const SymLeaf &lf = F.leaves[l];
         unsigned lcm, kind = 0;
-        const bool sane = lf.off >= 0 && lf.n >= 1 && lf.off + lf.n <= n && lf.fold_off + lf.n <= n && lf.blocks >= 1 && lf.blocks <= 16 &&
-                          lf.shift <= 15;
-        if (!sane) {
-            lcm = 0;                                                 // (a damaged record: the leaf is left alone)
-        } else if (lf.kind == 0) {
+        if (lf.kind == 0) {
             lcm = F.leafCm[l];
         } else {
             unsigned fill = 0;
@@ -531,16 +522,58 @@ __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const un
         F.masks = L.masks;
         float *norm2 = norm + (shape_edge(20, LM) - shape_edge(H.start, LM));
         unsigned seed = H.seed;
+        // Validation, a record per lane.  The records come from this project's own entropy stage, but the ABI takes them from
+        // any caller: every offset and count the passes below use is checked here against its bound, once and in parallel; a
+        // frame with one record that cannot be is played as silence (no loop below is unbounded, no write leaves the wave's
+        // own working set, whatever the bytes).
+        {
+            bool bad = false;
+            for (int l = lane; l < nleaves; l += kWave) {
+                const SymLeaf &lf = Lleaves[l];
+                bad |= lf.n < 1 || lf.n > 176 || lf.off < 0 || lf.off + lf.n > 176 || lf.blocks < 1 || lf.blocks > 16 || lf.shift > 15 ||
+                       lf.abs < 0 || lf.abs + lf.n > 2 * N || lf.fold_off + lf.n > 176 || lf.kind > 1 ||
+                       (lf.kind == 0 && (lf.n < 2 || lf.k < 1 || lf.k > 176 || lf.n % lf.blocks != 0));
+            }
+            for (int q = lane; q < nvecs; q += kWave) {
+                const SymVec &v = Lvecs[q];
+                bool vb = v.n < 2 || v.n > 176 || v.x < 0 || v.x + v.n > 2 * N || v.recombine > 3 || v.time_divide > 3 || v.b_tree < 1 ||
+                          v.b_tree > 16 || v.b_in < 1 || v.b_in > 8 || v.leaf0 < 0 || v.leaf1 < v.leaf0 || v.leaf1 - v.leaf0 > 16 ||
+                          v.leaf1 > nleaves || v.band > 20 || v.fill_lo > v.fill_hi || v.fill_hi > 21 || v.fill_mode > 3 || v.sel > 1 ||
+                          v.fold + v.n > kShapeNorm / 2 || v.out + v.n > kShapeNorm / 2 || (int)v.nb_tree * (int)v.b_tree != (int)v.n ||
+                          v.n % v.b_in != 0 || (v.b_in >> v.recombine) < 1 || ((int)v.b_tree << v.recombine) > 16;
+                if (!vb)
+                    for (int l = v.leaf0; l < v.leaf1; l++) {        // its leaves lie inside it
+                        const SymLeaf &lf = Lleaves[l];
+                        vb |= lf.off + lf.n > v.n || lf.fold_off + lf.n > v.n || lf.abs != v.x + lf.off;
+                    }
+                bad |= vb;
+            }
+            for (int q = lane; q < nops; q += kWave) {
+                const SymOp &o = Lops[q];
+                bool ob;
+                switch (o.kind) {
+                case 0: ob = o.a < 0 || o.a >= nvecs; break;
+                case 1: ob = o.a < 0 || o.a >= 2 * N || o.b >= kShapeNorm / 2 || o.band > 20; break;
+                case 2: ob = o.a < 0 || o.b < 0 || o.a + 2 > 2 * N || o.b + 2 > 2 * N; break;
+                case 3: ob = o.a < 0 || o.b < 0 || o.n < 0 || o.a + o.n > 2 * N || o.b + o.n > 2 * N; break;
+                case 4: ob = o.a < 0 || o.n < 0 || o.a + o.n > 2 * N; break;
+                case 5: ob = o.a < 0 || o.a > kShapeNorm / 2; break;
+                default: ob = true; break;
+                }
+                bad |= ob;
+            }
+            if (__any(bad)) {
+                float4 *o4 = reinterpret_cast<float4 *>(out);
+                for (int j = lane; j < CC * N / 4; j += kWave) o4[j] = float4{0.f, 0.f, 0.f, 0.f};
+                continue;
+            }
+        }
         // pass A: every pulse leaf of the frame, a leaf per lane
         for (int l = lane; l < nleaves && !NYQ_SHAPE_DBG_NO_A; l += kWave) {
             const SymLeaf &lf = Lleaves[l];
             if (lf.kind != 0) continue;
-            // (records come from the host's entropy stage; a damaged one must still leave every loop of this kernel bounded:
-            // a leaf that cannot be a leaf is skipped)
-            const bool sane = lf.n >= 2 && lf.n <= 176 && lf.k >= 1 && lf.k <= 176 && lf.blocks >= 1 && lf.blocks <= 16 && lf.abs >= 0 &&
-                              lf.abs + lf.n <= 2 * kSymN;
             unsigned cm = 0;
-            if (sane) lane_pulse_leaf(tab, lf, X, H.spread, &cm);
+            lane_pulse_leaf(tab, lf, X, H.spread, &cm);
             L.leafCm[l] = (unsigned short)cm;
         }
         NYQ_WAVE_SYNC();
@@ -549,10 +582,10 @@ __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const un
             const SymOp o = F.ops[q];
             switch (o.kind) {
             case 0:
-                if (o.a >= 0 && o.a < nvecs) shape_vector(F, F.vecs[o.a], X, norm, norm2, work, tmp, seed, lane);
+                shape_vector(F, F.vecs[o.a], X, norm, norm2, work, tmp, seed, lane);
                 break;
             case 1:
-                if (lane == 0 && o.a >= 0 && o.a < 2 * kSymN && o.b < kShapeNorm / 2 && o.band <= 20) {
+                if (lane == 0) {
                     X[o.a] = o.f0;
                     if (o.b >= 0) (o.n ? norm2 : norm)[o.b] = o.f0;
                     L.masks[o.band] |= 1;
@@ -561,7 +594,7 @@ __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const un
                 NYQ_WAVE_SYNC();
                 break;
             case 2:
-                if (lane == 0 && o.a >= 0 && o.b >= 0 && o.a + 2 <= 2 * kSymN && o.b + 2 <= 2 * kSymN) {
+                if (lane == 0) {
                     float *x = X + o.a, *y = X + o.b;
                     const int sign = (o.n & 1) ? -1 : 1;
                     float *x2 = (o.n & 2) ? y : x, *y2 = (o.n & 2) ? x : y;
@@ -576,7 +609,6 @@ __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const un
                 NYQ_WAVE_SYNC();
                 break;
             case 3: {                                                // mid / side -> left / right (bands.c:391-441)
-                if (o.a < 0 || o.b < 0 || o.n < 0 || o.a + o.n > 2 * kSymN || o.b + o.n > 2 * kSymN) break;
                 float *x = X + o.a, *y = X + o.b;
                 const float mid = o.f0;
                 float a = 0.f, b = 0.f;
@@ -600,12 +632,10 @@ __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const un
                 break;
             }
             case 4:
-                if (o.a < 0 || o.n < 0 || o.a + o.n > 2 * kSymN) break;
                 for (int j = lane; j < o.n; j += kWave) X[o.a + j] = -X[o.a + j];
                 NYQ_WAVE_SYNC();
                 break;
             default:
-                if (o.a > kShapeNorm / 2) break;
                 for (int j = lane; j < o.a; j += kWave) norm[j] = .5f * (norm[j] + norm2[j]);
                 NYQ_WAVE_SYNC();
                 break;
