@@ -1069,7 +1069,7 @@ void BatchOpusDecoder::decodeImpl(const std::vector<const std::vector<uint8_t> *
     });
     // Memory bound: the page-locked group buffers hold freq[] and PCM of every stream of a batch, so a big job
     // (BASELINE config 4: 1000 streams of a 224 s file = 86 GB of coefficients) runs as consecutive sub-batches
-    // of at most NYQ_BATCH_BYTES (default 6 GiB) of staging memory; files keep their order.
+    // of at most NYQ_BATCH_BYTES (default 12 GiB) of staging memory; files keep their order.
     const size_t budget = stagingBudget_;
     std::vector<std::vector<size_t>> batches(1);
     {
