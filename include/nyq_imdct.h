@@ -89,12 +89,16 @@ int  nyq_ctx_device_info(nyq_ctx *ctx, int *compute_units, char *name, size_t na
  *                           window k + 1 (an A/B form like the two below: measured, not faster -- DESIGN.md 4.8)
  * The alternative forms (POST_FORM != pipeline, CHAIN_FUSED = FUSED_R2, CHAIN_OVERLAP = 1) are measured-and-rejected designs kept for A/B
  * runs: they exist only in the tools' build of this library (-DNYQ_AB_FORMS, tools/libnyq_imdct_ab.so);
- * the product build answers NYQ_ERR_INVALID for them.  nyq_ab_forms_built() tells which build this is. */
+ * the product build answers NYQ_ERR_INVALID for them.  nyq_ab_forms_built() tells which build this is. *   NYQ_OPT_HOST_WINDOW     nyq_celt_frames_to_pcm* / nyq_celt_symbols_*_to_pcm_mapped on few long streams: frames per time window
+ *                           (a multiple of 64; upload / kernels / download of consecutive windows overlap, bit-identical); 0 = the
+ *                           built-in choice (about 24 MB of input per window)
+ */
 #define NYQ_OPT_BLOCKS_PER_CU 1
 #define NYQ_OPT_POST_FORM     2
 #define NYQ_OPT_CHAIN_FUSED   3
 #define NYQ_OPT_CHAIN_WINDOW  4
 #define NYQ_OPT_CHAIN_OVERLAP 5
+#define NYQ_OPT_HOST_WINDOW   6
 #define NYQ_CHAIN_TWO_KERNELS 0
 #define NYQ_CHAIN_ONE_LAUNCH  1
 #define NYQ_CHAIN_FUSED_R2    2

@@ -12,7 +12,7 @@ import numpy as np
 from . import _build
 
 # nyq_ctx_set_option (include/nyq_imdct.h)
-OPT_BLOCKS_PER_CU, OPT_POST_FORM, OPT_CHAIN_FUSED, OPT_CHAIN_WINDOW, OPT_CHAIN_OVERLAP = 1, 2, 3, 4, 5
+OPT_BLOCKS_PER_CU, OPT_POST_FORM, OPT_CHAIN_FUSED, OPT_CHAIN_WINDOW, OPT_CHAIN_OVERLAP, OPT_HOST_WINDOW = 1, 2, 3, 4, 5, 6
 POST_FORM_PIPELINE, POST_FORM_WAVE_PER_CHANNEL, POST_FORM_WAVE_PER_PAIR = 0, 1, 2
 
 HALF_OV = 60

@@ -67,6 +67,7 @@ struct nyq_ctx {
     int opt_post_form = NYQ_POST_FORM_PIPELINE;
     int opt_chain_fused = NYQ_CHAIN_ONE_LAUNCH;
     long opt_chain_window = 0;           // frames per window of the two-kernel chain; 0 = built-in choice
+    long opt_host_window = 0;            // frames per time window of the host-buffer frames -> PCM calls; 0 = built-in choice
     int opt_chain_overlap = 0;           // windows: post-filter of window k on a second stream beside the synthesis of window k + 1
     hipStream_t s_post = nullptr;        // (created on first use)
     unsigned *d_pvq = nullptr;           // U(n, k) of the pulse-vector codebooks (shape kernel; created on first use)
@@ -178,6 +179,10 @@ extern "C" int nyq_ctx_set_option(nyq_ctx *ctx, int option, long value) {
             return fail(ctx, NYQ_ERR_INVALID, "nyq_ctx_set_option: the overlapped-window chain is an A/B form (tools/libnyq_imdct_ab.so): measured, not faster");
         ctx->opt_chain_overlap = (int)value;
         return NYQ_OK;
+    case NYQ_OPT_HOST_WINDOW:
+        if (value < 0 || value % 64 != 0) return fail(ctx, NYQ_ERR_INVALID, "nyq_ctx_set_option: NYQ_OPT_HOST_WINDOW must be a multiple of 64, or 0");
+        ctx->opt_host_window = value;
+        return NYQ_OK;
     case NYQ_OPT_CHAIN_WINDOW:
         if (value < 0) return fail(ctx, NYQ_ERR_INVALID, "nyq_ctx_set_option: NYQ_OPT_CHAIN_WINDOW must be >= 0");
         ctx->opt_chain_window = value;         // (rounded up to the frame size's chain length at the call)
@@ -195,6 +200,7 @@ extern "C" int nyq_ctx_get_option(nyq_ctx *ctx, int option, long *value) {
     case NYQ_OPT_CHAIN_FUSED: *value = ctx->opt_chain_fused; return NYQ_OK;
     case NYQ_OPT_CHAIN_WINDOW: *value = ctx->opt_chain_window; return NYQ_OK;
     case NYQ_OPT_CHAIN_OVERLAP: *value = ctx->opt_chain_overlap; return NYQ_OK;
+    case NYQ_OPT_HOST_WINDOW: *value = ctx->opt_host_window; return NYQ_OK;
     default: return fail(ctx, NYQ_ERR_INVALID, "nyq_ctx_get_option: unknown option");
     }
 }
@@ -1308,10 +1314,11 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
     // carry chains restart at the same frames as in one launch, bit-identical), upload of window w+1, kernels of window w and
     // download of window w-1 at the same time; the decoder states travel from window to window in device memory.  This is the
     // shape of a batch decoder's time slices when the GPU side is what the job waits for.
-    if (npieces == 1 && nframes >= 256) {
+    if (npieces == 1 && (nframes >= 256 || ctx->opt_host_window > 0)) {
         const size_t frame_in = sym ? rec : (size_t)channels * N * sizeof(float);
         size_t W = ((kHostWindowBytes / (nstreams * frame_in)) / 64) * 64;
         if (W < 64) W = 64;
+        if (ctx->opt_host_window > 0) W = (size_t)ctx->opt_host_window;  // NYQ_OPT_HOST_WINDOW
         const size_t nwin = (nframes + W - 1) / W;
         if (nwin >= 2 && nwin <= kHostMaxWindows) {
             rc = need_copy_streams(ctx, 2 * nwin + 1);

@@ -321,11 +321,15 @@ def test_unchanged_tap_set_shortcut_on_sb_reverie_parameters(ctx, oracle, form):
     assert np.array_equal(gst, wst)
 
 
-@pytest.mark.parametrize("lm,ch,ns,nf,with_state", [(3, 2, 3, 700, True), (3, 2, 2, 333, False), (3, 1, 2, 450, True), (1, 2, 3, 900, True)])
-def test_host_call_on_few_long_streams_runs_in_time_windows(ctx, oracle, lm, ch, ns, nf, with_state):
+@pytest.mark.parametrize("lm,ch,ns,nf,with_state,window", [(3, 2, 3, 700, True, 128), (3, 2, 2, 333, False, 64), (3, 1, 2, 450, True, 192),
+                                                            (1, 2, 3, 900, True, 256), (3, 2, 16, 520, True, 0)])
+def test_host_call_on_few_long_streams_runs_in_time_windows(ctx, oracle, lm, ch, ns, nf, with_state, window):
     """nyq_celt_frames_to_pcm on a few LONG streams cuts the call in time windows (upload / kernels / download of
     consecutive windows at once, states carried on the device: nyq_imdct.hip frames_to_pcm_core): bit for bit what one
-    device-resident launch over the whole length gives, decoder state out included."""
+    device-resident launch over the whole length gives, decoder state out included.  NYQ_OPT_HOST_WINDOW forces the window
+    length on cases small enough for the test tier (3 .. 6 windows, the last one ragged); window 0 = the built-in choice on
+    a case large enough for it to cut (16 streams x 520 frames = 64 MB of freq[]: three windows of 192)."""
+    import libnyquist_amd as nyq
     ctx.set_tables(*oracle.tables()[:2])
     rng = np.random.default_rng(900 + lm * 10 + ch)
     freq, tr, pitch, gain, taps, pst, ov, hist, dm = _case(rng, ns, nf, 0.05, ch=ch, lm=lm)
@@ -333,7 +337,11 @@ def test_host_call_on_few_long_streams_runs_in_time_windows(ctx, oracle, lm, ch,
         pst, ov, hist, dm = np.zeros_like(pst), np.zeros_like(ov), np.zeros_like(hist), np.zeros_like(dm)
     want, wst, wov, wh, wdm = _run_chain(ctx, lm, freq, tr, pitch, gain, taps, pst, ov, hist, dm, ch, form=ONE_LAUNCH)
     state = np.concatenate([ov.ravel(), hist.ravel(), dm.ravel(), pst.ravel()]).astype(np.float32) if with_state else None
-    got = ctx.celt_frames_to_pcm(lm, freq, tr, pitch, gain, taps, ch, state=state)
+    ctx.set_option(nyq.binding.OPT_HOST_WINDOW, window)
+    try:
+        got = ctx.celt_frames_to_pcm(lm, freq, tr, pitch, gain, taps, ch, state=state)
+    finally:
+        ctx.set_option(nyq.binding.OPT_HOST_WINDOW, 0)
     assert np.array_equal(got, want)
     if with_state:
         nsc = ns * ch
@@ -341,3 +349,42 @@ def test_host_call_on_few_long_streams_runs_in_time_windows(ctx, oracle, lm, ch,
         assert np.array_equal(state[nsc * 60:nsc * 1148].reshape(nsc, 1088), wh)
         assert np.array_equal(state[nsc * 1148:nsc * 1149], wdm)
         assert np.array_equal(state[nsc * 1149:].reshape(ns, 6), wst)
+
+
+@pytest.mark.parametrize("lm,ch", [(3, 2), (3, 1), (2, 2)])
+def test_host_call_in_time_windows_with_output_records(ctx, oracle, lm, ch):
+    """The windowed host call with an output record per stream (what a multistream file of long streams runs through): every
+    window's launch gets the records with t0 moved to the window's first sample.  The files' device buffers must equal, bit
+    for bit, what the unwindowed call writes."""
+    import ctypes as C
+    import libnyquist_amd as nyq
+    import torch
+    ctx.set_tables(*oracle.tables()[:2])
+    rng = np.random.default_rng(77 + lm + ch)
+    ns, nf, n = 3, 300, 120 << lm
+    freq, tr, pitch, gain, taps, pst, ov, hist, dm = _case(rng, ns, nf, 0.05, ch=ch, lm=lm)
+    dev = torch.device("cuda", 0)
+    total = nf * n
+    results = []
+    for window in (0, 128):
+        files = torch.full((ns, total, 3), -7.0, device=dev)
+        desc = (_OutDesc * ns)()
+        for s in range(ns):
+            desc[s].base = files[s].data_ptr()
+            desc[s].first, desc[s].last, desc[s].t0 = 100 + 7 * s, total - 50 * s, 0
+            desc[s].cstride, desc[s].gain = 3, 0.5 + 0.25 * s
+            desc[s].coff[0], desc[s].coff[1] = 2, (0 if ch == 2 else -1)
+        state = np.concatenate([ov.ravel(), hist.ravel(), dm.ravel(), pst.ravel()]).astype(np.float32)
+        torch.cuda.synchronize(dev)
+        ctx.set_option(nyq.binding.OPT_HOST_WINDOW, window)
+        try:
+            P = lambda a: a.ctypes.data_as(C.c_void_p)
+            rc = ctx.lib.nyq_celt_frames_to_pcm_mapped(ctx.h, lm, P(freq), P(tr), P(pitch), P(gain), P(taps), None, C.cast(desc, C.c_void_p),
+                                                       P(state), ns, nf, ch, nf)
+        finally:
+            ctx.set_option(nyq.binding.OPT_HOST_WINDOW, 0)
+        assert rc == 0, ctx.lib.nyq_last_error(ctx.h)
+        ctx.synchronize()
+        results.append((files.cpu().numpy(), state))
+    assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
+    assert (results[0][0][:, :, 1] == -7.0).all() and (results[0][0][0, :total - 100, 2] != -7.0).all()

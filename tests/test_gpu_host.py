@@ -386,3 +386,34 @@ def test_concurrent_loads_from_several_threads(host):
     # down and rebuilt four of them -- 24 contexts -- per Load while the other threads were inside their GPU calls)
     host.nyqh_decoder_pool_counts(counts)
     assert counts[0] - made0 <= 6 and counts[1] - gone0 == 0, (counts[0] - made0, counts[1] - gone0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"NYQ_HOST_PACKED": "1"}, {"NYQ_HOST_SYMBOLS": "0"}], ids=["packed-records", "freq-not-symbols"])
+def test_staging_forms_decode_to_the_same_samples(host, env):
+    """The batch decoder's two measurement switches, read once at a decoder's construction (so: a process of its own): symbol
+    records packed back to back with one gather launch per window (NYQ_HOST_PACKED=1), and freq[] built on the host instead of
+    symbol records (NYQ_HOST_SYMBOLS=0).  Packed and slotted records are the same records: bit for bit.  Host-built freq[]
+    differs from the device's band shapes by the order of a few sums: 2e-6 of full scale."""
+    import subprocess
+    import sys
+    raw = open(os.path.join(GOLDEN, "short.opus"), "rb").read()
+    n = 421930
+    first = np.zeros(n, np.float32)
+    stats = np.zeros(4, np.float64)
+    assert host.nyqh_batch_decode(raw, len(raw), 40, 8, first.ctypes.data_as(C.c_void_p), None, n, stats) == n
+    code = ("import sys, ctypes as C, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from test_host_decoder import load_host\n"
+            "H = load_host(); raw = open(%r, 'rb').read(); n = 421930\n"
+            "a = np.zeros(n, np.float32); b = np.zeros(n, np.float32); st = np.zeros(4, np.float64)\n"
+            "assert H.nyqh_batch_decode(raw, len(raw), 40, 8, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), n, st) == n\n"
+            "assert np.array_equal(a, b); a.tofile(sys.argv[1])\n") % (ROOT, os.path.join(ROOT, "tests"), os.path.join(GOLDEN, "short.opus"))
+    out = os.path.join("/tmp", "nyq_staging_form_%s.bin" % "_".join(env))
+    r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    other = np.fromfile(out, np.float32)
+    os.unlink(out)
+    if "NYQ_HOST_PACKED" in env:
+        assert np.array_equal(other, first)
+    else:
+        assert np.abs(other - first).max() <= 2e-6

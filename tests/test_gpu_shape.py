@@ -169,3 +169,22 @@ def test_damaged_records_leave_the_kernel_bounded(host, ctx):
     ctx.celt_shape_dev(d_bad.data_ptr(), got.data_ptr(), 1, nf, 2)
     ctx.synchronize()
     assert torch.equal(got[1::2], want[1::2])
+
+
+def test_symbols_to_pcm_in_time_windows(host, ctx):
+    """nyq_celt_symbols_to_pcm_mapped cut in time windows (NYQ_OPT_HOST_WINDOW = 64: four windows over short.opus) against
+    one window: the shape kernel and the chain run window by window, states carried on the device -- bit for bit."""
+    import libnyquist_amd as nyq
+    raw = open(os.path.join(GOLDEN, "short.opus"), "rb").read()
+    rc, sym, flags, gain, rng, info = symbols(host, raw, 400, 2)
+    nf = int(info[2])
+    assert rc == 0
+    tr, pp, pt = (np.ascontiguousarray(flags[:nf, k]) for k in range(3))
+    args = (tr.astype(np.uint8), pp.astype(np.int32), gain[:nf].copy(), pt.astype(np.int32))
+    want = ctx.celt_symbols_to_pcm(sym[:nf], *args, 1, nf, 2)
+    ctx.set_option(nyq.binding.OPT_HOST_WINDOW, 64)
+    try:
+        got = ctx.celt_symbols_to_pcm(sym[:nf], *args, 1, nf, 2)
+    finally:
+        ctx.set_option(nyq.binding.OPT_HOST_WINDOW, 0)
+    assert np.array_equal(got, want)
