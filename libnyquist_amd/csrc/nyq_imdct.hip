@@ -1314,7 +1314,7 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
     // carry chains restart at the same frames as in one launch, bit-identical), upload of window w+1, kernels of window w and
     // download of window w-1 at the same time; the decoder states travel from window to window in device memory.  This is the
     // shape of a batch decoder's time slices when the GPU side is what the job waits for.
-    if (npieces == 1 && (nframes >= 256 || ctx->opt_host_window > 0)) {
+    if (npieces == 1 && nframes >= 128) {
         const size_t frame_in = sym ? rec : (size_t)channels * N * sizeof(float);
         size_t W = ((kHostWindowBytes / (nstreams * frame_in)) / 64) * 64;
         if (W < 64) W = 64;

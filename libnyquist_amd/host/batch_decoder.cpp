@@ -965,6 +965,8 @@ BatchOpusDecoder::BatchOpusDecoder(const std::vector<int> &devices) : devices_(d
     }
     if (const char *e = std::getenv("NYQ_HOST_SYMBOLS")) symbolRecords_ = std::atoi(e) != 0;   // (A/B switch, read once like the budget)
     if (const char *e = std::getenv("NYQ_BATCH_TRACE")) trace_ = std::atoi(e) != 0;
+    long hostWindow = -1;                                   // (measurement switch: NYQ_OPT_HOST_WINDOW of every context)
+    if (const char *e = std::getenv("NYQ_HOST_WINDOW")) hostWindow = std::atol(e);
     if (const char *e = std::getenv("NYQ_HOST_PACKED")) packedRecords_ = std::atoi(e) != 0;
     const int ndev = nyq_device_count();
     for (int d : devices_)
@@ -980,6 +982,7 @@ BatchOpusDecoder::BatchOpusDecoder(const std::vector<int> &devices) : devices_(d
                 ctx_.clear();
                 throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(nullptr));
             }
+            if (hostWindow >= 0) (void)nyq_ctx_set_option(c, NYQ_OPT_HOST_WINDOW, hostWindow);
             ctx_.push_back(c);
         }
 }

@@ -57,6 +57,7 @@ void nyq_ctx_destroy(nyq_ctx *c) {
     delete c;
 }
 const char *nyq_last_error(const nyq_ctx *) { return "fake"; }
+int nyq_ctx_set_option(nyq_ctx *, int, long) { return NYQ_OK; }
 void *nyq_host_alloc(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
 void nyq_host_free(void *p) { std::free(p); }
 
