@@ -329,6 +329,7 @@ public:
     bool symbolRecords_ = true;
     bool symbolRecords() const { return symbolRecords_; }
     bool packedRecords_ = false;        // records back to back (half the upload) or one per slot (one strided copy per window)
+    size_t pieceBytes_ = kPieceBytes;
     bool trace_ = false;
 
     // returns when every file of the sub-batch is decoded (or has its error set); throws if the GPU failed
@@ -485,7 +486,7 @@ private:
             // (Smaller pieces of long streams -- 4 or 8 streams, more slice chains side by side -- were measured in
             // round 4: -5 % ... +9 % of the job's wall time, profiles/r04_v_piece_ab.txt; what the job waited for was
             // the serial upload -> kernels -> download of every slice, now pipelined inside the library call.)
-            const size_t per = std::max<size_t>((size_t)std::max(1, threads_), kPieceBytes / std::max<size_t>(1, g.maxF * g.frameBytes));
+            const size_t per = std::max<size_t>((size_t)std::max(1, threads_), pieceBytes_ / std::max<size_t>(1, g.maxF * g.frameBytes));
             for (size_t k0 = 0; k0 < g.ns; k0 += per) {
                 pieces_.emplace_back();
                 Piece &p = pieces_.back();
@@ -968,6 +969,7 @@ BatchOpusDecoder::BatchOpusDecoder(const std::vector<int> &devices) : devices_(d
     long hostWindow = -1;                                   // (measurement switch: NYQ_OPT_HOST_WINDOW of every context)
     if (const char *e = std::getenv("NYQ_HOST_WINDOW")) hostWindow = std::atol(e);
     if (const char *e = std::getenv("NYQ_HOST_PACKED")) packedRecords_ = std::atoi(e) != 0;
+    if (const char *e = std::getenv("NYQ_PIECE_BYTES")) pieceBytes_ = (size_t)std::max<long long>(1 << 20, std::atoll(e));
     const int ndev = nyq_device_count();
     for (int d : devices_)
         if (d < 0 || d >= ndev)
@@ -1133,6 +1135,7 @@ void BatchOpusDecoder::decodeImpl(const std::vector<const std::vector<uint8_t> *
         SubBatch sb(jobs, out, members, ctx_.data(), (int)devices_.size(), kFeeders, threads, arenaFn, devArenaFn);
         sb.symbolRecords_ = symbolRecords_;
         sb.packedRecords_ = packedRecords_;
+        sb.pieceBytes_ = pieceBytes_;
         sb.trace_ = trace_;
         sb.run();
         cpuSecs += sb.cpuSeconds;

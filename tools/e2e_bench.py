@@ -22,7 +22,8 @@ threads = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 H = load_host()
 fname = sys.argv[3] if len(sys.argv) > 3 else "short.opus"      # or sb-reverie.opus (224 s, BASELINE config 4's file)
 raw = open(os.path.join(ROOT, "tests", "golden", fname), "rb").read()
-n = {"short.opus": 421930, "sb-reverie.opus": 21472602, "sb-reverie-60ms-frames.opus": 21472602}[fname]
+n = {"short.opus": 421930, "sb-reverie.opus": 21472602, "sb-reverie-60ms-frames.opus": 21472602,
+     "corpus/surround71_20ms_320k.opus": 384000}[fname]
 first = np.zeros(n, np.float32)
 stats = np.zeros(6, np.float64)
 import time  # noqa: E402
