@@ -11,9 +11,9 @@
 // sources; reductions are summed in another order).  Half of the host's per-frame time moves here, where it is one wavefront
 // per frame among thousands.
 //
-// One wavefront = one frame at a time (grid-stride over frames; kShapeWaves frames side by side in a workgroup, sharing the
-// codebook table).  The frame's record is staged into the wave's LDS slice, where its coefficients X[C][960] and the fold
-// memory live too.  Pass A, a leaf per LANE: everything a pulse leaf needs is its own -- codeword -> pulse counts ->
+// One wavefront = one frame at a time (frames handed out by a counter; kShapeWaves frames side by side in a workgroup, sharing
+// the codebook table).  The frame's coefficients X[C][960] and the fold memory live in the wave's LDS slice; its record is read
+// in place.  Pass A, a leaf per LANE: everything a pulse leaf needs is its own -- codeword -> pulse counts ->
 // unit-norm coefficients -> spreading rotation, all in place in X, the chains' carried values in registers and the loads
 // of a chain issued four steps ahead (a step is otherwise one LDS round trip).  Pass B, wave-uniform: the operation list in
 // order -- collapse masks, fills from the bands below, resolution changes, stereo -- lanes over the bins.
@@ -426,8 +426,15 @@ __device__ __forceinline__ int shape_edge(int i, int LM) {
 }
 
 // measurement switches (tools/shape_time.py builds variants with them; the product defines none)
+// NYQ_SHAPE_STAGE 0 (the product): the frame's operations / vectors / leaves are read where they lie, in global memory -- pass B's
+// addresses are wave-uniform, i.e. scalar loads -- and NINE waves per CU fit beside the table; 1: they are staged into LDS first
+// (10.5 KB per wave: five waves per CU).  Measured on 89,472 real frames: 5.75 ms against 8.86 (profiles/r04_av_*): a frame
+// waits longer for its records, and nearly twice as many frames wait at once.
+#ifndef NYQ_SHAPE_STAGE
+#define NYQ_SHAPE_STAGE 0
+#endif
 #ifndef NYQ_SHAPE_WAVES
-#define NYQ_SHAPE_WAVES 5
+#define NYQ_SHAPE_WAVES (NYQ_SHAPE_STAGE ? 5 : 9)
 #endif
 #ifndef NYQ_SHAPE_DBG_NO_A
 #define NYQ_SHAPE_DBG_NO_A 0
@@ -439,7 +446,9 @@ constexpr int kShapeWaves = NYQ_SHAPE_WAVES;                         // frames s
 struct ShapeWaveLds {
     float f[kShapeLdsFloats];                                        // X | fold memory | two work vectors
     // the frame's operations, vectors and leaves, staged as they lie in the record (one contiguous range)
+#if NYQ_SHAPE_STAGE
     unsigned rec[(kSymMaxOps * sizeof(SymOp) + kSymMaxVecs * sizeof(SymVec) + kSymMaxLeaves * sizeof(SymLeaf)) / 4];
+#endif
     unsigned short leafCm[kSymMaxLeaves];
     unsigned char masks[2 * 21 + 6];
 };
@@ -508,10 +517,16 @@ __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const un
         // (the counts were checked against their bounds above: the three parts are one contiguous range of the record)
         const int bops = nops * (int)sizeof(SymOp), bvecs = nvecs * (int)sizeof(SymVec), bleaves = nleaves * (int)sizeof(SymLeaf);
         const unsigned char *rleaves = r + kSymOpsOff + bops + bvecs;
+#if NYQ_SHAPE_STAGE
         stage_words(L.rec, r + kSymOpsOff, bops + bvecs + bleaves, lane);
         const SymOp *Lops = reinterpret_cast<const SymOp *>(L.rec);
         const SymVec *Lvecs = reinterpret_cast<const SymVec *>(L.rec + bops / 4);
         const SymLeaf *Lleaves = reinterpret_cast<const SymLeaf *>(L.rec + (bops + bvecs) / 4);
+#else
+        const SymOp *Lops = reinterpret_cast<const SymOp *>(r + kSymOpsOff);
+        const SymVec *Lvecs = reinterpret_cast<const SymVec *>(r + kSymOpsOff + bops);
+        const SymLeaf *Lleaves = reinterpret_cast<const SymLeaf *>(rleaves);
+#endif
         if (lane < 2 * 21) L.masks[lane] = 0;
         NYQ_WAVE_SYNC();
         ShapeFrame F;
