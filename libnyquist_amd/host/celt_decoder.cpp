@@ -425,6 +425,15 @@ int bitexactLog2tan(int isin, int icos) {
     isin <<= 15 - ls;
     return (ls - lc) * (1 << 11) + fracMul16(isin, fracMul16(isin, -2597) + 7932) - fracMul16(icos, fracMul16(icos, -2597) + 7932);
 }
+// floor(sqrt(v)) for the triangular angle density (v < 2^18 there): the hardware square root and one correction step in place
+// of the bit-serial isqrt32 (mathops.c:42-65) -- the same integer
+inline uint32_t floorSqrt(uint32_t v) {
+    uint32_t r = (uint32_t)std::sqrt((float)v);
+    if (r * r > v) r--;
+    else if ((r + 1) * (r + 1) <= v) r++;
+    return r;
+}
+
 int angleResolution(int N, int b, int offset, int pulseCap, bool stereo) {
     static const int16_t exp2Table8[8] = {16384, 17866, 19483, 21247, 23170, 25267, 27554, 30048};
     int N2 = 2 * N - 1;
@@ -492,11 +501,11 @@ struct CeltDecoder::BandShaper {
                 const int fm = (int)rc.decode(ft);
                 int fs, fl;
                 if (fm < (h * (h + 1) >> 1)) {
-                    itheta = (int)(isqrt32(8 * (uint32_t)fm + 1) - 1) >> 1;
+                    itheta = (int)(floorSqrt(8 * (uint32_t)fm + 1) - 1) >> 1;
                     fs = itheta + 1;
                     fl = itheta * (itheta + 1) >> 1;
                 } else {
-                    itheta = (int)(2 * (qn + 1) - isqrt32(8 * (uint32_t)(ft - fm - 1) + 1)) >> 1;
+                    itheta = (int)(2 * (qn + 1) - floorSqrt(8 * (uint32_t)(ft - fm - 1) + 1)) >> 1;
                     fs = qn + 1 - itheta;
                     fl = ft - ((qn + 1 - itheta) * (qn + 2 - itheta) >> 1);
                 }

@@ -20,6 +20,9 @@ static thread_local std::string g_capi_err;
 
 extern "C" {
 
+// RangeDecoder::tellFrac's table form against the reference's squaring loop, every case (0 = identical)
+long nyqh_tell_frac_self_check(void) { return RangeDecoder::tellFracSelfCheck(); }
+
 // cache tables of the 48 kHz mode as this library computed them (tests compare them with the
 // reference's static tables): returns sizes through the out parameters
 int nyqh_mode_tables(short *logN21, short *cacheIndex105, unsigned char *cacheBits, int *cacheBitsLen,

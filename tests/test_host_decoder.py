@@ -67,6 +67,13 @@ def entropy_decode(H, raw, max_frames=400, channels=2, n=960):
     return rc, freq, flags, gain, rng, info
 
 
+def test_tell_frac_table_equals_the_squaring_loop(host):
+    """ec_tell_frac (entcode.c:69-93) as a linear guess plus one table comparison: the same integer as the reference's three
+    squarings for every value of the range's top 16 bits at every width (589,806 cases)."""
+    host.nyqh_tell_frac_self_check.restype = C.c_long
+    assert host.nyqh_tell_frac_self_check() == 0
+
+
 def test_mode_tables_match_reference(host, ref_tables):
     """logN, pulse cache and caps are COMPUTED by the host library (rate.c:73-245 restated); they
     must equal the reference's generated static tables (static_modes_float.h:36-97)."""
