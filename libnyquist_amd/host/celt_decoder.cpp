@@ -434,6 +434,19 @@ inline uint32_t floorSqrt(uint32_t v) {
     return r;
 }
 
+// itheta * 16384 / qn (bands.c:779) without the division: qn <= 256, itheta <= qn, so the product is below 2^22 and a 40-bit
+// reciprocal rounded up gives the exact quotient (error < 2^22 / 2^40 < 1 / qn)
+inline int scaleAngle(int itheta, int qn) {
+    static const struct Recip {
+        uint64_t m[257];
+        Recip() {
+            m[0] = 0;
+            for (int q = 1; q <= 256; q++) m[q] = ((1ull << 40) + (uint64_t)q - 1) / (uint64_t)q;
+        }
+    } R;
+    return (int)(((uint64_t)itheta * 16384u * R.m[qn]) >> 40);
+}
+
 int angleResolution(int N, int b, int offset, int pulseCap, bool stereo) {
     static const int16_t exp2Table8[8] = {16384, 17866, 19483, 21247, 23170, 25267, 27554, 30048};
     int N2 = 2 * N - 1;
@@ -511,7 +524,7 @@ struct CeltDecoder::BandShaper {
                 }
                 rc.update(fl, fl + fs, ft);
             }
-            itheta = (int32_t)itheta * 16384 / qn;
+            itheta = scaleAngle(itheta, qn);
         } else if (stereo) {
             inv = (b > 2 << kBitRes && remaining > 2 << kBitRes) ? rc.bitLogp(2) : 0;
         }
@@ -557,9 +570,9 @@ struct CeltDecoder::BandShaper {
         const PulseLut &lut = pulseLut();
         const uint32_t *U32 = pvqTable32();
         int sp = 0;
-        stack[sp++] = Node{0, (int16_t)n0, (int16_t)(hasFold ? 0 : -1), b0, B0, lm0, fill0, 0, gain0, false, false, 0, 0};
-        while (sp > 0) {
-            Node nd = stack[--sp];
+        // (the node in hand stays in `nd`: of a split's halves only the second one goes through the stack)
+        Node nd{0, (int16_t)n0, (int16_t)(hasFold ? 0 : -1), b0, B0, lm0, fill0, 0, gain0, false, false, 0, 0};
+        for (;;) {
             if (nd.deferred) {
                 const int32_t surplus = nd.firstBits - (nd.remainingBefore - remaining);
                 if (surplus > 3 << kBitRes && nd.mayGrow) nd.b += surplus - (3 << kBitRes);
@@ -591,7 +604,7 @@ struct CeltDecoder::BandShaper {
                 second.remainingBefore = remaining;
                 second.mayGrow = mbits >= sbits ? a.itheta != 0 : a.itheta != 16384;
                 stack[sp++] = second;
-                stack[sp++] = first;
+                nd = first;
                 continue;
             }
             // a leaf: as many pulses as its bits buy (fewer if the frame runs out)
@@ -615,19 +628,22 @@ struct CeltDecoder::BandShaper {
             lf.shift = (uint8_t)nd.shift;
             lf.abs = (int16_t)(x0 + nd.off);
             lf.pad2 = 0;
-            const Img img = nd.fill & rep((1u << nd.B) - 1);
-            std::memcpy(lf.img, &img, sizeof img);                    // (lane i = the image of input bit i)
             if (q != 0) {
                 const int K = CeltMode::pulsesOf(q);
                 lf.kind = kPulses;
                 lf.k = (int16_t)K;
                 const uint32_t *urow = U32 + (size_t)nd.n * kPvqTableDim + K;          // codebook size V = U(n, K) + U(n, K + 1)
                 lf.index = rc.uint(urow[0] + urow[1]);
+                std::memset(lf.img, 0, sizeof lf.img);                // (a pulse leaf's fill is never asked for)
             } else {
                 lf.kind = kZero;
                 lf.k = 0;
                 lf.index = 0;
+                const Img img = nd.fill & rep((1u << nd.B) - 1);
+                std::memcpy(lf.img, &img, sizeof img);                // (lane i = the image of input bit i)
             }
+            if (sp == 0) break;
+            nd = stack[--sp];
         }
     }
 
