@@ -231,7 +231,7 @@ int nyq_device_dup_channel(nyq_ctx *ctx, float *d_base, int cstride, int src_slo
  * a short program of vector operations, the band gains) and nyq_celt_shape_dev builds freq[] from them on the device, one
  * wavefront per frame.  20 ms frames (LM 3), mono or stereo.  One frame = one record, at most nyq_celt_symbol_bytes(channels)
  * bytes (the slot of the fixed-stride forms), laid out compactly:
- *     nyq_sym_head | float gain[42] (2^(energy + mean) per band, channel-major) | nyq_sym_op ops[nops] | nyq_sym_vec vecs[nvecs] |
+ *     nyq_sym_head | float log_gain[42] (energy + mean per band in log2 units, channel-major: the device raises 2 to it) | nyq_sym_op ops[nops] | nyq_sym_vec vecs[nvecs] |
  *     nyq_sym_leaf leaves[nleaves] (+ float level[42] with NYQ_SYM_ANTI_COLLAPSE)
  *     --  or, with NYQ_SYM_HOST_FREQ:  nyq_sym_head | float freq[channels * 960]
  * A record of zeros is a silent frame.  Offsets inside a frame are in floats of X (channel c at c * 960).  head.channels is

@@ -54,7 +54,7 @@ struct SymOp {
 };
 constexpr int kSymMaxOps = 113, kSymMaxVecs = 44;
 constexpr int kSymN = 960;                                           // bins per channel of a 20 ms frame (LM 3); 120 << LM in general
-// a record is COMPACT: head | gain[42] | ops[nops] | vecs[nvecs] | leaves[nleaves] | (anti-collapse) level[42], or head | freq[];
+// a record is COMPACT: head | log_gain[42] | ops[nops] | vecs[nvecs] | leaves[nleaves] | (anti-collapse) level[42], or head | freq[];
 // the slot of the fixed-stride form (sym_bytes) holds the largest record the entropy stage writes
 constexpr int kSymOpsOff = 32 + 42 * 4;                              // 200
 constexpr int kSymFreqOff = 32;
@@ -512,7 +512,9 @@ __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const un
         }
         const int nleaves = H.nleaves < kSymMaxLeaves ? H.nleaves : kSymMaxLeaves;
         const int nops = H.nops < kSymMaxOps ? H.nops : kSymMaxOps, nvecs = H.nvecs < kSymMaxVecs ? H.nvecs : kSymMaxVecs;
-        const float laneGain = lane < 2 * 21 ? reinterpret_cast<const float *>(r + 32)[lane] : 0.f;   // lane c * 21 + band
+        // band gains: 2^(energy + mean), celt_exp2 of the float build (a double exponential rounded to float: mathops.h), a band
+        // per lane -- the host sends the exponents
+        const float laneGain = lane < 2 * 21 ? (float)exp(0.6931471805599453094 * (double)reinterpret_cast<const float *>(r + 32)[lane]) : 0.f;
         NYQ_WAVE_SYNC();                                             // (the previous frame's last reads of this slice)
         // (the counts were checked against their bounds above: the three parts are one contiguous range of the record)
         const int bops = nops * (int)sizeof(SymOp), bvecs = nvecs * (int)sizeof(SymVec), bleaves = nleaves * (int)sizeof(SymLeaf);

@@ -1066,7 +1066,7 @@ int CeltDecoder::decode(const uint8_t *data, int len, int frameSize, float *freq
     return decodeFrame(data, len, frameSize, freqOut, nullptr, info);
 }
 
-// layout of a symbol record (include/nyq_imdct.h), COMPACT: head | gain[42] | ops[nops] | vecs[nvecs] | leaves[nleaves] |
+// layout of a symbol record (include/nyq_imdct.h), COMPACT: head | log_gain[42] | ops[nops] | vecs[nvecs] | leaves[nleaves] |
 // (anti-collapse) level[42], rounded up to 16 bytes -- or head | freq[channels * 960] for a frame built on the host.
 // A record never exceeds symbolBytes(channels) = the slot of the fixed-stride form.
 namespace {
@@ -1324,7 +1324,7 @@ int CeltDecoder::decodeFrame(const uint8_t *data, int len, int frameSize, float 
         H->lm = (unsigned char)LM;
         float *gain = reinterpret_cast<float *>(record + kSymGainOff);
         for (int c = 0; c < C; c++)
-            for (int i = start; i < effEnd; i++) gain[c * kBands + i] = exp2Ref(E[i + c * kBands] + m.eMeans[i]);
+            for (int i = start; i < effEnd; i++) gain[c * kBands + i] = E[i + c * kBands] + m.eMeans[i];   // (log2: the device raises 2 to it)
         uint8_t *w = record + kSymOpsOff;
         std::memcpy(w, scratch_.ops, sizeof(nyq_sym_op) * (size_t)scratch_.nops);
         w += sizeof(nyq_sym_op) * (size_t)scratch_.nops;
