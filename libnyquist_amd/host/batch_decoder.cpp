@@ -370,6 +370,7 @@ public:
             }
             tDecode0 = std::chrono::steady_clock::now();
             parallelFor(members_.size(), threads_, [&](size_t mi) { decodeFile(members_[mi]); });
+            decodeDone_.store(true, std::memory_order_release);
             t1 = std::chrono::steady_clock::now();
             guard.armed = false;
             cv_.notify_all();
@@ -761,13 +762,46 @@ private:
     void handOver(const Piece &p, size_t f0, size_t len) {
         const Group &g = groups_[p.group];
         if (g.mapped) return;                                   // (its samples are in the files' device buffers)
-        for (size_t k = p.k0; k < p.k1; k++) {
+        // Once the entropy stage is over its threads' CPUs are idle and what is left of the job is this copying: a large
+        // hand-over is then split over a few short-lived threads (each stream has its own destination vector).  While the
+        // entropy stage runs, the copy stays on the feeder: every CPU has work.
+        const size_t bytes = (p.k1 - p.k0) * len * g.N * (size_t)g.ch * sizeof(float);
+        const size_t helpers = decodeDone_.load(std::memory_order_acquire) && bytes >= ((size_t)4 << 20)
+                                   ? std::min<size_t>(std::min<size_t>(8, (size_t)std::max(1, threads_)), p.k1 - p.k0)
+                                   : 1;
+        if (helpers > 1) {
+            std::atomic<bool> failed{false};
+            size_t started = 0;
+            {
+                JoinedThreads pool;                                 // (joined at the end of this block, whatever happens)
+                try {
+                    for (; started < helpers; started++)
+                        pool.start([this, &p, &failed, f0, len, h = started, helpers] {
+                            try {
+                                for (size_t k = p.k0 + h; k < p.k1; k += helpers) handOverStream(p, k, f0, len);
+                            } catch (...) {
+                                failed.store(true);
+                            }
+                        });
+                } catch (const std::system_error &) {               // no more threads to be had: the rest is done here
+                }
+                for (size_t h = started; h < helpers; h++)
+                    for (size_t k = p.k0 + h; k < p.k1; k += helpers) handOverStream(p, k, f0, len);
+            }
+            if (failed.load()) throw std::runtime_error("the hand-over of a slice's samples failed (out of memory)");
+            return;
+        }
+        for (size_t k = p.k0; k < p.k1; k++) handOverStream(p, k, f0, len);
+    }
+    void handOverStream(const Piece &p, size_t k, size_t f0, size_t len) {
+        const Group &g = groups_[p.group];
+        {
             const size_t i = fileOf_[g.ids[k]];
-            if (!streamed_[i]) continue;
+            if (!streamed_[i]) return;
             const int64_t n0 = (int64_t)sf(g.ids[k]).plan[0].nframes * (int64_t)g.N;   // (frames past it are padding)
             const int64_t lo = std::max<int64_t>(window_[i].first, (int64_t)(f0 * g.N));
             const int64_t hi = std::min<int64_t>(std::min<int64_t>(window_[i].second, n0), (int64_t)((f0 + len) * g.N));
-            if (hi <= lo) continue;
+            if (hi <= lo) return;
             std::vector<float> &pcm = out_[i].pcm;
             if (pcm.empty()) pcm.reserve((size_t)(window_[i].second - window_[i].first) * g.ch);
             const float *src = g.out + k * g.maxF * g.N * g.ch;
@@ -950,6 +984,7 @@ private:
     std::vector<std::deque<size_t>> ready_;   // per device
     size_t finishedPieces_ = 0;
     bool abort_ = false;                               // run() is unwinding: feeders stop taking pieces
+    std::atomic<bool> decodeDone_{false};              // the entropy stage is over: its CPUs are free for the hand-over copies
     std::string gpuError_;
     std::vector<double> gpuBusy_;
 };
