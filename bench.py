@@ -28,7 +28,10 @@ Secondary keys on the same line (rank 0; the last two at N = 1 only, never part 
   host_boundary         nyq_imdct_batch on pinned HOST buffers (PCIe both ways) and the per-call latency of
                         the reference's own offload interface (processMDCTCuda)
   opus_file_decode      256 Ogg Opus files through the plugin surface next to the reference's NyquistIO::Load
-                        on the same host threads (that leg's cpu_baseline)
+                        on the same host threads (that leg's cpu_baseline); .long_streams (32 x the 224 s file of BASELINE
+                        config 4), .surround_7_1 (config 5's shape: 8 channels in 5 elementary streams),
+                        .band_shapes_on_device (the entropy stage's two halves on real packets: host symbol stage
+                        frames/s/thread, celt_shape_kernel frames/s)
 """
 import argparse
 import ctypes
