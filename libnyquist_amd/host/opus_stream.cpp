@@ -11,28 +11,44 @@ int64_t rd64(const uint8_t *p) { return (int64_t)((uint64_t)rd32(p) | (uint64_t)
 }  // namespace
 
 namespace {
-uint32_t oggCrc(const uint8_t *header, size_t headerLen, const uint8_t *body, size_t bodyLen) {
-    static const std::vector<uint32_t> table = [] {
-        std::vector<uint32_t> t(256);
+// CRC-32 of RFC 3533 (polynomial 0x04c11db7, most significant bit first, no reflection), eight bytes per step ("slicing by
+// 8": T[k][i] is the remainder of byte i followed by k zero bytes): the scan of a file checks every page, and at one byte per
+// step that was 5-10 % of the host's time per file next to the entropy stage's 2e5 frames/s.
+struct CrcTables {
+    uint32_t t[8][256];
+    CrcTables() {
         for (uint32_t i = 0; i < 256; i++) {
             uint32_t r = i << 24;
             for (int k = 0; k < 8; k++) r = (r & 0x80000000u) ? (r << 1) ^ 0x04c11db7u : r << 1;
-            t[i] = r;
+            t[0][i] = r;
         }
-        return t;
-    }();
-    uint32_t c = 0;
-    for (size_t i = 0; i < headerLen; i++) {
-        const uint8_t b = (i >= 22 && i < 26) ? 0 : header[i];      // the checksum field counts as zero
-        c = (c << 8) ^ table[((c >> 24) & 0xff) ^ b];
+        for (int k = 1; k < 8; k++)
+            for (uint32_t i = 0; i < 256; i++) t[k][i] = (t[k - 1][i] << 8) ^ t[0][t[k - 1][i] >> 24];
     }
-    for (size_t i = 0; i < bodyLen; i++) c = (c << 8) ^ table[((c >> 24) & 0xff) ^ body[i]];
+};
+inline uint32_t crcBytes(const CrcTables &T, uint32_t c, const uint8_t *p, size_t n) {
+    while (n >= 8) {
+        c ^= (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | (uint32_t)p[3];
+        c = T.t[7][c >> 24] ^ T.t[6][(c >> 16) & 0xff] ^ T.t[5][(c >> 8) & 0xff] ^ T.t[4][c & 0xff] ^ T.t[3][p[4]] ^ T.t[2][p[5]] ^
+            T.t[1][p[6]] ^ T.t[0][p[7]];
+        p += 8;
+        n -= 8;
+    }
+    for (; n > 0; n--, p++) c = (c << 8) ^ T.t[0][((c >> 24) & 0xff) ^ *p];
     return c;
+}
+uint32_t oggCrc(const uint8_t *header, size_t headerLen, const uint8_t *body, size_t bodyLen) {
+    static const CrcTables T;
+    uint8_t h[27 + 255];
+    std::memcpy(h, header, headerLen);                              // (27 + segments <= 282 bytes)
+    h[22] = h[23] = h[24] = h[25] = 0;                               // the checksum field counts as zero
+    return crcBytes(T, crcBytes(T, 0, h, headerLen), body, bodyLen);
 }
 }  // namespace
 
 OggOpusFile parseOggOpus(const uint8_t *data, size_t size) {
     OggOpusFile f;
+    f.packets.reserveBytes(size);
     std::vector<uint8_t> pending;     // packet continued across pages
     bool havePending = false;
     int packetIndex = 0;

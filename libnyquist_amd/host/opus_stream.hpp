@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace nyq_host {
@@ -29,9 +30,44 @@ struct OpusHead {
     uint8_t mapping[255] = {0};
 };
 
+// The audio packets of a file, in order: ONE byte arena and a span per packet (a 224 s file has 11184 of them: a vector each
+// was 11184 allocations per scan).  Iterates as objects with data() / size(), like the vectors it replaces.
+class PacketList {
+public:
+    struct Ref {
+        const uint8_t *p;
+        size_t n;
+        const uint8_t *data() const { return p; }
+        size_t size() const { return n; }
+    };
+    class Iter {
+    public:
+        Iter(const PacketList *l, size_t i) : l_(l), i_(i) {}
+        Ref operator*() const { return (*l_)[i_]; }
+        Iter &operator++() { ++i_; return *this; }
+        bool operator!=(const Iter &o) const { return i_ != o.i_; }
+    private:
+        const PacketList *l_;
+        size_t i_;
+    };
+    void push_back(const std::vector<uint8_t> &pkt) {
+        spans_.emplace_back(bytes_.size(), pkt.size());
+        bytes_.insert(bytes_.end(), pkt.begin(), pkt.end());
+    }
+    void reserveBytes(size_t n) { bytes_.reserve(n); }
+    size_t size() const { return spans_.size(); }
+    bool empty() const { return spans_.empty(); }
+    Ref operator[](size_t i) const { return Ref{bytes_.data() + spans_[i].first, spans_[i].second}; }
+    Iter begin() const { return Iter(this, 0); }
+    Iter end() const { return Iter(this, spans_.size()); }
+private:
+    std::vector<uint8_t> bytes_;
+    std::vector<std::pair<size_t, size_t>> spans_;
+};
+
 struct OggOpusFile {
     OpusHead head;
-    std::vector<std::vector<uint8_t>> packets;   // audio packets in order
+    PacketList packets;                          // audio packets in order
     int64_t lastGranule = -1;                    // granule position of the last page (samples at 48 kHz incl. pre-skip)
 };
 
