@@ -93,11 +93,11 @@ void scanFile(const std::vector<uint8_t> &file, FileJob &job) {
     const int S = h.streamCount;
     job.subs.assign(S, StreamFrames());
     for (int k = 0; k < S; k++) job.subs[k].channels = k < h.coupledCount ? 2 : 1;
+    PacketFrames pf;                                        // (one frame list for the whole file: no allocation per packet)
     for (const auto &pkt : job.f.packets) {
         const uint8_t *p = pkt.data();
         int rem = (int)pkt.size();
         for (int k = 0; k < S; k++) {                       // opus_multistream_decoder.c:237-290
-            PacketFrames pf;
             int used = rem;
             if (!parseOpusPacket(p, rem, pf, k != S - 1, &used)) throw std::runtime_error("malformed Opus packet");
             if (pf.config < 16) throw std::runtime_error("SILK/hybrid packet: only CELT-only streams are supported");
@@ -140,11 +140,11 @@ void entropyDecode(FileJob &job, OnSlice &&onSlice) {
             L.pfGain.resize(L.nframes);
         }
     }
+    PacketFrames pf;
     for (const auto &pkt : job.f.packets) {
         const uint8_t *p = pkt.data();
         int rem = (int)pkt.size();
         for (int k = 0; k < S; k++) {
-            PacketFrames pf;
             int used = rem;
             parseOpusPacket(p, rem, pf, k != S - 1, &used);  // validated by the scan
             StreamFrames &s = job.subs[k];
