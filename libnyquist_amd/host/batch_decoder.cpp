@@ -323,7 +323,7 @@ public:
         : jobs_(jobs), out_(out), members_(members), ctxs_(ctxs), ndev_(ndev), feedersPerDev_(feedersPerDev),
           nfeeders_(ndev * feedersPerDev), threads_(threads), arena_(arena), devArena_(devArena), firstSub_(jobs.size(), 0),
           finished_(jobs.size(), 0), streamed_(jobs.size(), 0), window_(jobs.size()), subsLeft_(jobs.size()), fileDev_(jobs.size(), 0),
-          devOut_(jobs.size(), nullptr), ready_((size_t)ndev), gpuBusy_((size_t)(ndev * feedersPerDev), 0.0) {}
+          devOut_(jobs.size(), nullptr), hostOut_(jobs.size(), nullptr), ready_((size_t)ndev), gpuBusy_((size_t)(ndev * feedersPerDev), 0.0) {}
 
     // 20 ms mono / stereo streams hand SYMBOL records to the GPU (their band shapes are built there); off: freq[] as for every other shape
     bool symbolRecords_ = true;
@@ -462,6 +462,12 @@ private:
             bytes[(size_t)g.dev] += align256(q * g.frameBytes) + (g.mapped ? 0 : 1) * align256(x) + 3 * align256(q * 4) + align256(q) +   // (mapped: no dense output)
                                     (g.symbols ? align256(g.ns * (g.maxF + 1) * 4) : 0);
         }
+        // a mapped file's samples come back from its device buffer through page-locked memory too (one DMA per file; a copy
+        // into ordinary memory goes through the runtime's own staging in chunks, a blit kernel each: 128 surround files
+        // spent 10 ms of the job's 20 there)
+        for (size_t i : members_)
+            if (jobs_[i].error.empty() && !streamed_[i])
+                bytes[(size_t)fileDev_[i]] += align256((size_t)(window_[i].second - window_[i].first) * (size_t)jobs_[i].f.head.channels * sizeof(float));
         std::vector<char *> bases((size_t)ndev_, nullptr);
         for (int d = 0; d < ndev_; d++)
             if (bytes[(size_t)d]) bases[(size_t)d] = (char *)arena_(d, bytes[(size_t)d]);
@@ -502,6 +508,12 @@ private:
                 p.nslices = (g.maxF + p.sliceLen - 1) / p.sliceLen;
             }
         }
+        for (size_t i : members_)
+            if (jobs_[i].error.empty() && !streamed_[i]) {
+                char *&base = bases[(size_t)fileDev_[i]];
+                hostOut_[i] = (float *)base;
+                base += align256((size_t)(window_[i].second - window_[i].first) * (size_t)jobs_[i].f.head.channels * sizeof(float));
+            }
         progress_ = std::vector<std::atomic<long>>(n);
         for (auto &pr : progress_) pr.store(0, std::memory_order_relaxed);
         size_t pi = 0;                                          // slots -> pieces, destination pointers
@@ -939,7 +951,6 @@ private:
             }
             return;
         }
-        d.pcm.resize((size_t)total * ch);
         if (total == 0) return;
         nyq_ctx *ctx = (nyq_ctx *)ctxs_[(size_t)which];
         std::lock_guard<std::mutex> lk(ctxMu_[(size_t)which]);
@@ -952,8 +963,9 @@ private:
             else if (nyq_device_dup_channel(ctx, devOut_[i], ch, firstOf[(size_t)idx], c, (size_t)total) != NYQ_OK)
                 throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(ctx));
         }
-        if (nyq_device_download(ctx, d.pcm.data(), devOut_[i], (size_t)total * (size_t)ch * sizeof(float)) != NYQ_OK)
+        if (nyq_device_download(ctx, hostOut_[i], devOut_[i], (size_t)total * (size_t)ch * sizeof(float)) != NYQ_OK)
             throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(ctx));
+        d.pcm.assign(hostOut_[i], hostOut_[i] + (size_t)total * ch);
     }
 
     std::vector<FileJob> &jobs_;
@@ -976,6 +988,7 @@ private:
     std::vector<std::atomic<int>> subsLeft_;           // per file: elementary streams still on their way through the GPU
     std::vector<int> fileDev_;                         // per mapped file: the device (index into the decoder's list) of all its streams
     std::vector<float *> devOut_;                      // per mapped file: its interleaved output in that device's memory
+    std::vector<float *> hostOut_;                     // ... and where it lands in the page-locked arena on its way to the caller
     size_t nmapped_ = 0;
     std::vector<std::mutex> ctxMu_{(size_t)nfeeders_}; // per context: finishFile's device calls (a feeder owns its context otherwise)
 
