@@ -330,6 +330,7 @@ public:
     bool symbolRecords() const { return symbolRecords_; }
     bool packedRecords_ = false;        // records back to back (half the upload) or one per slot (one strided copy per window)
     size_t pieceBytes_ = kPieceBytes;
+    size_t longPieceStreams_ = 0;
     bool trace_ = false;
 
     // returns when every file of the sub-batch is decoded (or has its error set); throws if the GPU failed
@@ -493,7 +494,8 @@ private:
             // (Smaller pieces of long streams -- 4 or 8 streams, more slice chains side by side -- were measured in
             // round 4: -5 % ... +9 % of the job's wall time, profiles/r04_v_piece_ab.txt; what the job waited for was
             // the serial upload -> kernels -> download of every slice, now pipelined inside the library call.)
-            const size_t per = std::max<size_t>((size_t)std::max(1, threads_), pieceBytes_ / std::max<size_t>(1, g.maxF * g.frameBytes));
+            size_t per = std::max<size_t>((size_t)std::max(1, threads_), pieceBytes_ / std::max<size_t>(1, g.maxF * g.frameBytes));
+            if (longPieceStreams_ > 0 && g.maxF * g.frameBytes * longPieceStreams_ > (kSliceBytes * 3) / 2) per = longPieceStreams_;   // (measurement switch)
             for (size_t k0 = 0; k0 < g.ns; k0 += per) {
                 pieces_.emplace_back();
                 Piece &p = pieces_.back();
@@ -1017,6 +1019,7 @@ BatchOpusDecoder::BatchOpusDecoder(const std::vector<int> &devices) : devices_(d
     long hostWindow = -1;                                   // (measurement switch: NYQ_OPT_HOST_WINDOW of every context)
     if (const char *e = std::getenv("NYQ_HOST_WINDOW")) hostWindow = std::atol(e);
     if (const char *e = std::getenv("NYQ_HOST_PACKED")) packedRecords_ = std::atoi(e) != 0;
+    if (const char *e = std::getenv("NYQ_LONG_PIECE_STREAMS")) longPieceStreams_ = (size_t)std::max(0, std::atoi(e));
     if (const char *e = std::getenv("NYQ_PIECE_BYTES")) pieceBytes_ = (size_t)std::max<long long>(1 << 20, std::atoll(e));
     const int ndev = nyq_device_count();
     for (int d : devices_)
@@ -1184,6 +1187,7 @@ void BatchOpusDecoder::decodeImpl(const std::vector<const std::vector<uint8_t> *
         sb.symbolRecords_ = symbolRecords_;
         sb.packedRecords_ = packedRecords_;
         sb.pieceBytes_ = pieceBytes_;
+        sb.longPieceStreams_ = longPieceStreams_;
         sb.trace_ = trace_;
         sb.run();
         cpuSecs += sb.cpuSeconds;

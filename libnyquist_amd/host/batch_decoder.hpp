@@ -89,6 +89,7 @@ private:
     std::vector<int> devices_;
     size_t stagingBudget_ = (size_t)12 << 30;
     bool symbolRecords_ = true;
+    size_t longPieceStreams_ = 0;             // NYQ_LONG_PIECE_STREAMS: streams per piece of time-sliced streams (0: as many as threads)
     size_t pieceBytes_ = (size_t)24 << 20;    // of GPU input per piece of short streams (NYQ_PIECE_BYTES at construction)
     bool packedRecords_ = false;              // NYQ_HOST_PACKED=1 at construction: symbol records packed back to back
     bool trace_ = false;                      // NYQ_BATCH_TRACE=1 at construction: per-sub-batch timing on stderr
