@@ -21,9 +21,12 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <vector>
 
 #include "../../include/nyq_imdct.h"
+#include "../csrc/nyq_entropy_core.hpp"
 #include "celt_synth.hpp"
 
 namespace nyq_host {
@@ -1385,6 +1388,56 @@ int CeltDecoder::decodeFrame(const uint8_t *data, int len, int frameSize, float 
     if (dec.tell() > 8 * len) return -3;
     if (dec.error()) return -4;
     return 0;
+}
+
+// ---- the tables of the frame-per-lane entropy stage (csrc/nyq_entropy_core.hpp), from this decoder's own ------------------------
+size_t entropyTablesBytes() { return sizeof(nyq_ent::EntropyTables); }
+void fillEntropyTables(void *out) {
+    nyq_ent::EntropyTables &T = *new (out) nyq_ent::EntropyTables();
+    std::memset(&T, 0, sizeof T);
+    const CeltMode &m = mode48k();
+    for (int lm = 0; lm < 4; lm++)
+        for (int c = 1; c <= 2; c++) {
+            const AllocConst &a = allocConst(lm, c);
+            nyq_ent::EntAlloc &e = T.alloc[lm][c - 1];
+            for (int j = 0; j < kBands; j++) {
+                e.width[j] = a.width[j]; e.bins[j] = a.bins[j]; e.first[j] = a.first[j]; e.floorBits[j] = a.floorBits[j];
+                e.trimUnit[j] = a.trimUnit[j]; e.cap[j] = a.cap[j]; e.pulseCap[j] = a.pulseCap[j]; e.boostQuantum[j] = a.boostQuantum[j];
+                for (int r = 0; r < kAllocVectors; r++) e.row[r][j] = a.row[r][j];
+            }
+            e.first[kBands] = a.first[kBands];
+            e.minBits = a.minBits;
+        }
+    for (int j = 0; j <= kBands; j++) T.eBands[j] = m.eBands[j];
+    for (int j = 0; j < kBands; j++) {
+        T.logN[j] = m.logN[j];
+        T.eMeans[j] = m.eMeans[j];
+    }
+    if (m.cacheBits.size() > sizeof T.cacheBits) throw std::runtime_error("entropy tables: pulse cache larger than its place");
+    std::memcpy(T.cacheBits, m.cacheBits.data(), m.cacheBits.size());
+    const PulseLut &lut = pulseLut();
+    size_t at = 0;
+    for (int k = 0; k < 5 * kBands; k++) {
+        T.cacheIndex[k] = m.cacheIndex[(size_t)k] < 0 ? 0 : m.cacheIndex[(size_t)k];
+        const std::vector<uint8_t> &q = lut.q[k];
+        if (at + q.size() > sizeof T.lut) throw std::runtime_error("entropy tables: pulse look-up larger than its place");
+        T.lutOff[k] = (uint16_t)at;
+        T.lutLen[k] = (uint16_t)q.size();
+        if (!q.empty()) std::memcpy(T.lut + at, q.data(), q.size());
+        at += q.size();
+    }
+    // the compact U(n, k) rows (csrc/nyq_shape_kernel.hpp pvq_table_build): row k = U(0 .. len - 1, k), every entry below 2^32
+    const uint64_t *U = pvqTable();
+    size_t off = 0;
+    for (int k = 0; k < nyq_ent::kPvqInfo; k++) {
+        int len = 0;
+        while (k < kPvqTableDim && len < kPvqTableDim && U[(size_t)len * kPvqTableDim + k] < 0x100000000ull) len++;
+        T.pvq[k] = (uint32_t)off | (uint32_t)len << 16;
+        for (int n = 0; n < len; n++) {
+            if (off >= (size_t)nyq_ent::kPvqWords) throw std::runtime_error("entropy tables: codebook table larger than its place");
+            T.pvq[nyq_ent::kPvqInfo + off++] = (uint32_t)U[(size_t)n * kPvqTableDim + k];
+        }
+    }
 }
 
 }  // namespace nyq_host

@@ -86,4 +86,8 @@ private:
     Scratch scratch_;
 };
 
+// the tables of the frame-per-lane entropy stage (csrc/nyq_entropy_core.hpp: nyq_ent::EntropyTables), built from this decoder's
+size_t entropyTablesBytes();
+void fillEntropyTables(void *out);
+
 }  // namespace nyq_host
