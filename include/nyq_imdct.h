@@ -285,6 +285,49 @@ int nyq_celt_shape_dev(nyq_ctx *ctx, const void *d_sym, float *d_freq, size_t ns
 int nyq_celt_shape_lm_dev(nyq_ctx *ctx, int LM, const void *d_sym, float *d_freq, size_t nstreams, size_t nframes, int channels,
                           size_t sstride);
 
+/* ---- The entropy stage itself on the device: frames' BYTES -> symbol records --------------------------------------------------
+ * Replaces, per frame, what the reference does between ec_dec_init and the end of quant_all_bands' bit reading
+ * (celt_decoder_clean.c:462-640, quant_bands.c:427-540, rate.c:247-638, bands.c:661-1518 as far as symbols go).  Nothing a CELT
+ * frame's symbols decide depends on another frame, so every frame is one GPU lane (csrc/nyq_entropy_core.hpp); what does cross
+ * frames -- band energies, the noise seed, anti-collapse levels -- is folded in by a second kernel, a wave per stream.
+ * The records are SPREAD: head.reserved[0] = ops offset | vecs offset << 16, reserved[1] = leaves offset | level offset << 16
+ * (bytes from the record's start; zero words = the compact form above); nyq_celt_shape_* read both forms.
+ * d_tables: nyq_celt_entropy_tables_bytes() bytes, filled by the host library (nyqh_entropy_tables) and uploaded by the caller.
+ * d_payload / d_desc [nstreams][nframes]: every frame's bytes and where they are; d_sym [nstreams][nframes][slot of
+ * nyq_celt_symbol_bytes_lm(channels, LM)]; d_info [nstreams][nframes]; d_energy: scratch, NYQ_ENT_ENERGY_BYTES per frame;
+ * d_state [nstreams]: the streams' energies and final range, read unless `fresh` (streams that start here), always written.
+ * A frame whose lists outgrow the slot comes back with NYQ_ENT_TOO_LARGE and a silent record: the caller decodes it elsewhere.
+ * Asynchronous on the context stream. */
+typedef struct nyq_ent_desc {
+    unsigned int offset;             /* of the frame's first byte in d_payload */
+    unsigned short len;              /* bytes (0..1275) */
+    unsigned char channels;          /* what the packet codes (TOC stereo flag): 1 or 2 */
+    unsigned char start, end;        /* coded bands [start, end): 0 and 13 / 17 / 19 / 21 by the TOC's bandwidth */
+    unsigned char pad[3];
+} nyq_ent_desc;                      /* 12 bytes */
+#define NYQ_ENT_TRANSIENT 1
+#define NYQ_ENT_SILENCE 2
+#define NYQ_ENT_INTRA 4
+#define NYQ_ENT_ANTI_COLLAPSE 8
+#define NYQ_ENT_ERROR 16             /* the frame read past its end or named an impossible codeword (the host decoder's -3 / -4) */
+#define NYQ_ENT_TOO_LARGE 32
+typedef struct nyq_ent_info {
+    unsigned int range_final;        /* the range decoder's final state (OPUS_GET_FINAL_RANGE's CELT part) */
+    short pf_pitch;                  /* post-filter period, tapset and gain index (gain = 0.09375 * index; 0: none) */
+    unsigned char pf_tapset, pf_gain_index;
+    unsigned char flags;             /* NYQ_ENT_* */
+    unsigned char lm, channels, start, end, pad[3];
+} nyq_ent_info;                      /* 16 bytes */
+typedef struct nyq_ent_state {
+    float energy[42], log_energy[42], log_energy2[42];   /* oldBandE, oldLogE, oldLogE2 (celt_decoder_clean.c:685-718) */
+    unsigned int range, pad;
+} nyq_ent_state;
+#define NYQ_ENT_ENERGY_BYTES 672
+size_t nyq_celt_entropy_tables_bytes(void);
+int nyq_celt_entropy_dev(nyq_ctx *ctx, int LM, const void *d_tables, const unsigned char *d_payload, const nyq_ent_desc *d_desc,
+                         size_t nstreams, size_t nframes, int channels, void *d_sym, nyq_ent_info *d_info, void *d_energy,
+                         nyq_ent_state *d_state, int fresh);
+
 /* libvorbis' mdct_backward (third_party/libvorbis/src/mdct.c:397-491) on `batch` rows: n/2 coefficients
  * in, n samples out per row, n a power of two in 64..8192 (every Vorbis block size).
  * d_in [batch][n/2], d_out [batch][n].  out[i] = sum_k in[k] cos(2 pi/n (i + 1/2 + n/4)(k + 1/2)):

@@ -67,9 +67,13 @@ struct EntDesc {
 
 // the "spread" record the entropy stage writes: the three lists at fixed places, named in the head's reserved words
 // (reserved[0] = ops offset | vecs offset << 16, reserved[1] = leaves offset | level offset << 16; zero = the compact form)
-constexpr int kRecGainOff = 32, kRecOpsOff = 200, kRecMaxOps = 113, kRecMaxVecs = 44;
-constexpr int kRecVecsOff = kRecOpsOff + 16 * kRecMaxOps, kRecLeavesOff = kRecVecsOff + 24 * kRecMaxVecs;   // 2008, 3064
-constexpr int kRecMaxLeaves = 192;
+// A packet that codes one channel has at most one operation and one vector per band, one that codes two at most five and two
+// (host: Scratch::ops / vecs): the places of the lists follow the packet's channel count.
+constexpr int kRecGainOff = 32, kRecOpsOff = 200, kRecMaxLeaves = 192;
+NYQ_ED int recMaxOps(int C) { return C == 2 ? 113 : 24; }
+NYQ_ED int recMaxVecs(int C) { return C == 2 ? 44 : 22; }
+NYQ_ED int recVecsOff(int C) { return kRecOpsOff + 16 * recMaxOps(C); }
+NYQ_ED int recLeavesOff(int C) { return recVecsOff(C) + 24 * recMaxVecs(C); }                                // 3064 (two channels), 1112 (one)
 
 struct RecHead {
     uint32_t seed;
@@ -316,15 +320,18 @@ struct Frame {
     const int LM, C, N;
     uint8_t *rec;                      // the record slot
     int leafCap;
-    int spread = 0, intensity = 0;
-    int32_t remaining = 0;
-    int band = 0, tfChange = 0, fillLo = 0, fillHi = 0;
-    int nops = 0, nvecs = 0, nleaves = 0;
-    bool overflow = false;
+    int spread, intensity;
+    int32_t remaining;
+    int band, tfChange, fillLo, fillHi;
+    int nops, nvecs, nleaves;
+    int overflow;                      // which list outgrew its place (1 tree stack, 2 leaves, 4 operations, 8 vectors)
+    NYQ_ED Frame(const EntropyTables &t, const EntAlloc &k, int lm, int c, int n, uint8_t *r, int cap)
+        : T(t), K(k), LM(lm), C(c), N(n), rec(r), leafCap(cap), spread(0), intensity(0), remaining(0), band(0), tfChange(0), fillLo(0), fillHi(0),
+          nops(0), nvecs(0), nleaves(0), overflow(0) {}
 
     NYQ_ED RecOp *ops() const { return reinterpret_cast<RecOp *>(rec + kRecOpsOff); }
-    NYQ_ED RecVec *vecs() const { return reinterpret_cast<RecVec *>(rec + kRecVecsOff); }
-    NYQ_ED RecLeaf *leaves() const { return reinterpret_cast<RecLeaf *>(rec + kRecLeavesOff); }
+    NYQ_ED RecVec *vecs() const { return reinterpret_cast<RecVec *>(rec + recVecsOff(C)); }
+    NYQ_ED RecLeaf *leaves() const { return reinterpret_cast<RecLeaf *>(rec + recLeavesOff(C)); }
     NYQ_ED const uint8_t *cacheFor(int b, int lm) const { return T.cacheBits + T.cacheIndex[(lm + 1) * kBands + b]; }
     NYQ_ED int lut(int b, int lm, int bits) const {
         const int k = (lm + 1) * kBands + b, len = T.lutLen[k];
@@ -627,7 +634,7 @@ struct Frame {
                 second.remainingBefore = remaining;
                 second.mayGrow = midFirst ? a.itheta != 0 : a.itheta != 16384;
                 if (sp < 10) stack[sp++] = second;
-                else overflow = true;
+                else overflow |= 1;
                 nd = first;
                 continue;
             }
@@ -671,7 +678,7 @@ struct Frame {
                     lf.img[4 + i] = (uint16_t)(img.b >> (16 * i));
                 }
             } else {
-                overflow = true;
+                overflow |= 2;
             }
             nleaves++;
             if (sp == 0) break;
@@ -680,8 +687,8 @@ struct Frame {
     }
 
     NYQ_ED void emit(int kind, int a, int b, int n, float f0, float f1, int bnd = 0) {
-        if (nops >= kRecMaxOps) {
-            overflow = true;
+        if (nops >= recMaxOps(C)) {
+            overflow |= 4;
             return;
         }
         RecOp &o = ops()[nops++];
@@ -717,8 +724,8 @@ struct Frame {
             timeDivide++;
             tf++;
         }
-        if (nvecs >= kRecMaxVecs) {
-            overflow = true;
+        if (nvecs >= recMaxVecs(C)) {
+            overflow |= 8;
             return;
         }
         RecVec &v = vecs()[nvecs];
@@ -837,9 +844,9 @@ NYQ_ED void decode_frame(const EntropyTables &T, const uint8_t *data, int len, i
 #endif
     const int M = 1 << LM, N = M * 120;
     const int effEnd = imin(end, kBands);
-    int cap = (slotBytes - kRecLeavesOff - 2 * kBands * 4) / (int)sizeof(RecLeaf);
+    int cap = (slotBytes - recLeavesOff(C) - 2 * kBands * 4) / (int)sizeof(RecLeaf);
     cap = imax(0, imin(cap, kRecMaxLeaves));
-    Frame F{T, T.alloc[LM][C - 1], Range{}, LM, C, N, rec, cap};
+    Frame F(T, T.alloc[LM][C - 1], LM, C, N, rec, cap);
     Range &dec = F.rc;
     dec.init(data, (uint32_t)len);
     const EntAlloc &K = F.K;
@@ -977,8 +984,8 @@ NYQ_ED void decode_frame(const EntropyTables &T, const uint8_t *data, int len, i
     }
 
     RecHead *H = reinterpret_cast<RecHead *>(rec);
-    const int levelOff = kRecLeavesOff + (int)sizeof(RecLeaf) * imin(F.nleaves, cap);
-    const bool tooLarge = F.overflow || F.nleaves > cap;
+    const int levelOff = recLeavesOff(C) + (int)sizeof(RecLeaf) * imin(F.nleaves, cap);
+    const bool tooLarge = F.overflow != 0 || F.nleaves > cap;
     H->seed = 0;                                                   // (the energy pass sets it: the previous frame's final range)
     H->nleaves = (uint16_t)(silence || tooLarge ? 0 : F.nleaves);
     H->nvecs = (uint16_t)(silence || tooLarge ? 0 : F.nvecs);
@@ -989,8 +996,8 @@ NYQ_ED void decode_frame(const EntropyTables &T, const uint8_t *data, int len, i
     H->end = (uint8_t)effEnd;
     H->channels = (uint8_t)C;
     H->lm = (uint8_t)LM;
-    H->reserved[0] = (uint32_t)kRecOpsOff | (uint32_t)kRecVecsOff << 16;
-    H->reserved[1] = (uint32_t)kRecLeavesOff | (uint32_t)levelOff << 16;
+    H->reserved[0] = (uint32_t)kRecOpsOff | (uint32_t)recVecsOff(C) << 16;
+    H->reserved[1] = (uint32_t)recLeavesOff(C) | (uint32_t)levelOff << 16;
     H->reserved[2] = H->reserved[3] = 0;
     if (antiCollapseOn && !silence && !tooLarge) {
         // what of the anti-collapse level the frame itself decides: the threshold per band (the energy pass adds the rest)
@@ -1012,7 +1019,8 @@ NYQ_ED void decode_frame(const EntropyTables &T, const uint8_t *data, int len, i
     info.C = (uint8_t)C;
     info.start = (uint8_t)start;
     info.end = (uint8_t)end;
-    info.pad[0] = info.pad[1] = info.pad[2] = 0;
+    info.pad[0] = (uint8_t)F.overflow;
+    info.pad[1] = info.pad[2] = 0;
 }
 
 // ---- the energy pass: one (channel, band) of one stream, frame after frame (host: decodeFrame's energy clauses) ----------------
@@ -1021,7 +1029,11 @@ NYQ_ED void decode_frame(const EntropyTables &T, const uint8_t *data, int len, i
 struct EnergyLane {
     float E, L1, L2;                   // oldBandE, oldLogE, oldLogE2 of the host decoder
 };
+#if defined(__HIPCC__)
+NYQ_ED float exp2Ref(float x) { return (float)::exp(0.6931471805599453094 * (double)x); }
+#else
 NYQ_ED float exp2Ref(float x) { return (float)__builtin_exp(0.6931471805599453094 * (double)x); }
+#endif
 
 // returns the lane's energy after the frame's own contributions; *logGain / *level: what goes into the record (if it has them)
 NYQ_ED float energy_begin(EnergyLane &s, const EnergyLane &partner, int lane, const EntInfo &f, float prev, float q, float fine, float last,

@@ -22,7 +22,8 @@
 #include "nyq_kernels.hpp"
 #include "nyq_post_pipe.hpp"
 #include "nyq_chain_kernel.hpp"    // the one-launch frames -> PCM kernel (round 4)
-#include "nyq_shape_kernel.hpp"    // band shapes from symbol records (round 4)
+#include "nyq_shape_kernel.hpp"
+#include "nyq_entropy_kernel.hpp"    // band shapes from symbol records (round 4)
 // The round-1 post-filter kernels (one wave per channel / per stereo pair) and round 2's fused chain are measured-and-
 // rejected designs kept for A/B runs: their sources live under tools/ab/ and are compiled only into the tools' build of this
 // library (-DNYQ_AB_FORMS -Itools/ab, tools/libnyq_imdct_ab.so), selected through nyq_ctx_set_option; the product has neither.
@@ -889,6 +890,35 @@ extern "C" int nyq_celt_shape_dev(nyq_ctx *ctx, const void *d_sym, float *d_freq
 extern "C" int nyq_celt_shape_lm_dev(nyq_ctx *ctx, int LM, const void *d_sym, float *d_freq, size_t nstreams, size_t nframes, int channels,
                                      size_t sstride) {
     return shape_core(ctx, d_sym, d_freq, nstreams, nframes, channels, sstride, 0, nullptr, 0, LM);
+}
+
+// ---- the entropy stage on the device (nyq_entropy_kernel.hpp): frames' bytes -> symbol records ------------------------------------
+static_assert(sizeof(nyq_ent_desc) == sizeof(nyq_ent::EntDesc) && sizeof(nyq_ent_info) == sizeof(nyq_ent::EntInfo) &&
+                  sizeof(nyq_ent_state) == sizeof(EnergyState) && NYQ_ENT_ENERGY_BYTES == sizeof(nyq_ent::EntEnergy),
+              "include/nyq_imdct.h and the kernels agree on the entropy stage's records");
+extern "C" size_t nyq_celt_entropy_tables_bytes(void) { return sizeof(nyq_ent::EntropyTables); }
+extern "C" int nyq_celt_entropy_dev(nyq_ctx *ctx, int LM, const void *d_tables, const unsigned char *d_payload, const nyq_ent_desc *d_desc,
+                                    size_t nstreams, size_t nframes, int channels, void *d_sym, nyq_ent_info *d_info, void *d_energy,
+                                    nyq_ent_state *d_state, int fresh) {
+    if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_celt_entropy_dev: ctx is NULL");
+    if (channels != 1 && channels != 2) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_entropy_dev: symbol records carry mono and stereo streams");
+    if (LM < 0 || LM > 3) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_entropy_dev: LM must be 0..3");
+    if (nstreams == 0 || nframes == 0) return NYQ_OK;
+    if (!d_tables || !d_payload || !d_desc || !d_sym || !d_info || !d_energy || !d_state)
+        return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_entropy_dev: NULL buffer");
+    const size_t total = nstreams * nframes;
+    if (total > (size_t)0x7fffffff) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_entropy_dev: more than 2^31 frames in one call");
+    NYQ_HIP(ctx, hipSetDevice(ctx->device));
+    const long slot = (long)sym_bytes(channels, LM);
+    hipLaunchKernelGGL(celt_entropy_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, ctx->stream,
+                       static_cast<const nyq_ent::EntropyTables *>(d_tables), d_payload, reinterpret_cast<const nyq_ent::EntDesc *>(d_desc), (long)total, LM,
+                       static_cast<unsigned char *>(d_sym), slot, reinterpret_cast<nyq_ent::EntInfo *>(d_info), static_cast<nyq_ent::EntEnergy *>(d_energy));
+    NYQ_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(celt_energy_kernel, dim3((unsigned)nstreams), dim3(64), 0, ctx->stream, static_cast<const nyq_ent::EntropyTables *>(d_tables),
+                       reinterpret_cast<const nyq_ent::EntInfo *>(d_info), static_cast<const nyq_ent::EntEnergy *>(d_energy),
+                       static_cast<unsigned char *>(d_sym), slot, (long)nstreams, (long)nframes, reinterpret_cast<EnergyState *>(d_state), fresh ? 1 : 0);
+    NYQ_HIP(ctx, hipGetLastError());
+    return NYQ_OK;
 }
 
 extern "C" void *nyq_device_alloc(nyq_ctx *ctx, size_t bytes) {

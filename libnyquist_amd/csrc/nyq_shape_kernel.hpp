@@ -518,15 +518,32 @@ __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const un
         NYQ_WAVE_SYNC();                                             // (the previous frame's last reads of this slice)
         // (the counts were checked against their bounds above: the three parts are one contiguous range of the record)
         const int bops = nops * (int)sizeof(SymOp), bvecs = nvecs * (int)sizeof(SymVec), bleaves = nleaves * (int)sizeof(SymLeaf);
-        const unsigned char *rleaves = r + kSymOpsOff + bops + bvecs;
+        // a SPREAD record (the device's own entropy stage writes these: nyq_entropy_core.hpp) names where its lists are in the
+        // head's reserved words; zero = the compact form
+        int opsOff = kSymOpsOff, vecsOff = kSymOpsOff + bops, leavesOff = kSymOpsOff + bops + bvecs, levelOff = kSymOpsOff + bops + bvecs + bleaves;
+        if (H.reserved[0] | H.reserved[1]) {
+            opsOff = (int)(H.reserved[0] & 0xffffu);
+            vecsOff = (int)(H.reserved[0] >> 16);
+            leavesOff = (int)(H.reserved[1] & 0xffffu);
+            levelOff = (int)(H.reserved[1] >> 16);
+            const bool fits = !offsets && !NYQ_SHAPE_STAGE && ((opsOff | vecsOff | leavesOff | levelOff) & 7) == 0 && opsOff >= kSymOpsOff &&
+                              (size_t)(opsOff + bops) <= rec && (size_t)(vecsOff + bvecs) <= rec && (size_t)(leavesOff + bleaves) <= rec &&
+                              (size_t)(levelOff + 2 * 21 * 4) <= rec;
+            if (!fits) {
+                float4 *o4 = reinterpret_cast<float4 *>(out);
+                for (int j = lane; j < CC * N / 4; j += kWave) o4[j] = float4{0.f, 0.f, 0.f, 0.f};
+                continue;
+            }
+        }
+        const unsigned char *rleaves = r + leavesOff;
 #if NYQ_SHAPE_STAGE
         stage_words(L.rec, r + kSymOpsOff, bops + bvecs + bleaves, lane);
         const SymOp *Lops = reinterpret_cast<const SymOp *>(L.rec);
         const SymVec *Lvecs = reinterpret_cast<const SymVec *>(L.rec + bops / 4);
         const SymLeaf *Lleaves = reinterpret_cast<const SymLeaf *>(L.rec + (bops + bvecs) / 4);
 #else
-        const SymOp *Lops = reinterpret_cast<const SymOp *>(r + kSymOpsOff);
-        const SymVec *Lvecs = reinterpret_cast<const SymVec *>(r + kSymOpsOff + bops);
+        const SymOp *Lops = reinterpret_cast<const SymOp *>(r + opsOff);
+        const SymVec *Lvecs = reinterpret_cast<const SymVec *>(r + vecsOff);
         const SymLeaf *Lleaves = reinterpret_cast<const SymLeaf *>(rleaves);
 #endif
         if (lane < 2 * 21) L.masks[lane] = 0;
@@ -661,7 +678,7 @@ __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const un
         // anti-collapse (bands.c:258-351): short blocks of a transient frame that received nothing get noise at the level the
         // host computed from the energies, then the band is renormalised; the generator goes on from where the fills left it
         if (H.flags & 2) {
-            const float *level = reinterpret_cast<const float *>(rleaves + (size_t)H.nleaves * sizeof(SymLeaf));
+            const float *level = reinterpret_cast<const float *>(r + levelOff);
             const float laneLevel = lane < 2 * 21 ? level[lane] : 0.f;
             for (int i = H.start; i < H.end; i++) {
                 const int e0 = shape_edge(i, LM), n0 = (shape_edge(i + 1, LM) - e0) >> LM, M = 1 << LM;

@@ -158,6 +158,65 @@ done:
     return 0;
 }
 
+// The device's own entropy stage (include/nyq_imdct.h nyq_celt_entropy_dev): its tables, and a file's frames as it takes them --
+// every frame's bytes back to back in `payload` and a nyq_ent_desc per frame (one-stream files; the walk ends at the first frame
+// of another size, as above).  info = {channels, pre-skip, frames, frame size, payload bytes}.  Returns 0, -10 (not Ogg Opus),
+// -11 (not a one-stream CELT-only file), -12 (payload_cap too small).
+long nyqh_entropy_tables(void *out, long cap) {
+    const long need = (long)entropyTablesBytes();
+    if (!out) return need;
+    if (cap < need) return -1;
+    try {
+        fillEntropyTables(out);
+    } catch (const std::exception &e) {
+        g_capi_err = e.what();
+        return -1;
+    }
+    return need;
+}
+int nyqh_frame_table(const unsigned char *file, long size, long max_frames, unsigned char *payload, long payload_cap, nyq_ent_desc *desc, long *info) {
+    OggOpusFile f;
+    try {
+        f = parseOggOpus(file, (size_t)size);
+    } catch (const std::exception &) {
+        return -10;
+    }
+    if (f.head.mappingFamily != 0 || f.head.channels < 1 || f.head.channels > 2) return -11;
+    long nframes = 0, at = 0;
+    int frameSize = 0;
+    for (const auto &pkt : f.packets) {
+        PacketFrames pf;
+        if (!parseOpusPacket(pkt.data(), (int)pkt.size(), pf)) return -10;
+        if (pf.config < 16) return -11;
+        if (frameSize == 0) frameSize = pf.frameSize;
+        if (pf.frameSize != frameSize) break;
+        bool full = false;
+        for (const auto &fr : pf.frames) {
+            if (nframes >= max_frames) {
+                full = true;
+                break;
+            }
+            if (at + fr.second > payload_cap) return -12;
+            if (fr.second > 0) std::memcpy(payload + at, fr.first, (size_t)fr.second);
+            nyq_ent_desc &d = desc[nframes++];
+            d.offset = (unsigned)at;
+            d.len = (unsigned short)fr.second;
+            d.channels = pf.stereo ? 2 : 1;
+            d.start = 0;
+            d.end = (unsigned char)pf.bandwidthEnd;
+            d.pad[0] = d.pad[1] = d.pad[2] = 0;
+            at += fr.second;
+        }
+        if (full) break;
+    }
+    info[0] = f.head.channels;
+    info[1] = f.head.preSkip;
+    info[2] = nframes;
+    info[3] = frameSize;
+    info[4] = at;
+    return 0;
+}
+
 // NyquistIO::Load through the plugin surface (what examples/src/Main.cpp:86-154 does): returns the number
 // of float samples (channels * frames) or <0 on exception; info = {channelCount, sampleRate, frameSize,
 // lengthSeconds}.  Call twice: first with samples == NULL to learn the size.

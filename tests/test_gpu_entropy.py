@@ -1,0 +1,146 @@
+"""GPU tier: the entropy stage ON THE DEVICE (nyq_celt_entropy_dev: a frame per lane, csrc/nyq_entropy_core.hpp, then the energy
+pass, a wave per stream) against the host decoder's symbol records (CeltDecoder::decodeSymbols) on every frame of every
+one-stream file of the corpus: operation, vector and leaf lists byte for byte, head fields, log gains bit for bit, final range,
+post-filter parameters and flags; then the band shapes built from the device's records against those built from the host's."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from test_host_decoder import load_host
+
+pytestmark = pytest.mark.gpu
+
+FILES = sorted(p for p in glob.glob(os.path.join(GOLDEN, "corpus", "*.opus"))
+               if not os.path.basename(p).startswith(("surround", "unsupported_"))) + \
+    [os.path.join(GOLDEN, "short.opus"), os.path.join(GOLDEN, "sb-reverie.opus")]
+
+DESC = np.dtype([("offset", "<u4"), ("len", "<u2"), ("channels", "u1"), ("start", "u1"), ("end", "u1"), ("pad", "u1", 3)])
+INFO = np.dtype([("range_final", "<u4"), ("pf_pitch", "<i2"), ("pf_tapset", "u1"), ("pf_gain_index", "u1"), ("flags", "u1"),
+                 ("lm", "u1"), ("channels", "u1"), ("start", "u1"), ("end", "u1"), ("pad", "u1", 3)])
+HEAD = np.dtype([("seed", "<u4"), ("nleaves", "<u2"), ("nvecs", "<u2"), ("nops", "<u2"), ("flags", "u1"), ("spread", "u1"),
+                 ("start", "u1"), ("end", "u1"), ("channels", "u1"), ("lm", "u1"), ("reserved", "<u4", 4)])
+TOO_LARGE, ERROR, TRANSIENT, SILENCE = 32, 16, 1, 2
+
+
+@pytest.fixture(scope="module")
+def host():
+    H = load_host()
+    u8 = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+    H.nyqh_symbol_bytes_lm.argtypes = [C.c_int, C.c_int]
+    H.nyqh_symbol_bytes_lm.restype = C.c_long
+    H.nyqh_decode_to_symbols.argtypes = [C.c_char_p, C.c_long, C.c_long, u8] + list(H.nyqh_decode_to_freq.argtypes[4:])
+    H.nyqh_entropy_tables.argtypes = [C.c_void_p, C.c_long]
+    H.nyqh_entropy_tables.restype = C.c_long
+    H.nyqh_frame_table.argtypes = [C.c_char_p, C.c_long, C.c_long, u8, C.c_long, C.c_void_p, np.ctypeslib.ndpointer(np.int64)]
+    return H
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import libnyquist_amd as nyq
+    c = nyq.Context(0)
+    yield c
+    c.close()
+
+
+def device_records(host, ctx, raw, copies=1):
+    """(lm, channels, nf, records [copies * nf][slot] uint8, info [copies * nf], device tensor of the records)"""
+    import torch
+    need = host.nyqh_entropy_tables(None, 0)
+    assert need == ctx.lib.nyq_celt_entropy_tables_bytes()
+    tables = np.zeros(need, np.uint8)
+    assert host.nyqh_entropy_tables(tables.ctypes.data, need) == need
+    cap = 12000
+    payload = np.zeros(cap * 1275 // 4, np.uint8)
+    desc = np.zeros(cap, DESC)
+    finfo = np.zeros(8, np.int64)
+    assert host.nyqh_frame_table(raw, len(raw), cap, payload, payload.size, desc.ctypes.data, finfo) == 0
+    ch, nf, frame = int(finfo[0]), int(finfo[2]), int(finfo[3])
+    lm = {120: 0, 240: 1, 480: 2, 960: 3}[frame]
+    slot = ctx.lib.nyq_celt_symbol_bytes_lm(ch, lm)
+    dev = torch.device("cuda", 0)
+    d_tab = torch.from_numpy(tables).to(dev)
+    d_pay = torch.from_numpy(payload[:max(int(finfo[4]), 1)].copy()).to(dev)
+    d_desc = torch.from_numpy(np.tile(desc[:nf], copies).view(np.uint8)).to(dev)
+    d_sym = torch.zeros((copies * nf, slot), dtype=torch.uint8, device=dev)
+    d_info = torch.zeros((copies * nf, INFO.itemsize), dtype=torch.uint8, device=dev)
+    d_energy = torch.zeros((copies * nf, 672), dtype=torch.uint8, device=dev)
+    d_state = torch.zeros((copies, 43 * 3 * 4), dtype=torch.uint8, device=dev)
+    assert INFO.itemsize == 16 and DESC.itemsize == 12
+    torch.cuda.synchronize(dev)
+    ctx.celt_entropy_dev(lm, d_tab.data_ptr(), d_pay.data_ptr(), d_desc.data_ptr(), copies, nf, ch, d_sym.data_ptr(), d_info.data_ptr(),
+                         d_energy.data_ptr(), d_state.data_ptr(), True)
+    ctx.synchronize()
+    return lm, ch, nf, d_sym.cpu().numpy(), d_info.cpu().numpy().view(INFO).reshape(-1), d_sym
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(p) for p in FILES])
+def test_device_entropy_stage_equals_the_host_decoder(host, ctx, path):
+    import torch
+    raw = open(path, "rb").read()
+    lm, ch, nf, recs, info, d_sym = device_records(host, ctx, raw)
+    slot = recs.shape[1]
+    sym = np.zeros((nf, slot), np.uint8)
+    flags = np.zeros((nf, 4), np.int32)
+    gain = np.zeros(nf, np.float32)
+    rng = np.zeros(nf, np.uint32)
+    hinfo = np.zeros(8, np.int64)
+    assert host.nyqh_decode_to_symbols(raw, len(raw), nf, sym, flags, gain, rng, hinfo) == 0 and int(hinfo[2]) == nf
+    # what the frame says beside its record
+    assert np.array_equal(info["range_final"], rng)
+    assert np.array_equal((info["flags"] & TRANSIENT) != 0, flags[:, 0] != 0)
+    assert np.array_equal(info["pf_pitch"].astype(np.int32), flags[:, 1]) and np.array_equal(info["pf_tapset"].astype(np.int32), flags[:, 2])
+    assert np.array_equal(np.float32(.09375) * info["pf_gain_index"].astype(np.float32), gain)
+    assert not (info["flags"] & ERROR).any()
+    hh = sym[:, :32].copy().view(HEAD).reshape(-1)
+    dh = recs[:, :32].copy().view(HEAD).reshape(-1)
+    compared = too_large = 0
+    for f in range(nf):
+        if hh["flags"][f] & 1 or info["flags"][f] & TOO_LARGE:      # built by the host there / too large for the spread slot here
+            too_large += 1
+            continue
+        if hh["nops"][f] == 0:                                      # a silent frame
+            assert dh["nops"][f] == 0
+            continue
+        for k in ("seed", "nleaves", "nvecs", "nops", "flags", "spread", "start", "end", "channels", "lm"):
+            assert hh[k][f] == dh[k][f], (f, k)
+        no, nv, nl = int(hh["nops"][f]), int(hh["nvecs"][f]), int(hh["nleaves"][f])
+        o_ops, o_vecs = int(dh["reserved"][f][0]) & 0xffff, int(dh["reserved"][f][0]) >> 16
+        o_leaves, o_level = int(dh["reserved"][f][1]) & 0xffff, int(dh["reserved"][f][1]) >> 16
+        h, d = sym[f], recs[f]
+        assert np.array_equal(h[200:200 + 16 * no], d[o_ops:o_ops + 16 * no]), f
+        assert np.array_equal(h[200 + 16 * no:200 + 16 * no + 24 * nv], d[o_vecs:o_vecs + 24 * nv]), f
+        hl = 200 + 16 * no + 24 * nv
+        assert np.array_equal(h[hl:hl + 40 * nl], d[o_leaves:o_leaves + 40 * nl]), f
+        C_, end = int(hh["channels"][f]), int(hh["end"][f])
+        hg, dg = h[32:200].view(np.float32), d[32:200].view(np.float32)
+        for c in range(C_):
+            assert np.array_equal(hg[21 * c:21 * c + end].view(np.uint32), dg[21 * c:21 * c + end].view(np.uint32)), (f, c)
+        if hh["flags"][f] & 2:                                      # anti-collapse levels: a double exponential on either side
+            hv = h[hl + 40 * nl:hl + 40 * nl + 168].view(np.float32)
+            dv = d[o_level:o_level + 168].view(np.float32)
+            for c in range(C_):
+                assert np.allclose(hv[21 * c:21 * c + end], dv[21 * c:21 * c + end], rtol=2e-6, atol=0), (f, c)
+        compared += 1
+    print(f"{os.path.basename(path)}: {nf} frames, {compared} records equal, {too_large} not compared (host-built or too large for the slot)")
+    assert compared >= (nf * 3) // 4 or lm < 3 or "256k" in path
+    # the band shapes from the device's records against those from the host's
+    dev = torch.device("cuda", 0)
+    n = 120 << lm
+    keep = np.array([not (hh["flags"][f] & 1 or info["flags"][f] & TOO_LARGE) for f in range(nf)])
+    d_host = torch.from_numpy(sym).to(dev)
+    want = torch.zeros((nf, ch, n), device=dev)
+    got = torch.zeros((nf, ch, n), device=dev)
+    torch.cuda.synchronize(dev)
+    ctx.celt_shape_dev(d_host.data_ptr(), want.data_ptr(), 1, nf, ch, lm=lm)
+    ctx.celt_shape_dev(d_sym.data_ptr(), got.data_ptr(), 1, nf, ch, lm=lm)
+    ctx.synchronize()
+    w, g = want.cpu().numpy()[keep], got.cpu().numpy()[keep]
+    assert np.isfinite(g).all()
+    peak = np.abs(w).reshape(len(w), -1).max(1)
+    err = np.abs(g - w).reshape(len(w), -1).max(1)
+    assert (err <= 1e-6 * np.maximum(peak, 1.0)).all()

@@ -111,8 +111,8 @@ int main(int argc, char **argv) {
                             const uint8_t *ho = hostRec.data() + 200;
                             const uint8_t *hv = ho + 16 * hh->nops, *hl = hv + 24 * hh->nvecs, *hlev = hl + 40 * hh->nleaves;
                             if (std::memcmp(ho, coreRec.data() + kRecOpsOff, 16 * hh->nops)) { diff = true; why += " ops"; }
-                            if (std::memcmp(hv, coreRec.data() + kRecVecsOff, 24 * hh->nvecs)) { diff = true; why += " vecs"; }
-                            if (std::memcmp(hl, coreRec.data() + kRecLeavesOff, 40 * hh->nleaves)) { diff = true; why += " leaves"; }
+                            if (std::memcmp(hv, coreRec.data() + recVecsOff(C), 24 * hh->nvecs)) { diff = true; why += " vecs"; }
+                            if (std::memcmp(hl, coreRec.data() + recLeavesOff(C), 40 * hh->nleaves)) { diff = true; why += " leaves"; }
                             const float *hg = reinterpret_cast<const float *>(hostRec.data() + 32);
                             for (int c = 0; c < C; c++)
                                 for (int i = 0; i < hh->end; i++)
