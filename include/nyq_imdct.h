@@ -293,7 +293,8 @@ int nyq_celt_shape_lm_dev(nyq_ctx *ctx, int LM, const void *d_sym, float *d_freq
  * The records are SPREAD: head.reserved[0] = ops offset | vecs offset << 16, reserved[1] = leaves offset | level offset << 16
  * (bytes from the record's start; zero words = the compact form above); nyq_celt_shape_* read both forms.
  * d_tables: nyq_celt_entropy_tables_bytes() bytes, filled by the host library (nyqh_entropy_tables) and uploaded by the caller.
- * d_payload / d_desc [nstreams][nframes]: every frame's bytes and where they are; d_sym [nstreams][nframes][slot of
+ * d_payload (payload_bytes long) / d_desc [nstreams][nframes]: every frame's bytes and where they are (a descriptor that points
+ * outside the payload is an empty frame); d_sym [nstreams][nframes][slot of
  * nyq_celt_symbol_bytes_lm(channels, LM)]; d_info [nstreams][nframes]; d_energy: scratch, NYQ_ENT_ENERGY_BYTES per frame;
  * d_state [nstreams]: the streams' energies and final range, read unless `fresh` (streams that start here), always written.
  * A frame whose lists outgrow the slot comes back with NYQ_ENT_TOO_LARGE and a silent record: the caller decodes it elsewhere.
@@ -324,9 +325,13 @@ typedef struct nyq_ent_state {
 } nyq_ent_state;
 #define NYQ_ENT_ENERGY_BYTES 672
 size_t nyq_celt_entropy_tables_bytes(void);
-int nyq_celt_entropy_dev(nyq_ctx *ctx, int LM, const void *d_tables, const unsigned char *d_payload, const nyq_ent_desc *d_desc,
+int nyq_celt_entropy_dev(nyq_ctx *ctx, int LM, const void *d_tables, const unsigned char *d_payload, size_t payload_bytes, const nyq_ent_desc *d_desc,
                          size_t nstreams, size_t nframes, int channels, void *d_sym, nyq_ent_info *d_info, void *d_energy,
                          nyq_ent_state *d_state, int fresh);
+/* d_info[n] -> the per-frame arrays nyq_celt_synth_dev / nyq_celt_post_dev / nyq_celt_chain_dev take (transient flags, post-filter
+ * period, gain, tapset), on the device */
+int nyq_celt_entropy_split_dev(nyq_ctx *ctx, const nyq_ent_info *d_info, size_t n, unsigned char *d_transient, int *d_pf_pitch,
+                               float *d_pf_gain, int *d_pf_tapset);
 
 /* libvorbis' mdct_backward (third_party/libvorbis/src/mdct.c:397-491) on `batch` rows: n/2 coefficients
  * in, n samples out per row, n a power of two in 64..8192 (every Vorbis block size).

@@ -897,7 +897,7 @@ static_assert(sizeof(nyq_ent_desc) == sizeof(nyq_ent::EntDesc) && sizeof(nyq_ent
                   sizeof(nyq_ent_state) == sizeof(EnergyState) && NYQ_ENT_ENERGY_BYTES == sizeof(nyq_ent::EntEnergy),
               "include/nyq_imdct.h and the kernels agree on the entropy stage's records");
 extern "C" size_t nyq_celt_entropy_tables_bytes(void) { return sizeof(nyq_ent::EntropyTables); }
-extern "C" int nyq_celt_entropy_dev(nyq_ctx *ctx, int LM, const void *d_tables, const unsigned char *d_payload, const nyq_ent_desc *d_desc,
+extern "C" int nyq_celt_entropy_dev(nyq_ctx *ctx, int LM, const void *d_tables, const unsigned char *d_payload, size_t payload_bytes, const nyq_ent_desc *d_desc,
                                     size_t nstreams, size_t nframes, int channels, void *d_sym, nyq_ent_info *d_info, void *d_energy,
                                     nyq_ent_state *d_state, int fresh) {
     if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_celt_entropy_dev: ctx is NULL");
@@ -911,12 +911,24 @@ extern "C" int nyq_celt_entropy_dev(nyq_ctx *ctx, int LM, const void *d_tables, 
     NYQ_HIP(ctx, hipSetDevice(ctx->device));
     const long slot = (long)sym_bytes(channels, LM);
     hipLaunchKernelGGL(celt_entropy_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, ctx->stream,
-                       static_cast<const nyq_ent::EntropyTables *>(d_tables), d_payload, reinterpret_cast<const nyq_ent::EntDesc *>(d_desc), (long)total, LM,
+                       static_cast<const nyq_ent::EntropyTables *>(d_tables), d_payload, (long)payload_bytes, reinterpret_cast<const nyq_ent::EntDesc *>(d_desc), (long)total, LM,
                        static_cast<unsigned char *>(d_sym), slot, reinterpret_cast<nyq_ent::EntInfo *>(d_info), static_cast<nyq_ent::EntEnergy *>(d_energy));
     NYQ_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(celt_energy_kernel, dim3((unsigned)nstreams), dim3(64), 0, ctx->stream, static_cast<const nyq_ent::EntropyTables *>(d_tables),
                        reinterpret_cast<const nyq_ent::EntInfo *>(d_info), static_cast<const nyq_ent::EntEnergy *>(d_energy),
                        static_cast<unsigned char *>(d_sym), slot, (long)nstreams, (long)nframes, reinterpret_cast<EnergyState *>(d_state), fresh ? 1 : 0);
+    NYQ_HIP(ctx, hipGetLastError());
+    return NYQ_OK;
+}
+
+extern "C" int nyq_celt_entropy_split_dev(nyq_ctx *ctx, const nyq_ent_info *d_info, size_t n, unsigned char *d_transient, int *d_pf_pitch,
+                                          float *d_pf_gain, int *d_pf_tapset) {
+    if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_celt_entropy_split_dev: ctx is NULL");
+    if (n == 0) return NYQ_OK;
+    if (!d_info || !d_transient || !d_pf_pitch || !d_pf_gain || !d_pf_tapset) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_entropy_split_dev: NULL buffer");
+    NYQ_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(celt_entropy_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const nyq_ent::EntInfo *>(d_info), (long)n, d_transient, d_pf_pitch, d_pf_gain, d_pf_tapset);
     NYQ_HIP(ctx, hipGetLastError());
     return NYQ_OK;
 }

@@ -72,7 +72,7 @@ def device_records(host, ctx, raw, copies=1):
     d_state = torch.zeros((copies, 43 * 3 * 4), dtype=torch.uint8, device=dev)
     assert INFO.itemsize == 16 and DESC.itemsize == 12
     torch.cuda.synchronize(dev)
-    ctx.celt_entropy_dev(lm, d_tab.data_ptr(), d_pay.data_ptr(), d_desc.data_ptr(), copies, nf, ch, d_sym.data_ptr(), d_info.data_ptr(),
+    ctx.celt_entropy_dev(lm, d_tab.data_ptr(), d_pay.data_ptr(), d_pay.numel(), d_desc.data_ptr(), copies, nf, ch, d_sym.data_ptr(), d_info.data_ptr(),
                          d_energy.data_ptr(), d_state.data_ptr(), True)
     ctx.synchronize()
     return lm, ch, nf, d_sym.cpu().numpy(), d_info.cpu().numpy().view(INFO).reshape(-1), d_sym
@@ -144,3 +144,101 @@ def test_device_entropy_stage_equals_the_host_decoder(host, ctx, path):
     peak = np.abs(w).reshape(len(w), -1).max(1)
     err = np.abs(g - w).reshape(len(w), -1).max(1)
     assert (err <= 1e-6 * np.maximum(peak, 1.0)).all()
+
+
+def bytes_to_pcm_on_device(ctx, lm, ch, copies, nf, d_tab, d_pay, d_desc, bufs=None):
+    """frames' bytes -> interleaved PCM without leaving the device: entropy stage, per-frame arrays, band shapes, synthesis +
+    post-filter (fresh streams).  Returns the PCM tensor [copies][nf * (120 << lm)][ch] and the infos' tensor."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n = 120 << lm
+    slot = ctx.lib.nyq_celt_symbol_bytes_lm(ch, lm)
+    tot = copies * nf
+    if bufs is None:
+        bufs = dict(
+            sym=torch.zeros((tot, slot), dtype=torch.uint8, device=dev), info=torch.zeros((tot, 16), dtype=torch.uint8, device=dev),
+            energy=torch.zeros((tot, 672), dtype=torch.uint8, device=dev), state=torch.zeros((copies, 43 * 3 * 4), dtype=torch.uint8, device=dev),
+            tr=torch.zeros(tot, dtype=torch.uint8, device=dev), pp=torch.zeros(tot, dtype=torch.int32, device=dev),
+            pg=torch.zeros(tot, dtype=torch.float32, device=dev), pt=torch.zeros(tot, dtype=torch.int32, device=dev),
+            freq=torch.zeros((tot, ch, n), device=dev), out=torch.zeros((copies, nf * n, ch), device=dev),
+            pcm=torch.empty((copies * ch, nf * n), device=dev), work=torch.empty(ctx.celt_synth_work_floats(copies, nf, ch), device=dev))
+        torch.cuda.synchronize(dev)
+    b = bufs
+    ctx.celt_entropy_dev(lm, d_tab.data_ptr(), d_pay.data_ptr(), d_pay.numel(), d_desc.data_ptr(), copies, nf, ch, b["sym"].data_ptr(), b["info"].data_ptr(),
+                         b["energy"].data_ptr(), b["state"].data_ptr(), True)
+    ctx.celt_entropy_split_dev(b["info"].data_ptr(), tot, b["tr"].data_ptr(), b["pp"].data_ptr(), b["pg"].data_ptr(), b["pt"].data_ptr())
+    ctx.celt_shape_dev(b["sym"].data_ptr(), b["freq"].data_ptr(), copies, nf, ch, lm=lm)
+    ctx.celt_chain_dev(lm, b["freq"].data_ptr(), b["tr"].data_ptr(), b["pp"].data_ptr(), b["pg"].data_ptr(), b["pt"].data_ptr(), 0, 0, 0, 0, 0,
+                       b["out"].data_ptr(), b["pcm"].data_ptr(), b["work"].data_ptr(), copies, nf, ch)
+    return b
+
+
+def frame_table(host, raw, cap=12000):
+    payload = np.zeros(cap * 1275 // 4, np.uint8)
+    desc = np.zeros(cap, DESC)
+    finfo = np.zeros(8, np.int64)
+    assert host.nyqh_frame_table(raw, len(raw), cap, payload, payload.size, desc.ctypes.data, finfo) == 0
+    nf = int(finfo[2])
+    return int(finfo[0]), nf, {120: 0, 240: 1, 480: 2, 960: 3}[int(finfo[3])], payload[:max(int(finfo[4]), 1)].copy(), desc[:nf].copy()
+
+
+@pytest.mark.parametrize("name", ["short.opus", "corpus/mono_20ms_64k.opus", "corpus/st_10ms_20k_cx0.opus", "corpus/st_2p5ms_128k.opus"])
+def test_bytes_to_pcm_on_the_device_equals_the_host_record_path(host, ctx, name):
+    """The whole decode of a stream's frames on the device -- bytes in, PCM out, nothing but packet parsing on the host -- against
+    today's product path (host entropy stage -> symbol records -> nyq_celt_symbols_to_pcm_mapped)."""
+    import torch
+    raw = open(os.path.join(GOLDEN, name), "rb").read()
+    ch, nf, lm, payload, desc = frame_table(host, raw)
+    need = host.nyqh_entropy_tables(None, 0)
+    tables = np.zeros(need, np.uint8)
+    host.nyqh_entropy_tables(tables.ctypes.data, need)
+    dev = torch.device("cuda", 0)
+    d_tab, d_pay = torch.from_numpy(tables).to(dev), torch.from_numpy(payload).to(dev)
+    d_desc = torch.from_numpy(desc.view(np.uint8)).to(dev)
+    b = bytes_to_pcm_on_device(ctx, lm, ch, 1, nf, d_tab, d_pay, d_desc)
+    ctx.synchronize()
+    got = b["out"].cpu().numpy()
+    info = b["info"].cpu().numpy().view(INFO).reshape(-1)
+    assert not (info["flags"] & (TOO_LARGE | ERROR)).any()
+    slot = ctx.lib.nyq_celt_symbol_bytes_lm(ch, lm)
+    sym = np.zeros((nf, slot), np.uint8)
+    flags = np.zeros((nf, 4), np.int32)
+    gain = np.zeros(nf, np.float32)
+    rng = np.zeros(nf, np.uint32)
+    hinfo = np.zeros(8, np.int64)
+    assert host.nyqh_decode_to_symbols(raw, len(raw), nf, sym, flags, gain, rng, hinfo) == 0 and int(hinfo[2]) == nf
+    tr, pp, pt = (np.ascontiguousarray(flags[:, k]) for k in range(3))
+    want = ctx.celt_symbols_to_pcm(sym, tr.astype(np.uint8), pp.astype(np.int32), gain, pt.astype(np.int32), 1, nf, ch, lm=lm)
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= 1e-6                       # samples are in [-1, 1)
+
+
+@pytest.mark.timeout(120)
+def test_random_bytes_leave_the_entropy_stage_bounded(host, ctx):
+    """Frames of random bytes and random lengths (and descriptors that point outside the payload): the kernels return, twice the
+    same, every record they leave passes through the shape kernel (whose own checks bound it), nothing is NaN."""
+    import torch
+    need = host.nyqh_entropy_tables(None, 0)
+    tables = np.zeros(need, np.uint8)
+    host.nyqh_entropy_tables(tables.ctypes.data, need)
+    r = np.random.default_rng(11)
+    ns, nf = 64, 128
+    payload = r.integers(0, 256, 1 << 20, dtype=np.uint8)
+    desc = np.zeros(ns * nf, DESC)
+    desc["offset"] = r.integers(0, payload.size + 4000, ns * nf)
+    desc["len"] = r.integers(0, 1400, ns * nf)
+    desc["channels"] = r.integers(0, 4, ns * nf)
+    desc["start"] = r.integers(0, 3, ns * nf) * (r.uniform(size=ns * nf) < .1)
+    desc["end"] = r.choice([13, 17, 19, 21, 21, 21, 30, 0], ns * nf)
+    dev = torch.device("cuda", 0)
+    d_tab, d_pay = torch.from_numpy(tables).to(dev), torch.from_numpy(payload).to(dev)
+    d_desc = torch.from_numpy(desc.view(np.uint8)).to(dev)
+    for lm, ch in ((3, 2), (0, 1), (2, 2)):
+        outs = []
+        for rep in range(2):
+            b = bytes_to_pcm_on_device(ctx, lm, ch, ns, nf, d_tab, d_pay, d_desc)
+            ctx.synchronize()
+            outs.append((b["info"].cpu().numpy().copy(), b["out"].cpu().numpy().copy()))
+        assert np.array_equal(outs[0][0], outs[1][0])
+        assert np.isfinite(outs[0][1]).all()
+        assert np.array_equal(outs[0][1], outs[1][1])

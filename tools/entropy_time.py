@@ -51,7 +51,7 @@ torch.cuda.synchronize(dev)
 best = 1e9
 for rep in range(6):
     t0 = time.perf_counter()
-    ctx.celt_entropy_dev(lm, d_tab.data_ptr(), d_pay.data_ptr(), d_desc.data_ptr(), copies, nf, ch, d_sym.data_ptr(), d_info.data_ptr(),
+    ctx.celt_entropy_dev(lm, d_tab.data_ptr(), d_pay.data_ptr(), d_pay.numel(), d_desc.data_ptr(), copies, nf, ch, d_sym.data_ptr(), d_info.data_ptr(),
                          d_energy.data_ptr(), d_state.data_ptr(), True)
     ctx.synchronize()
     dt = time.perf_counter() - t0
