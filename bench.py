@@ -31,7 +31,8 @@ Secondary keys on the same line (rank 0; the last two at N = 1 only, never part 
                         on the same host threads (that leg's cpu_baseline); .long_streams (32 x the 224 s file of BASELINE
                         config 4), .surround_7_1 (config 5's shape: 8 channels in 5 elementary streams),
                         .band_shapes_on_device (the entropy stage's two halves on real packets: host symbol stage
-                        frames/s/thread, celt_shape_kernel frames/s)
+                        frames/s/thread, celt_shape_kernel frames/s), .entropy_stage_on_device (the entropy stage itself as a
+                        kernel, a frame per lane: frames/s, and bytes -> PCM device-resident)
 """
 import argparse
 import ctypes
@@ -154,6 +155,76 @@ def band_shapes_leg(ctx, dev, rep=8):
             "device_GBps_records_in_plus_freq_out": n * (rec + 7680) / best / 1e9,
             "note": "latency-bound integer / LDS work (DESIGN 4.10), not a roofline kernel: what matters is device_frames_per_sec against "
                     "host threads x host_symbol_stage_frames_per_sec_per_thread"}
+
+
+def device_entropy_leg(ctx, dev, streams=32):
+    """The entropy stage ON THE DEVICE (nyq_celt_entropy_dev: a frame per lane, then the energy pass, a wave per stream) on
+    `streams` copies of sb-reverie.opus' 11184 frames as independent streams, bytes resident in HBM: frames/s of the stage, and of
+    bytes -> PCM through it (entropy + band shapes + synthesis + post-filter, device-resident).  An operator-level capability this
+    round: the batch decoder (opus_file_decode) still runs the entropy stage on the host."""
+    import torch
+    H = ctypes.CDLL(os.path.join(ROOT, "libnyquist_amd", "libnyquist_host.so"))
+    u8 = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+    H.nyqh_entropy_tables.argtypes = [ctypes.c_void_p, ctypes.c_long]
+    H.nyqh_entropy_tables.restype = ctypes.c_long
+    H.nyqh_frame_table.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_long, u8, ctypes.c_long, ctypes.c_void_p, np.ctypeslib.ndpointer(np.int64)]
+    raw = open(os.path.join(ROOT, "tests", "golden", "sb-reverie.opus"), "rb").read()
+    need = H.nyqh_entropy_tables(None, 0)
+    tables = np.zeros(need, np.uint8)
+    if H.nyqh_entropy_tables(tables.ctypes.data, need) != need:
+        raise RuntimeError("nyqh_entropy_tables failed")
+    cap = 11200
+    payload = np.zeros(cap * 320, np.uint8)
+    desc = np.zeros(cap * 12, np.uint8)
+    finfo = np.zeros(8, np.int64)
+    t0 = time.perf_counter()
+    if H.nyqh_frame_table(raw, len(raw), cap, payload, payload.size, desc.ctypes.data, finfo) != 0:
+        raise RuntimeError("nyqh_frame_table failed")
+    walk = time.perf_counter() - t0
+    nf, nbytes = int(finfo[2]), int(finfo[4])
+    slot = int(ctx.lib.nyq_celt_symbol_bytes_lm(2, 3))
+    tot = streams * nf
+    d_tab = torch.from_numpy(tables).to(dev)
+    d_pay = torch.from_numpy(payload[:nbytes].copy()).to(dev)
+    d_desc = torch.from_numpy(np.tile(desc[:nf * 12], streams)).to(dev)
+    Z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+    d_sym, d_info, d_energy, d_state = Z((tot, slot), torch.uint8), Z((tot, 16), torch.uint8), Z((tot, 672), torch.uint8), Z((streams, 516), torch.uint8)
+    d_tr, d_pp, d_pg, d_pt = Z(tot, torch.uint8), Z(tot, torch.int32), Z(tot, torch.float32), Z(tot, torch.int32)
+    d_freq, d_out = Z((tot, 2, 960), torch.float32), Z((streams, nf * 960, 2), torch.float32)
+    d_pcm = torch.empty((streams * 2, nf * 960), device=dev)
+    d_work = torch.empty(ctx.celt_synth_work_floats(streams, nf, 2), device=dev)
+    torch.cuda.synchronize(dev)
+
+    def entropy():
+        ctx.celt_entropy_dev(3, d_tab.data_ptr(), d_pay.data_ptr(), d_pay.numel(), d_desc.data_ptr(), streams, nf, 2, d_sym.data_ptr(),
+                             d_info.data_ptr(), d_energy.data_ptr(), d_state.data_ptr(), True)
+
+    def rest():
+        ctx.celt_entropy_split_dev(d_info.data_ptr(), tot, d_tr.data_ptr(), d_pp.data_ptr(), d_pg.data_ptr(), d_pt.data_ptr())
+        ctx.celt_shape_dev(d_sym.data_ptr(), d_freq.data_ptr(), streams, nf, 2)
+        ctx.celt_chain_dev(3, d_freq.data_ptr(), d_tr.data_ptr(), d_pp.data_ptr(), d_pg.data_ptr(), d_pt.data_ptr(), 0, 0, 0, 0, 0,
+                           d_out.data_ptr(), d_pcm.data_ptr(), d_work.data_ptr(), streams, nf, 2)
+
+    best_e = best_all = 1e9
+    for rep in range(4):
+        t0 = time.perf_counter()
+        entropy()
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        rest()
+        ctx.synchronize()
+        t2 = time.perf_counter()
+        if rep:
+            best_e, best_all = min(best_e, t1 - t0), min(best_all, t2 - t0)
+    flags = d_info.cpu().numpy()[:, 8]
+    return {"file": "sb-reverie.opus", "streams": streams, "frames": tot, "payload_bytes_per_frame": nbytes / nf, "record_slot_bytes": slot,
+            "entropy_stage_ms": best_e * 1e3, "entropy_stage_frames_per_sec": tot / best_e,
+            "bytes_to_pcm_device_resident_ms": best_all * 1e3, "bytes_to_pcm_device_resident_frames_per_sec": tot / best_all,
+            "frames_too_large_for_a_record": int((flags & 32 != 0).sum()), "frames_in_error": int((flags & 16 != 0).sum()),
+            "host_packet_walk_ms_per_file_one_thread": walk * 1e3, "checksum_stream0": float(d_out[0].double().abs().sum().item()),
+            "note": "parity: tests/test_gpu_entropy.py (records equal to the host decoder's on every corpus frame; bytes -> PCM within 1e-6 "
+                    "of the host-record path); compare entropy_stage_frames_per_sec with opus_file_decode.long_streams.frames_per_sec, "
+                    "which the host entropy stage bounds"}
 
 
 def opus_file_decode_leg(count=256, fname="short.opus", n=421930, threads=None, device=0, channels=2):
@@ -578,6 +649,10 @@ def main():
                     file_leg["band_shapes_on_device"] = band_shapes_leg(ctx, dev)
                 except Exception as e:  # noqa: BLE001
                     file_leg["band_shapes_on_device"] = {"error": str(e)}
+                try:
+                    file_leg["entropy_stage_on_device"] = device_entropy_leg(ctx, dev)
+                except Exception as e:  # noqa: BLE001
+                    file_leg["entropy_stage_on_device"] = {"error": str(e)}
                 file_leg["surround_7_1"] = opus_file_decode_leg(128, os.path.join("corpus", "surround71_20ms_320k.opus"), 384000, threads=thr,
                                                                 device=local_rank, channels=8)
         except Exception as e:
