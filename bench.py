@@ -182,7 +182,7 @@ def device_entropy_leg(ctx, dev, streams=32):
         raise RuntimeError("nyqh_frame_table failed")
     walk = time.perf_counter() - t0
     nf, nbytes = int(finfo[2]), int(finfo[4])
-    slot = int(ctx.lib.nyq_celt_symbol_bytes_lm(2, 3))
+    slot = int(ctx.lib.nyq_celt_entropy_slot_bytes(2, 3))           # holds any frame (the records never leave the device)
     tot = streams * nf
     d_tab = torch.from_numpy(tables).to(dev)
     d_pay = torch.from_numpy(payload[:nbytes].copy()).to(dev)
@@ -197,11 +197,11 @@ def device_entropy_leg(ctx, dev, streams=32):
 
     def entropy():
         ctx.celt_entropy_dev(3, d_tab.data_ptr(), d_pay.data_ptr(), d_pay.numel(), d_desc.data_ptr(), streams, nf, 2, d_sym.data_ptr(),
-                             d_info.data_ptr(), d_energy.data_ptr(), d_state.data_ptr(), True)
+                             d_info.data_ptr(), d_energy.data_ptr(), d_state.data_ptr(), True, slot)
 
     def rest():
         ctx.celt_entropy_split_dev(d_info.data_ptr(), tot, d_tr.data_ptr(), d_pp.data_ptr(), d_pg.data_ptr(), d_pt.data_ptr())
-        ctx.celt_shape_dev(d_sym.data_ptr(), d_freq.data_ptr(), streams, nf, 2)
+        ctx.celt_shape_slots_dev(3, d_sym.data_ptr(), slot, d_freq.data_ptr(), streams, nf, 2)
         ctx.celt_chain_dev(3, d_freq.data_ptr(), d_tr.data_ptr(), d_pp.data_ptr(), d_pg.data_ptr(), d_pt.data_ptr(), 0, 0, 0, 0, 0,
                            d_out.data_ptr(), d_pcm.data_ptr(), d_work.data_ptr(), streams, nf, 2)
 

@@ -297,7 +297,7 @@ int nyq_celt_shape_lm_dev(nyq_ctx *ctx, int LM, const void *d_sym, float *d_freq
  * outside the payload is an empty frame); d_sym [nstreams][nframes][slot of
  * nyq_celt_symbol_bytes_lm(channels, LM)]; d_info [nstreams][nframes]; d_energy: scratch, NYQ_ENT_ENERGY_BYTES per frame;
  * d_state [nstreams]: the streams' energies and final range, read unless `fresh` (streams that start here), always written.
- * A frame whose lists outgrow the slot comes back with NYQ_ENT_TOO_LARGE and a silent record: the caller decodes it elsewhere.
+ * A frame whose lists outgrow the slot comes back with NYQ_ENT_TOO_LARGE and a silent record (never with the full slot below).
  * Asynchronous on the context stream. */
 typedef struct nyq_ent_desc {
     unsigned int offset;             /* of the frame's first byte in d_payload */
@@ -326,8 +326,14 @@ typedef struct nyq_ent_state {
 #define NYQ_ENT_ENERGY_BYTES 672
 size_t nyq_celt_entropy_tables_bytes(void);
 int nyq_celt_entropy_dev(nyq_ctx *ctx, int LM, const void *d_tables, const unsigned char *d_payload, size_t payload_bytes, const nyq_ent_desc *d_desc,
-                         size_t nstreams, size_t nframes, int channels, void *d_sym, nyq_ent_info *d_info, void *d_energy,
+                         size_t nstreams, size_t nframes, int channels, void *d_sym, size_t slot_bytes, nyq_ent_info *d_info, void *d_energy,
                          nyq_ent_state *d_state, int fresh);
+/* slot_bytes: bytes per record slot of d_sym; 0 = nyq_celt_symbol_bytes_lm(channels, LM) (what the host-record entry points take:
+ * busy frames come back NYQ_ENT_TOO_LARGE); nyq_celt_entropy_slot_bytes(channels, LM) holds ANY frame (the records never leave
+ * the device, so the larger slot costs HBM only) -- read such records with nyq_celt_shape_slots_dev. */
+size_t nyq_celt_entropy_slot_bytes(int channels, int LM);
+int nyq_celt_shape_slots_dev(nyq_ctx *ctx, int LM, const void *d_sym, size_t slot_bytes, float *d_freq, size_t nstreams, size_t nframes,
+                             int channels);
 /* d_info[n] -> the per-frame arrays nyq_celt_synth_dev / nyq_celt_post_dev / nyq_celt_chain_dev take (transient flags, post-filter
  * period, gain, tapset), on the device */
 int nyq_celt_entropy_split_dev(nyq_ctx *ctx, const nyq_ent_info *d_info, size_t n, unsigned char *d_transient, int *d_pf_pitch,

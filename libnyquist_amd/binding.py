@@ -31,7 +31,7 @@ EXPORTS = [
     "nyq_celt_chain_mapped_dev", "nyq_device_alloc", "nyq_device_free", "nyq_device_zero", "nyq_device_download", "nyq_device_dup_channel",
     "nyq_celt_frames_to_pcm_mapped", "nyq_celt_symbol_bytes", "nyq_celt_shape_dev", "nyq_celt_symbols_to_pcm_mapped",
     "nyq_celt_symbols_packed_to_pcm_mapped", "nyq_celt_symbol_bytes_lm", "nyq_celt_shape_lm_dev",
-    "nyq_celt_entropy_tables_bytes", "nyq_celt_entropy_dev", "nyq_celt_entropy_split_dev",
+    "nyq_celt_entropy_tables_bytes", "nyq_celt_entropy_dev", "nyq_celt_entropy_split_dev", "nyq_celt_entropy_slot_bytes", "nyq_celt_shape_slots_dev",
     "nyq_celt_frames_to_pcm", "nyq_celt_frames_to_pcm_window", "nyq_celt_state_floats", "nyq_vorbis_imdct_batch_dev", "nyq_vorbis_imdct_batch",
     "nyq_ifft_batch", "nyq_imdct_batch", "nyq_imdct_chain", "nyq_host_alloc", "nyq_host_free",
     "processMDCTCuda", "processMDCTCudaB1C2", "processMDCTCudaB8C2", "cleanupCudaBuffers", "printCudaVersion", "nyq_shim_set_error_handler",
@@ -158,7 +158,10 @@ def load(path=None):
     L.nyq_celt_symbol_bytes_lm.restype = sz
     L.nyq_celt_shape_lm_dev.argtypes = [vp, i, vp, vp, sz, sz, i, sz]
     L.nyq_celt_entropy_tables_bytes.restype = sz
-    L.nyq_celt_entropy_dev.argtypes = [vp, i, vp, vp, sz, vp, sz, sz, i, vp, vp, vp, vp, i]
+    L.nyq_celt_entropy_dev.argtypes = [vp, i, vp, vp, sz, vp, sz, sz, i, vp, sz, vp, vp, vp, i]
+    L.nyq_celt_entropy_slot_bytes.argtypes = [i, i]
+    L.nyq_celt_entropy_slot_bytes.restype = sz
+    L.nyq_celt_shape_slots_dev.argtypes = [vp, i, vp, sz, vp, sz, sz, i]
     L.nyq_celt_entropy_split_dev.argtypes = [vp, vp, sz, vp, vp, vp, vp]
     L.nyq_device_copy_forms.restype = i
     L.nyq_device_copy_form_name.argtypes = [i]
@@ -364,11 +367,16 @@ class Context:
         """symbol records -> freq[] (the band shapes of frames of 120 << lm samples built on the device)."""
         self._ck(self.lib.nyq_celt_shape_lm_dev(self.h, lm, C.c_void_p(d_sym), C.c_void_p(d_freq), nstreams, nframes, channels, sstride))
 
-    def celt_entropy_dev(self, lm, d_tables, d_payload, payload_bytes, d_desc, nstreams, nframes, channels, d_sym, d_info, d_energy, d_state, fresh=True):
+    def celt_entropy_dev(self, lm, d_tables, d_payload, payload_bytes, d_desc, nstreams, nframes, channels, d_sym, d_info, d_energy, d_state, fresh=True,
+                         slot_bytes=0):
         """frames' bytes -> spread symbol records, a frame per lane, then the energy pass, a wave per stream (nyq_celt_entropy_dev)"""
         V = lambda p: C.c_void_p(p or 0)
         self._ck(self.lib.nyq_celt_entropy_dev(self.h, lm, V(d_tables), V(d_payload), payload_bytes, V(d_desc), nstreams, nframes, channels, V(d_sym),
-                                               V(d_info), V(d_energy), V(d_state), 1 if fresh else 0))
+                                               slot_bytes, V(d_info), V(d_energy), V(d_state), 1 if fresh else 0))
+
+    def celt_shape_slots_dev(self, lm, d_sym, slot_bytes, d_freq, nstreams, nframes, channels):
+        """records in slots of slot_bytes (nyq_celt_entropy_slot_bytes: any frame fits) -> freq[]"""
+        self._ck(self.lib.nyq_celt_shape_slots_dev(self.h, lm, C.c_void_p(d_sym), slot_bytes, C.c_void_p(d_freq), nstreams, nframes, channels))
 
     def celt_entropy_split_dev(self, d_info, n, d_transient, d_pf_pitch, d_pf_gain, d_pf_tapset):
         V = lambda p: C.c_void_p(p or 0)

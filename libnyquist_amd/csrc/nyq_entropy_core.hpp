@@ -69,11 +69,17 @@ struct EntDesc {
 // (reserved[0] = ops offset | vecs offset << 16, reserved[1] = leaves offset | level offset << 16; zero = the compact form)
 // A packet that codes one channel has at most one operation and one vector per band, one that codes two at most five and two
 // (host: Scratch::ops / vecs): the places of the lists follow the packet's channel count.
-constexpr int kRecGainOff = 32, kRecOpsOff = 200, kRecMaxLeaves = 192;
+constexpr int kRecGainOff = 32, kRecOpsOff = 200, kRecMaxLeaves = 416;   // (= the shape kernel's kSymMaxLeaves)
 NYQ_ED int recMaxOps(int C) { return C == 2 ? 113 : 24; }
 NYQ_ED int recMaxVecs(int C) { return C == 2 ? 44 : 22; }
 NYQ_ED int recVecsOff(int C) { return kRecOpsOff + 16 * recMaxOps(C); }
 NYQ_ED int recLeavesOff(int C) { return recVecsOff(C) + 24 * recMaxVecs(C); }                                // 3064 (two channels), 1112 (one)
+// the slot that holds ANY frame of 120 << LM samples in `channels` channels: a vector of n bins has at most min(2^(LM+1), n/2)
+// leaves -- 42, 84, 104, 208 per channel for LM 0..3 (the 48 kHz mode's band widths)
+NYQ_ED int recFullSlot(int channels, int LM) {
+    const int perChannel = LM == 0 ? 42 : LM == 1 ? 84 : LM == 2 ? 104 : 208;
+    return (recLeavesOff(2) + 40 * perChannel * (channels == 2 ? 2 : 1) + 2 * kBands * 4 + 15) & ~15;
+}
 
 struct RecHead {
     uint32_t seed;

@@ -843,10 +843,12 @@ extern "C" size_t nyq_celt_symbol_bytes_lm(int channels, int LM) {
 // d_off: records packed back to back inside each stream's region of sstride slots, d_off[stream * ostride + frame] = byte offset
 // of the frame's record from the region's start; null: one record per slot of nyq_celt_symbol_bytes
 static int shape_core(nyq_ctx *ctx, const void *d_sym, float *d_freq, size_t nstreams, size_t nframes, int channels, size_t sstride,
-                      size_t fstride = 0, const unsigned *d_off = nullptr, size_t ostride = 0, int LM = 3) {
+                      size_t fstride = 0, const unsigned *d_off = nullptr, size_t ostride = 0, int LM = 3, size_t slot = 0) {
     if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_celt_shape_dev: ctx is NULL");
     if (channels != 1 && channels != 2) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_shape_dev: symbol records carry mono and stereo streams");
     if (LM < 0 || LM > 3) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_shape_dev: LM must be 0..3");
+    if (slot == 0) slot = sym_bytes(channels, LM);
+    if (slot < 256 || slot > 65520 || slot % 16 != 0) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_shape_dev: a record slot is 256..65520 bytes, a multiple of 16");
     if (nstreams == 0 || nframes == 0) return NYQ_OK;
     if (!d_sym || !d_freq) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_shape_dev: NULL buffer");
     if (sstride == 0) sstride = nframes;
@@ -871,7 +873,7 @@ static int shape_core(nyq_ctx *ctx, const void *d_sym, float *d_freq, size_t nst
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(kWave * kShapeWaves), 0, ctx->stream, static_cast<const unsigned char *>(d_sym), d_freq,
                            ctx->d_pvq, (long)nstreams, (long)nframes, channels, (long)sstride, (long)fstride, d_off, (long)(ostride ? ostride : nframes),
-                           d_next);
+                           d_next, (long)slot);
     };
     switch (LM) {
     case 0: launch(celt_shape_kernel<0>); break;
@@ -891,14 +893,21 @@ extern "C" int nyq_celt_shape_lm_dev(nyq_ctx *ctx, int LM, const void *d_sym, fl
                                      size_t sstride) {
     return shape_core(ctx, d_sym, d_freq, nstreams, nframes, channels, sstride, 0, nullptr, 0, LM);
 }
+extern "C" int nyq_celt_shape_slots_dev(nyq_ctx *ctx, int LM, const void *d_sym, size_t slot_bytes, float *d_freq, size_t nstreams, size_t nframes,
+                                        int channels) {
+    return shape_core(ctx, d_sym, d_freq, nstreams, nframes, channels, 0, 0, nullptr, 0, LM, slot_bytes);
+}
 
 // ---- the entropy stage on the device (nyq_entropy_kernel.hpp): frames' bytes -> symbol records ------------------------------------
 static_assert(sizeof(nyq_ent_desc) == sizeof(nyq_ent::EntDesc) && sizeof(nyq_ent_info) == sizeof(nyq_ent::EntInfo) &&
                   sizeof(nyq_ent_state) == sizeof(EnergyState) && NYQ_ENT_ENERGY_BYTES == sizeof(nyq_ent::EntEnergy),
               "include/nyq_imdct.h and the kernels agree on the entropy stage's records");
 extern "C" size_t nyq_celt_entropy_tables_bytes(void) { return sizeof(nyq_ent::EntropyTables); }
+extern "C" size_t nyq_celt_entropy_slot_bytes(int channels, int LM) {
+    return (channels == 1 || channels == 2) && LM >= 0 && LM <= 3 ? (size_t)nyq_ent::recFullSlot(channels, LM) : 0;
+}
 extern "C" int nyq_celt_entropy_dev(nyq_ctx *ctx, int LM, const void *d_tables, const unsigned char *d_payload, size_t payload_bytes, const nyq_ent_desc *d_desc,
-                                    size_t nstreams, size_t nframes, int channels, void *d_sym, nyq_ent_info *d_info, void *d_energy,
+                                    size_t nstreams, size_t nframes, int channels, void *d_sym, size_t slot_bytes, nyq_ent_info *d_info, void *d_energy,
                                     nyq_ent_state *d_state, int fresh) {
     if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_celt_entropy_dev: ctx is NULL");
     if (channels != 1 && channels != 2) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_entropy_dev: symbol records carry mono and stereo streams");
@@ -909,7 +918,8 @@ extern "C" int nyq_celt_entropy_dev(nyq_ctx *ctx, int LM, const void *d_tables, 
     const size_t total = nstreams * nframes;
     if (total > (size_t)0x7fffffff) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_entropy_dev: more than 2^31 frames in one call");
     NYQ_HIP(ctx, hipSetDevice(ctx->device));
-    const long slot = (long)sym_bytes(channels, LM);
+    const long slot = (long)(slot_bytes ? slot_bytes : sym_bytes(channels, LM));
+    if (slot < 256 || slot > 65520 || slot % 16 != 0) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_entropy_dev: a record slot is 256..65520 bytes, a multiple of 16");
     hipLaunchKernelGGL(celt_entropy_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, ctx->stream,
                        static_cast<const nyq_ent::EntropyTables *>(d_tables), d_payload, (long)payload_bytes, reinterpret_cast<const nyq_ent::EntDesc *>(d_desc), (long)total, LM,
                        static_cast<unsigned char *>(d_sym), slot, reinterpret_cast<nyq_ent::EntInfo *>(d_info), static_cast<nyq_ent::EntEnergy *>(d_energy));

@@ -59,7 +59,9 @@ constexpr int kSymN = 960;                                           // bins per
 constexpr int kSymOpsOff = 32 + 42 * 4;                              // 200
 constexpr int kSymFreqOff = 32;
 constexpr int kSymSlotFixed = 3072;
-constexpr int kSymMaxLeaves = 192;                                   // 96 per channel: what the body holds
+// leaves of one frame: a vector of n bins splits into at most min(2^(LM+1), n/2) leaves -- 208 per channel at LM 3 (8 bands x 4,
+// 4 x 8, 9 x 16), fewer below; the host's records stop at 192 (what their slot holds), the device's own entropy stage at this
+constexpr int kSymMaxLeaves = 416;
 constexpr int kPvqDim = 178;                                         // U(n, k) for n, k < 178 (the widest band has 176 bins)
 // slot of a frame of 120 << LM samples: the 20 ms slot, 5/8 of it at 10 ms, and a floor below that (the fixed parts, a
 // leaf or two per vector: short frames spend their bits on fewer, not smaller, records); never less than head + freq[]
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const un
                                                                         const unsigned *__restrict__ pvq, long nstreams, long nframes,
                                                                         int channels, long sstride, long fstride,
                                                                         const unsigned *__restrict__ offsets, long ostride,
-                                                                        unsigned *__restrict__ next_frame) {
+                                                                        unsigned *__restrict__ next_frame, long slot) {
 #pragma clang fp contract(off)
     __shared__ __attribute__((aligned(16))) ShapeWaveLds wl[kShapeWaves];
     __shared__ unsigned tab[kPvqInfo + kPvqWords];
@@ -474,7 +476,7 @@ __global__ __launch_bounds__(kWave *kShapeWaves) void celt_shape_kernel(const un
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
     ShapeWaveLds &L = wl[wv];
     float *X = L.f, *norm = L.f + 2 * kSymN, *work = norm + kShapeNorm, *tmp = work + 192;
-    const size_t rec = sym_bytes(channels, LM);
+    const size_t rec = (size_t)slot;                                 // bytes per record slot (sym_bytes(channels, LM) unless the caller says otherwise)
     constexpr int N = 120 << LM;                                     // bins per channel
     const long total = nstreams * nframes;
     // Frames are handed out by a counter (zeroed before the launch), not dealt in advance: a transient frame costs several

@@ -47,8 +47,9 @@ def ctx():
     c.close()
 
 
-def device_records(host, ctx, raw, copies=1):
-    """(lm, channels, nf, records [copies * nf][slot] uint8, info [copies * nf], device tensor of the records)"""
+def device_records(host, ctx, raw, copies=1, full_slot=True):
+    """(lm, channels, nf, records [copies * nf][slot] uint8, info [copies * nf], device tensor of the records); full_slot: slots
+    that hold any frame (nyq_celt_entropy_slot_bytes), else the host records' slot (busy frames come back TOO_LARGE)"""
     import torch
     need = host.nyqh_entropy_tables(None, 0)
     assert need == ctx.lib.nyq_celt_entropy_tables_bytes()
@@ -61,7 +62,7 @@ def device_records(host, ctx, raw, copies=1):
     assert host.nyqh_frame_table(raw, len(raw), cap, payload, payload.size, desc.ctypes.data, finfo) == 0
     ch, nf, frame = int(finfo[0]), int(finfo[2]), int(finfo[3])
     lm = {120: 0, 240: 1, 480: 2, 960: 3}[frame]
-    slot = ctx.lib.nyq_celt_symbol_bytes_lm(ch, lm)
+    slot = ctx.lib.nyq_celt_entropy_slot_bytes(ch, lm) if full_slot else ctx.lib.nyq_celt_symbol_bytes_lm(ch, lm)
     dev = torch.device("cuda", 0)
     d_tab = torch.from_numpy(tables).to(dev)
     d_pay = torch.from_numpy(payload[:max(int(finfo[4]), 1)].copy()).to(dev)
@@ -73,7 +74,7 @@ def device_records(host, ctx, raw, copies=1):
     assert INFO.itemsize == 16 and DESC.itemsize == 12
     torch.cuda.synchronize(dev)
     ctx.celt_entropy_dev(lm, d_tab.data_ptr(), d_pay.data_ptr(), d_pay.numel(), d_desc.data_ptr(), copies, nf, ch, d_sym.data_ptr(), d_info.data_ptr(),
-                         d_energy.data_ptr(), d_state.data_ptr(), True)
+                         d_energy.data_ptr(), d_state.data_ptr(), True, slot)
     ctx.synchronize()
     return lm, ch, nf, d_sym.cpu().numpy(), d_info.cpu().numpy().view(INFO).reshape(-1), d_sym
 
@@ -83,7 +84,8 @@ def test_device_entropy_stage_equals_the_host_decoder(host, ctx, path):
     import torch
     raw = open(path, "rb").read()
     lm, ch, nf, recs, info, d_sym = device_records(host, ctx, raw)
-    slot = recs.shape[1]
+    assert not (info["flags"] & TOO_LARGE).any()                      # (the full slot holds any frame)
+    slot = ctx.lib.nyq_celt_symbol_bytes_lm(ch, lm)                   # the host records' slot
     sym = np.zeros((nf, slot), np.uint8)
     flags = np.zeros((nf, 4), np.int32)
     gain = np.zeros(nf, np.float32)
@@ -100,7 +102,7 @@ def test_device_entropy_stage_equals_the_host_decoder(host, ctx, path):
     dh = recs[:, :32].copy().view(HEAD).reshape(-1)
     compared = too_large = 0
     for f in range(nf):
-        if hh["flags"][f] & 1 or info["flags"][f] & TOO_LARGE:      # built by the host there / too large for the spread slot here
+        if hh["flags"][f] & 1:                                      # built by the host there (more leaves than a host record holds)
             too_large += 1
             continue
         if hh["nops"][f] == 0:                                      # a silent frame
@@ -126,24 +128,27 @@ def test_device_entropy_stage_equals_the_host_decoder(host, ctx, path):
             for c in range(C_):
                 assert np.allclose(hv[21 * c:21 * c + end], dv[21 * c:21 * c + end], rtol=2e-6, atol=0), (f, c)
         compared += 1
-    print(f"{os.path.basename(path)}: {nf} frames, {compared} records equal, {too_large} not compared (host-built or too large for the slot)")
+    print(f"{os.path.basename(path)}: {nf} frames, {compared} records equal, {too_large} have no host record (built on the host there)")
     assert compared >= (nf * 3) // 4 or lm < 3 or "256k" in path
     # the band shapes from the device's records against those from the host's
     dev = torch.device("cuda", 0)
     n = 120 << lm
-    keep = np.array([not (hh["flags"][f] & 1 or info["flags"][f] & TOO_LARGE) for f in range(nf)])
     d_host = torch.from_numpy(sym).to(dev)
     want = torch.zeros((nf, ch, n), device=dev)
     got = torch.zeros((nf, ch, n), device=dev)
     torch.cuda.synchronize(dev)
     ctx.celt_shape_dev(d_host.data_ptr(), want.data_ptr(), 1, nf, ch, lm=lm)
-    ctx.celt_shape_dev(d_sym.data_ptr(), got.data_ptr(), 1, nf, ch, lm=lm)
+    ctx.celt_shape_slots_dev(lm, d_sym.data_ptr(), recs.shape[1], got.data_ptr(), 1, nf, ch)
     ctx.synchronize()
-    w, g = want.cpu().numpy()[keep], got.cpu().numpy()[keep]
+    # (every frame: where the host built freq[] itself -- its record carries it -- the device's record stands against the host's
+    # floats, a few ulp per band apart as in test_gpu_shape; elsewhere both sides ran the same kernel on equal records)
+    w, g = want.cpu().numpy(), got.cpu().numpy()
     assert np.isfinite(g).all()
     peak = np.abs(w).reshape(len(w), -1).max(1)
     err = np.abs(g - w).reshape(len(w), -1).max(1)
-    assert (err <= 1e-6 * np.maximum(peak, 1.0)).all()
+    built = (hh["flags"] & 1) != 0
+    assert (err[~built] <= 1e-6 * np.maximum(peak[~built], 1.0)).all()
+    assert (err[built] <= 2e-6 * np.maximum(peak[built], 1.0)).all()
 
 
 def bytes_to_pcm_on_device(ctx, lm, ch, copies, nf, d_tab, d_pay, d_desc, bufs=None):
@@ -152,7 +157,7 @@ def bytes_to_pcm_on_device(ctx, lm, ch, copies, nf, d_tab, d_pay, d_desc, bufs=N
     import torch
     dev = torch.device("cuda", 0)
     n = 120 << lm
-    slot = ctx.lib.nyq_celt_symbol_bytes_lm(ch, lm)
+    slot = ctx.lib.nyq_celt_entropy_slot_bytes(ch, lm)
     tot = copies * nf
     if bufs is None:
         bufs = dict(
@@ -165,9 +170,9 @@ def bytes_to_pcm_on_device(ctx, lm, ch, copies, nf, d_tab, d_pay, d_desc, bufs=N
         torch.cuda.synchronize(dev)
     b = bufs
     ctx.celt_entropy_dev(lm, d_tab.data_ptr(), d_pay.data_ptr(), d_pay.numel(), d_desc.data_ptr(), copies, nf, ch, b["sym"].data_ptr(), b["info"].data_ptr(),
-                         b["energy"].data_ptr(), b["state"].data_ptr(), True)
+                         b["energy"].data_ptr(), b["state"].data_ptr(), True, slot)
     ctx.celt_entropy_split_dev(b["info"].data_ptr(), tot, b["tr"].data_ptr(), b["pp"].data_ptr(), b["pg"].data_ptr(), b["pt"].data_ptr())
-    ctx.celt_shape_dev(b["sym"].data_ptr(), b["freq"].data_ptr(), copies, nf, ch, lm=lm)
+    ctx.celt_shape_slots_dev(lm, b["sym"].data_ptr(), slot, b["freq"].data_ptr(), copies, nf, ch)
     ctx.celt_chain_dev(lm, b["freq"].data_ptr(), b["tr"].data_ptr(), b["pp"].data_ptr(), b["pg"].data_ptr(), b["pt"].data_ptr(), 0, 0, 0, 0, 0,
                        b["out"].data_ptr(), b["pcm"].data_ptr(), b["work"].data_ptr(), copies, nf, ch)
     return b
@@ -182,7 +187,18 @@ def frame_table(host, raw, cap=12000):
     return int(finfo[0]), nf, {120: 0, 240: 1, 480: 2, 960: 3}[int(finfo[3])], payload[:max(int(finfo[4]), 1)].copy(), desc[:nf].copy()
 
 
-@pytest.mark.parametrize("name", ["short.opus", "corpus/mono_20ms_64k.opus", "corpus/st_10ms_20k_cx0.opus", "corpus/st_2p5ms_128k.opus"])
+def test_frames_too_large_for_a_host_sized_slot_are_flagged(host, ctx):
+    """With the host records' slot (slot_bytes = 0) a busy frame does not fit: it is flagged and its record is a silent frame."""
+    raw = open(os.path.join(GOLDEN, "corpus", "st_20ms_256k_cbr.opus"), "rb").read()
+    lm, ch, nf, recs, info, _ = device_records(host, ctx, raw, full_slot=False)
+    big = (info["flags"] & TOO_LARGE) != 0
+    assert 5 <= big.sum() < nf
+    dh = recs[:, :32].copy().view(HEAD).reshape(-1)
+    assert (dh["nops"][big] == 0).all() and (dh["nops"][~big] > 0).all()
+
+
+@pytest.mark.parametrize("name", ["short.opus", "corpus/mono_20ms_64k.opus", "corpus/st_10ms_20k_cx0.opus", "corpus/st_2p5ms_128k.opus",
+                                  "corpus/st_20ms_256k_cbr.opus", "corpus/st_5ms_96k.opus"])
 def test_bytes_to_pcm_on_the_device_equals_the_host_record_path(host, ctx, name):
     """The whole decode of a stream's frames on the device -- bytes in, PCM out, nothing but packet parsing on the host -- against
     today's product path (host entropy stage -> symbol records -> nyq_celt_symbols_to_pcm_mapped)."""
@@ -210,7 +226,7 @@ def test_bytes_to_pcm_on_the_device_equals_the_host_record_path(host, ctx, name)
     tr, pp, pt = (np.ascontiguousarray(flags[:, k]) for k in range(3))
     want = ctx.celt_symbols_to_pcm(sym, tr.astype(np.uint8), pp.astype(np.int32), gain, pt.astype(np.int32), 1, nf, ch, lm=lm)
     assert np.isfinite(got).all()
-    assert np.abs(got - want).max() <= 1e-6                       # samples are in [-1, 1)
+    assert np.abs(got - want).max() <= 2e-6                       # samples are in [-1, 1)
 
 
 @pytest.mark.timeout(120)

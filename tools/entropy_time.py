@@ -37,7 +37,7 @@ finfo = np.zeros(8, np.int64)
 assert H.nyqh_frame_table(raw, len(raw), cap, payload, payload.size, desc.ctypes.data, finfo) == 0
 ch, nf, frame = int(finfo[0]), int(finfo[2]), int(finfo[3])
 lm = {120: 0, 240: 1, 480: 2, 960: 3}[frame]
-slot = ctx.lib.nyq_celt_symbol_bytes_lm(ch, lm)
+slot = ctx.lib.nyq_celt_entropy_slot_bytes(ch, lm)
 dev = torch.device("cuda", 0)
 d_tab = torch.from_numpy(tables).to(dev)
 d_pay = torch.from_numpy(payload[:int(finfo[4])].copy()).to(dev)
@@ -52,7 +52,7 @@ best = 1e9
 for rep in range(6):
     t0 = time.perf_counter()
     ctx.celt_entropy_dev(lm, d_tab.data_ptr(), d_pay.data_ptr(), d_pay.numel(), d_desc.data_ptr(), copies, nf, ch, d_sym.data_ptr(), d_info.data_ptr(),
-                         d_energy.data_ptr(), d_state.data_ptr(), True)
+                         d_energy.data_ptr(), d_state.data_ptr(), True, slot)
     ctx.synchronize()
     dt = time.perf_counter() - t0
     if rep:
@@ -60,7 +60,7 @@ for rep in range(6):
 bshape = 1e9
 for rep in range(4):
     t0 = time.perf_counter()
-    ctx.celt_shape_dev(d_sym.data_ptr(), d_freq.data_ptr(), copies, nf, ch, lm=lm)
+    ctx.celt_shape_slots_dev(lm, d_sym.data_ptr(), slot, d_freq.data_ptr(), copies, nf, ch)
     ctx.synchronize()
     dt = time.perf_counter() - t0
     if rep:

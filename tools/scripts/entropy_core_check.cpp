@@ -43,7 +43,7 @@ int main(int argc, char **argv) {
         for (auto &l : lanes) l = EnergyLane{0.f, -28.f, -28.f};
         uint32_t prevRange = 0;
         long fileBad = 0, fileFrames = 0;
-        std::vector<uint8_t> hostRec(CeltDecoder::symbolBytes(2, 3)), coreRec(CeltDecoder::symbolBytes(2, 3));
+        std::vector<uint8_t> hostRec(CeltDecoder::symbolBytes(2, 3)), coreRec((size_t)recFullSlot(2, 3));   // (the core: a slot that holds any frame)
         for (const auto &pkt : of.packets) {
             PacketFrames pf;
             if (!parseOpusPacket(pkt.data(), (int)pkt.size(), pf)) return 3;
@@ -57,7 +57,7 @@ int main(int argc, char **argv) {
                 const int C = pf.stereo ? 2 : 1;
                 dec.setEndBand(pf.bandwidthEnd);
                 dec.setStreamChannels(C);
-                const size_t slot = CeltDecoder::symbolBytes(CC, LM);
+                const size_t slot = (size_t)recFullSlot(CC, LM);
                 for (const auto &fr : pf.frames) {
                     CeltFrame hi;
                     std::memset(hostRec.data(), 0, hostRec.size());
