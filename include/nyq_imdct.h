@@ -321,8 +321,10 @@ typedef struct nyq_ent_info {
 } nyq_ent_info;                      /* 16 bytes */
 typedef struct nyq_ent_state {
     float energy[42], log_energy[42], log_energy2[42];   /* oldBandE, oldLogE, oldLogE2 (celt_decoder_clean.c:685-718) */
-    unsigned int range, pad;
-} nyq_ent_state;
+    unsigned int range;
+    unsigned int valid;                                   /* set by the call; anything else on entry (e.g. zeros): the stream starts here */
+    unsigned int errors;                                  /* frames in error so far */
+} nyq_ent_state;                                          /* 516 bytes */
 #define NYQ_ENT_ENERGY_BYTES 672
 size_t nyq_celt_entropy_tables_bytes(void);
 int nyq_celt_entropy_dev(nyq_ctx *ctx, int LM, const void *d_tables, const unsigned char *d_payload, size_t payload_bytes, const nyq_ent_desc *d_desc,
@@ -338,6 +340,19 @@ int nyq_celt_shape_slots_dev(nyq_ctx *ctx, int LM, const void *d_sym, size_t slo
  * period, gain, tapset), on the device */
 int nyq_celt_entropy_split_dev(nyq_ctx *ctx, const nyq_ent_info *d_info, size_t n, unsigned char *d_transient, int *d_pf_pitch,
                                float *d_pf_gain, int *d_pf_tapset);
+
+/* The host-buffer form: nyq_celt_symbols_to_pcm_mapped with the frames' BYTES in place of records -- `bytes`
+ * [nstreams][frames_per_stream][nyq_celt_byte_slot()] (a frame's bytes at the start of its slot), `frame_words`
+ * [nstreams][frames_per_stream] = len | coded channels << 16 | end band << 24.  The entropy stage, the band shapes, synthesis
+ * and post-filter all run on the device; per-frame arrays are not passed (they come out of the entropy stage).  `state`
+ * (nyq_celt_state_floats, zero = streams that start here) carries the entropy stage's state too: its last
+ * nstreams * sizeof(nyq_ent_state) / 4 floats are a nyq_ent_state per stream (`errors` = frames in error so far).
+ * nyq_ctx_set_entropy_tables(ctx, block of nyqh_entropy_tables, its size) once per context before the first call. */
+int nyq_ctx_set_entropy_tables(nyq_ctx *ctx, const void *host_tables, size_t bytes);
+size_t nyq_celt_byte_slot(void);
+int nyq_celt_bytes_to_pcm_mapped(nyq_ctx *ctx, int LM, const unsigned char *bytes, const unsigned *frame_words, float *out,
+                                 const nyq_out_desc *desc, float *state, size_t nstreams, size_t nframes, int channels,
+                                 size_t frames_per_stream);
 
 /* libvorbis' mdct_backward (third_party/libvorbis/src/mdct.c:397-491) on `batch` rows: n/2 coefficients
  * in, n samples out per row, n a power of two in 64..8192 (every Vorbis block size).

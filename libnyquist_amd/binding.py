@@ -32,6 +32,7 @@ EXPORTS = [
     "nyq_celt_frames_to_pcm_mapped", "nyq_celt_symbol_bytes", "nyq_celt_shape_dev", "nyq_celt_symbols_to_pcm_mapped",
     "nyq_celt_symbols_packed_to_pcm_mapped", "nyq_celt_symbol_bytes_lm", "nyq_celt_shape_lm_dev",
     "nyq_celt_entropy_tables_bytes", "nyq_celt_entropy_dev", "nyq_celt_entropy_split_dev", "nyq_celt_entropy_slot_bytes", "nyq_celt_shape_slots_dev",
+    "nyq_ctx_set_entropy_tables", "nyq_celt_byte_slot", "nyq_celt_bytes_to_pcm_mapped",
     "nyq_celt_frames_to_pcm", "nyq_celt_frames_to_pcm_window", "nyq_celt_state_floats", "nyq_vorbis_imdct_batch_dev", "nyq_vorbis_imdct_batch",
     "nyq_ifft_batch", "nyq_imdct_batch", "nyq_imdct_chain", "nyq_host_alloc", "nyq_host_free",
     "processMDCTCuda", "processMDCTCudaB1C2", "processMDCTCudaB8C2", "cleanupCudaBuffers", "printCudaVersion", "nyq_shim_set_error_handler",
@@ -163,6 +164,9 @@ def load(path=None):
     L.nyq_celt_entropy_slot_bytes.restype = sz
     L.nyq_celt_shape_slots_dev.argtypes = [vp, i, vp, sz, vp, sz, sz, i]
     L.nyq_celt_entropy_split_dev.argtypes = [vp, vp, sz, vp, vp, vp, vp]
+    L.nyq_ctx_set_entropy_tables.argtypes = [vp, vp, sz]
+    L.nyq_celt_byte_slot.restype = sz
+    L.nyq_celt_bytes_to_pcm_mapped.argtypes = [vp, i, vp, vp, vp, vp, vp, sz, sz, i, sz]
     L.nyq_device_copy_forms.restype = i
     L.nyq_device_copy_form_name.argtypes = [i]
     L.nyq_device_copy_form_name.restype = C.c_char_p
@@ -381,6 +385,16 @@ class Context:
     def celt_entropy_split_dev(self, d_info, n, d_transient, d_pf_pitch, d_pf_gain, d_pf_tapset):
         V = lambda p: C.c_void_p(p or 0)
         self._ck(self.lib.nyq_celt_entropy_split_dev(self.h, V(d_info), n, V(d_transient), V(d_pf_pitch), V(d_pf_gain), V(d_pf_tapset)))
+
+    def set_entropy_tables(self, tables):
+        self._ck(self.lib.nyq_ctx_set_entropy_tables(self.h, _np(tables), tables.nbytes))
+
+    def celt_bytes_to_pcm(self, lm, frame_bytes, frame_words, nstreams, nframes, channels, state=None):
+        """frames' bytes [nstreams][nframes][nyq_celt_byte_slot] + words [nstreams][nframes] -> interleaved PCM (entropy stage on the device)"""
+        out = np.empty((nstreams, nframes * (120 << lm), channels), np.float32)
+        self._ck(self.lib.nyq_celt_bytes_to_pcm_mapped(self.h, lm, _np(frame_bytes), _np(frame_words), _np(out), None, _np(state), nstreams, nframes,
+                                                      channels, nframes))
+        return out
 
     def celt_symbols_to_pcm(self, sym, transient, pf_pitch, pf_gain, pf_tapset, nstreams, nframes, channels, state=None, lm=3):
         """host symbol records [nstreams][nframes][nyq_celt_symbol_bytes_lm] -> interleaved PCM [nstreams][nframes * (120 << lm)][channels]"""

@@ -20,22 +20,37 @@ namespace nyq {
 __global__ __launch_bounds__(64) void celt_entropy_kernel(const nyq_ent::EntropyTables *__restrict__ T, const unsigned char *__restrict__ payload,
                                                           long payload_bytes, const nyq_ent::EntDesc *__restrict__ desc, long total, int LM,
                                                           unsigned char *__restrict__ records, long slot, nyq_ent::EntInfo *__restrict__ info,
-                                                          nyq_ent::EntEnergy *__restrict__ energy) {
+                                                          nyq_ent::EntEnergy *__restrict__ energy, long pslot) {
     const long u = (long)blockIdx.x * 64 + threadIdx.x;
     if (u >= total) return;
-    const nyq_ent::EntDesc d = desc[u];
+    nyq_ent::EntDesc d;
+    if (pslot > 0) {                                                 // frame u's bytes in slot u of `pslot` bytes; desc = words: len | C << 16 | end << 24
+        const unsigned w = reinterpret_cast<const unsigned *>(desc)[u];
+        d.offset = 0;
+        d.len = (uint16_t)(w & 0xffffu);
+        d.C = (uint8_t)(w >> 16 & 0xff);
+        d.start = 0;
+        d.end = (uint8_t)(w >> 24);
+        if ((long)d.len > pslot) d.len = 0;
+        payload += u * pslot;
+    } else {
+        d = desc[u];
+    }
     nyq_ent::EntInfo fi;
     const int C = d.C == 2 ? 2 : 1, end = d.end > 21 ? 21 : d.end, start = d.start < end ? d.start : 0;
     int len = d.len > 1275 ? 1275 : d.len;
-    if ((long)d.offset + len > payload_bytes) len = 0;              // (a descriptor that points outside the payload: an empty frame)
+    if (pslot == 0 && (long)d.offset + len > payload_bytes) len = 0;   // (a descriptor that points outside the payload: an empty frame)
     nyq_ent::decode_frame(*T, payload + d.offset, len, LM, C, start, end, records + u * slot, (int)slot, fi, energy[u]);
     info[u] = fi;
 }
 
 struct EnergyState {                   // what a stream carries from one call to the next
     float E[42], L1[42], L2[42];
-    unsigned range, pad;
+    unsigned range;
+    unsigned valid;                    // kEnergyValid once a call has written it (anything else: a stream that starts here)
+    unsigned errors;                   // frames in error so far (NYQ_ENT_ERROR), counted over the calls
 };
+constexpr unsigned kEnergyValid = 0x0E17A7E5u;
 
 constexpr int kEnergyChunk = 32;       // frames staged per round: 32 x (672 + 16 + 8) bytes of LDS
 
@@ -54,13 +69,15 @@ __global__ __launch_bounds__(64) void celt_energy_kernel(const nyq_ent::EntropyT
     const bool live = lane < 42;
     const int l = live ? lane : 0, band = l >= 21 ? l - 21 : l, partnerLane = l >= 21 ? l - 21 : l + 21;
     nyq_ent::EnergyLane st{0.f, -28.f, -28.f};
-    unsigned range = 0;
-    if (!fresh) {
+    unsigned range = 0, errors = 0;
+    if (!fresh && state[s].valid == kEnergyValid) {
         st.E = state[s].E[l];
         st.L1 = state[s].L1[l];
         st.L2 = state[s].L2[l];
         range = state[s].range;
+        errors = state[s].errors;
     }
+    __syncthreads();                                                 // (every lane has read the state before lane 0 rewrites it)
     const float eMean = T->eMeans[band];
     const long u0 = s * nframes;
     for (long base = 0; base < nframes; base += kEnergyChunk) {
@@ -104,6 +121,7 @@ __global__ __launch_bounds__(64) void celt_energy_kernel(const nyq_ent::EntropyT
             }
             if (lane == 0) reinterpret_cast<nyq_ent::RecHead *>(r)->seed = range;
             range = fi.rangeFinal;
+            errors += (fi.flags & nyq_ent::kEntError) ? 1u : 0u;
         }
     }
     if (live) {
@@ -111,7 +129,11 @@ __global__ __launch_bounds__(64) void celt_energy_kernel(const nyq_ent::EntropyT
         state[s].L1[l] = st.L1;
         state[s].L2[l] = st.L2;
     }
-    if (lane == 0) state[s].range = range;
+    if (lane == 0) {
+        state[s].range = range;
+        state[s].valid = kEnergyValid;
+        state[s].errors = errors;
+    }
 }
 
 // what the synthesis and the post-filter take per frame (transient flag, post-filter period / gain / tapset), from the infos

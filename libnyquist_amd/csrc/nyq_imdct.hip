@@ -72,6 +72,7 @@ struct nyq_ctx {
     int opt_chain_overlap = 0;           // windows: post-filter of window k on a second stream beside the synthesis of window k + 1
     hipStream_t s_post = nullptr;        // (created on first use)
     unsigned *d_pvq = nullptr;           // U(n, k) of the pulse-vector codebooks (shape kernel; created on first use)
+    void *d_ent_tables = nullptr;        // the entropy stage's tables (nyq_ctx_set_entropy_tables)
     float *d_vtab = nullptr;             // Vorbis rotation + twiddle tables of every block size, one allocation
     size_t vrot_off[12] = {0}, vtw_off[12] = {0};   // float offsets by log2(n/4)
     std::string err;
@@ -261,6 +262,7 @@ extern "C" void nyq_ctx_destroy(nyq_ctx *ctx) {
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_vtab) (void)hipFree(ctx->d_vtab);
     if (ctx->d_pvq) (void)hipFree(ctx->d_pvq);
+    if (ctx->d_ent_tables) (void)hipFree(ctx->d_ent_tables);
     if (ctx->d_trig) (void)hipFree(ctx->d_trig);
     if (ctx->d_window) (void)hipFree(ctx->d_window);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -906,6 +908,21 @@ extern "C" size_t nyq_celt_entropy_tables_bytes(void) { return sizeof(nyq_ent::E
 extern "C" size_t nyq_celt_entropy_slot_bytes(int channels, int LM) {
     return (channels == 1 || channels == 2) && LM >= 0 && LM <= 3 ? (size_t)nyq_ent::recFullSlot(channels, LM) : 0;
 }
+constexpr size_t kByteSlot = 1280;                                   // a frame's bytes in the host-buffer form (a CELT frame is at most 1275)
+// frames' bytes -> spread records + infos (+ the per-frame arrays of the chain), all on the context stream
+static int entropy_core(nyq_ctx *ctx, int LM, const void *d_tables, const unsigned char *d_payload, size_t payload_bytes, const void *d_desc, size_t pslot,
+                        size_t nstreams, size_t nframes, unsigned char *d_sym, size_t slot, nyq_ent::EntInfo *d_info, nyq_ent::EntEnergy *d_energy,
+                        EnergyState *d_state, int fresh) {
+    const size_t total = nstreams * nframes;
+    hipLaunchKernelGGL(celt_entropy_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, ctx->stream,
+                       static_cast<const nyq_ent::EntropyTables *>(d_tables), d_payload, (long)payload_bytes, static_cast<const nyq_ent::EntDesc *>(d_desc), (long)total, LM,
+                       d_sym, (long)slot, d_info, d_energy, (long)pslot);
+    NYQ_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(celt_energy_kernel, dim3((unsigned)nstreams), dim3(64), 0, ctx->stream, static_cast<const nyq_ent::EntropyTables *>(d_tables),
+                       d_info, d_energy, d_sym, (long)slot, (long)nstreams, (long)nframes, d_state, fresh ? 1 : 0);
+    NYQ_HIP(ctx, hipGetLastError());
+    return NYQ_OK;
+}
 extern "C" int nyq_celt_entropy_dev(nyq_ctx *ctx, int LM, const void *d_tables, const unsigned char *d_payload, size_t payload_bytes, const nyq_ent_desc *d_desc,
                                     size_t nstreams, size_t nframes, int channels, void *d_sym, size_t slot_bytes, nyq_ent_info *d_info, void *d_energy,
                                     nyq_ent_state *d_state, int fresh) {
@@ -915,19 +932,20 @@ extern "C" int nyq_celt_entropy_dev(nyq_ctx *ctx, int LM, const void *d_tables, 
     if (nstreams == 0 || nframes == 0) return NYQ_OK;
     if (!d_tables || !d_payload || !d_desc || !d_sym || !d_info || !d_energy || !d_state)
         return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_entropy_dev: NULL buffer");
-    const size_t total = nstreams * nframes;
-    if (total > (size_t)0x7fffffff) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_entropy_dev: more than 2^31 frames in one call");
+    if (nstreams * nframes > (size_t)0x7fffffff) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_entropy_dev: more than 2^31 frames in one call");
     NYQ_HIP(ctx, hipSetDevice(ctx->device));
-    const long slot = (long)(slot_bytes ? slot_bytes : sym_bytes(channels, LM));
+    const size_t slot = slot_bytes ? slot_bytes : sym_bytes(channels, LM);
     if (slot < 256 || slot > 65520 || slot % 16 != 0) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_entropy_dev: a record slot is 256..65520 bytes, a multiple of 16");
-    hipLaunchKernelGGL(celt_entropy_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, ctx->stream,
-                       static_cast<const nyq_ent::EntropyTables *>(d_tables), d_payload, (long)payload_bytes, reinterpret_cast<const nyq_ent::EntDesc *>(d_desc), (long)total, LM,
-                       static_cast<unsigned char *>(d_sym), slot, reinterpret_cast<nyq_ent::EntInfo *>(d_info), static_cast<nyq_ent::EntEnergy *>(d_energy));
-    NYQ_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(celt_energy_kernel, dim3((unsigned)nstreams), dim3(64), 0, ctx->stream, static_cast<const nyq_ent::EntropyTables *>(d_tables),
-                       reinterpret_cast<const nyq_ent::EntInfo *>(d_info), static_cast<const nyq_ent::EntEnergy *>(d_energy),
-                       static_cast<unsigned char *>(d_sym), slot, (long)nstreams, (long)nframes, reinterpret_cast<EnergyState *>(d_state), fresh ? 1 : 0);
-    NYQ_HIP(ctx, hipGetLastError());
+    return entropy_core(ctx, LM, d_tables, d_payload, payload_bytes, d_desc, 0, nstreams, nframes, static_cast<unsigned char *>(d_sym), slot,
+                        reinterpret_cast<nyq_ent::EntInfo *>(d_info), static_cast<nyq_ent::EntEnergy *>(d_energy), reinterpret_cast<EnergyState *>(d_state), fresh);
+}
+// the tables of the entropy stage, kept by the context for the host-buffer form below (host_tables: nyqh_entropy_tables' block)
+extern "C" int nyq_ctx_set_entropy_tables(nyq_ctx *ctx, const void *host_tables, size_t bytes) {
+    if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_ctx_set_entropy_tables: ctx is NULL");
+    if (!host_tables || bytes != sizeof(nyq_ent::EntropyTables)) return fail(ctx, NYQ_ERR_INVALID, "nyq_ctx_set_entropy_tables: the block is nyq_celt_entropy_tables_bytes() long");
+    NYQ_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d_ent_tables) NYQ_HIP(ctx, hipMalloc(&ctx->d_ent_tables, bytes));
+    NYQ_HIP(ctx, hipMemcpy(ctx->d_ent_tables, host_tables, bytes, hipMemcpyHostToDevice));
     return NYQ_OK;
 }
 
@@ -1241,7 +1259,7 @@ extern "C" int nyq_celt_synth(nyq_ctx *ctx, int LM, const float *freq, const uns
 
 extern "C" size_t nyq_celt_state_floats(size_t nstreams, int channels) {
     const size_t nsc = nstreams * (size_t)(channels > 0 ? channels : 0);
-    return nsc * (NYQ_HALF_OV + kPostHist + 1) + nstreams * 6;
+    return nsc * (NYQ_HALF_OV + kPostHist + 1) + nstreams * 6 + nstreams * (sizeof(EnergyState) / sizeof(float));   // (+ the entropy stage's state: the bytes form)
 }
 
 // Host arrays may be windows into longer per-stream arrays: consecutive streams are `hstride` frames apart
@@ -1276,18 +1294,23 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
                               const int *pf_pitch, const float *pf_gain, const int *pf_tapset, float *out,
                               float *state, size_t nstreams, size_t nframes, int channels, size_t hstride,
                               const nyq_out_desc *desc = nullptr, const unsigned char *sym = nullptr, const unsigned *offsets = nullptr,
-                              size_t sym_stream_bytes = 0) {
+                              size_t sym_stream_bytes = 0, const unsigned *fdesc = nullptr) {
+    // fdesc != NULL: `sym` holds the frames' BYTES (slots of kByteSlot) and fdesc a word per frame (len | channels << 16 | end band
+    // << 24): the entropy stage runs on the device (nyq_entropy_kernel.hpp) and the per-frame arrays come from it
+    const bool bytes = fdesc != nullptr;
     if (!ctx) return fail(nullptr, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm: ctx is NULL");
     if (LM < 0 || LM > 3) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm: LM must be 0..3");
     if (channels < 1 || channels > 255) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm: channels must be 1..255");
     if (nstreams == 0 || nframes == 0) return NYQ_OK;
     bool all_mapped = desc != nullptr;
     for (size_t k = 0; desc && k < nstreams; k++) all_mapped = all_mapped && desc[k].base != nullptr;
-    if ((!freq && !sym) || !pf_pitch || !pf_gain || !pf_tapset || (!out && !all_mapped))
+    if ((!freq && !sym) || (!bytes && (!pf_pitch || !pf_gain || !pf_tapset)) || (!out && !all_mapped))
         return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm: NULL buffer");
+    if (bytes && (!sym || offsets)) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_bytes_to_pcm_mapped: NULL buffer");
+    if (bytes && !ctx->d_ent_tables) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_bytes_to_pcm_mapped: nyq_ctx_set_entropy_tables first");
     if (desc && channels > 2) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_frames_to_pcm_mapped: output descriptors serve mono and stereo streams");
     if (sym && channels > 2) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_symbols_to_pcm_mapped: symbol records carry mono and stereo streams");
-    const size_t rec = sym ? sym_bytes(channels, LM) : 0;
+    const size_t rec = bytes ? (size_t)nyq_ent::recFullSlot(channels, LM) : sym ? sym_bytes(channels, LM) : 0;   // a record on the device
     NYQ_HIP(ctx, hipSetDevice(ctx->device));
     const size_t N = (size_t)120 << LM, nsc = nstreams * (size_t)channels, nfr = nstreams * nframes;
     const size_t n_x = round16f(nsc * nframes * N), n_w = round16f(nyq_celt_synth_work_floats(nstreams, nframes, channels)),
@@ -1299,7 +1322,11 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
     const size_t n_sy = sym ? round16f(nfr * rec / sizeof(float)) : 0;
     const size_t n_dw = desc ? kHostMaxWindows * n_ds : 0;           // (the time-window form: a set of records per window)
     const size_t n_of = offsets ? round16f(nfr + 2 * nstreams) : 0;  // packed records: nframes + 1 device offsets per stream, its first
-    int rc = need_scratch(ctx, (3 * n_x + n_w + 3 * n_p + n_t + n_ov + n_hi + n_de + 2 * n_pf + n_ds + n_sy + n_dw + n_of) * sizeof(float));
+    // the bytes form: the frames' bytes, their descriptor words, infos, energy deltas, the entropy stage's state
+    const size_t n_by = bytes ? round16f(nfr * kByteSlot / sizeof(float)) : 0, n_fd = bytes ? round16f(nfr) : 0, n_in = bytes ? round16f(nfr * 4) : 0,
+                 n_en = bytes ? round16f(nfr * sizeof(nyq_ent::EntEnergy) / sizeof(float)) : 0,
+                 n_es = bytes ? round16f(nstreams * sizeof(EnergyState) / sizeof(float)) : 0;
+    int rc = need_scratch(ctx, (3 * n_x + n_w + 3 * n_p + n_t + n_ov + n_hi + n_de + 2 * n_pf + n_ds + n_sy + n_dw + n_of + n_by + n_fd + n_in + n_en + n_es) * sizeof(float));
     if (rc != NYQ_OK) return rc;
     float *d_x = ctx->d_scratch, *d_pcm = d_x + n_x, *d_out = d_pcm + n_x, *d_w = d_out + n_x, *d_pg = d_w + n_w;
     int *d_pp = reinterpret_cast<int *>(d_pg + n_p), *d_pt = d_pp + n_p;
@@ -1309,6 +1336,32 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
     nyq_out_desc *d_ds = desc ? reinterpret_cast<nyq_out_desc *>(d_pfo + n_pf) : nullptr;
     unsigned char *d_sy = sym ? reinterpret_cast<unsigned char *>(d_pfo + n_pf + n_ds) : nullptr;
     unsigned *d_of = offsets ? reinterpret_cast<unsigned *>(d_pfo + n_pf + n_ds + n_sy + n_dw) : nullptr;
+    float *d_ent0 = d_pfo + n_pf + n_ds + n_sy + n_dw + n_of;
+    unsigned char *d_by = reinterpret_cast<unsigned char *>(d_ent0);
+    unsigned *d_fd = reinterpret_cast<unsigned *>(d_ent0 + n_by);
+    nyq_ent::EntInfo *d_in = reinterpret_cast<nyq_ent::EntInfo *>(d_ent0 + n_by + n_fd);
+    nyq_ent::EntEnergy *d_en = reinterpret_cast<nyq_ent::EntEnergy *>(d_ent0 + n_by + n_fd + n_in);
+    EnergyState *d_es = reinterpret_cast<EnergyState *>(d_ent0 + n_by + n_fd + n_in + n_en);
+    constexpr size_t kEsFloats = sizeof(EnergyState) / sizeof(float);
+    // the bytes form, for streams [s0, s0 + cnt) (all frames of the call): upload on hs, then -- behind `up` -- entropy stage and split
+    auto up_bytes = [&](size_t s0, size_t cnt, hipStream_t hs, float *h_es) -> hipError_t {
+        hipError_t e = copy_rows(d_by + s0 * nframes * kByteSlot, nframes * kByteSlot, sym + s0 * hstride * kByteSlot, hstride * kByteSlot,
+                                 nframes * kByteSlot, cnt, hipMemcpyHostToDevice, hs);
+        if (e != hipSuccess) return e;
+        e = copy_rows(d_fd + s0 * nframes, nframes * 4, fdesc + s0 * hstride, hstride * 4, nframes * 4, cnt, hipMemcpyHostToDevice, hs);
+        if (e != hipSuccess) return e;
+        if (h_es) return hipMemcpyAsync(d_es + s0, h_es + s0 * kEsFloats, cnt * sizeof(EnergyState), hipMemcpyHostToDevice, hs);
+        return hipMemsetAsync(d_es + s0, 0, cnt * sizeof(EnergyState), hs);
+    };
+    auto run_entropy = [&](size_t s0, size_t cnt) -> int {
+        int r = entropy_core(ctx, LM, ctx->d_ent_tables, d_by + s0 * nframes * kByteSlot, 0, d_fd + s0 * nframes, kByteSlot, cnt, nframes,
+                             d_sy + s0 * nframes * rec, rec, d_in + s0 * nframes, d_en + s0 * nframes, d_es + s0, 0);
+        if (r != NYQ_OK) return r;
+        hipLaunchKernelGGL(celt_entropy_split_kernel, dim3((unsigned)((cnt * nframes + 255) / 256)), dim3(256), 0, ctx->stream, d_in + s0 * nframes,
+                           (long)(cnt * nframes), d_t + s0 * nframes, d_pp + s0 * nframes, d_pg + s0 * nframes, d_pt + s0 * nframes);
+        NYQ_HIP(ctx, hipGetLastError());
+        return NYQ_OK;
+    };
     // Packed records (offsets[stream][hstride + 1], 16-byte units from the stream's base sym + stream * stream_bytes): on the device a
     // stream keeps a region of nframes slots and its records sit packed from the region's start; up_sym uploads frames
     // [f0, f0 + len) of streams [s0, s0 + cnt) -- one copy per stream -- or, for slots, one strided copy
@@ -1348,7 +1401,7 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
         return hipSuccess;
     };
     float *h_ov = state, *h_hi = state ? h_ov + nsc * NYQ_HALF_OV : nullptr, *h_de = state ? h_hi + nsc * kPostHist : nullptr,
-          *h_pf = state ? h_de + nsc : nullptr;
+          *h_pf = state ? h_de + nsc : nullptr, *h_es = state ? h_pf + nstreams * 6 : nullptr;
     // pieces of whole streams: upload of piece k+1, kernels of piece k, download of piece k-1 at the same time
     const size_t stream_bytes = nframes * (size_t)channels * N * sizeof(float);
     size_t per = (kHostPieceBytes + stream_bytes - 1) / stream_bytes;
@@ -1367,13 +1420,13 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
     // download of window w-1 at the same time; the decoder states travel from window to window in device memory.  This is the
     // shape of a batch decoder's time slices when the GPU side is what the job waits for.
     if (npieces == 1 && nframes >= 128) {
-        const size_t frame_in = sym ? rec : (size_t)channels * N * sizeof(float);
+        const size_t frame_in = bytes ? sym_bytes(channels, LM) : sym ? rec : (size_t)channels * N * sizeof(float);
         size_t W = ((kHostWindowBytes / (nstreams * frame_in)) / 64) * 64;
         if (W < 64) W = 64;
         if (ctx->opt_host_window > 0) W = (size_t)ctx->opt_host_window;  // NYQ_OPT_HOST_WINDOW
         const size_t nwin = (nframes + W - 1) / W;
         if (nwin >= 2 && nwin <= kHostMaxWindows) {
-            rc = need_copy_streams(ctx, 2 * nwin + 1);
+            rc = need_copy_streams(ctx, 2 * nwin + 2);
             if (rc != NYQ_OK) return rc;
             DrainOnExit drain{ctx};
             hipStream_t hs = ctx->s_h2d, ds = ctx->s_d2h;
@@ -1382,10 +1435,20 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
             NYQ_HIP(ctx, hipStreamWaitEvent(hs, ev0, 0));
             NYQ_HIP(ctx, hipStreamWaitEvent(ds, ev0, 0));
             // per-frame parameters, descriptors and the states: small, the whole call's at once
-            if (transient) NYQ_HIP(ctx, copy_rows(d_t, nframes, transient, hstride, nframes, nstreams, hipMemcpyHostToDevice, hs));
-            NYQ_HIP(ctx, copy_rows(d_pg, nframes * 4, pf_gain, hstride * 4, nframes * 4, nstreams, hipMemcpyHostToDevice, hs));
-            NYQ_HIP(ctx, copy_rows(d_pp, nframes * 4, pf_pitch, hstride * 4, nframes * 4, nstreams, hipMemcpyHostToDevice, hs));
-            NYQ_HIP(ctx, copy_rows(d_pt, nframes * 4, pf_tapset, hstride * 4, nframes * 4, nstreams, hipMemcpyHostToDevice, hs));
+            if (!bytes) {
+                if (transient) NYQ_HIP(ctx, copy_rows(d_t, nframes, transient, hstride, nframes, nstreams, hipMemcpyHostToDevice, hs));
+                NYQ_HIP(ctx, copy_rows(d_pg, nframes * 4, pf_gain, hstride * 4, nframes * 4, nstreams, hipMemcpyHostToDevice, hs));
+                NYQ_HIP(ctx, copy_rows(d_pp, nframes * 4, pf_pitch, hstride * 4, nframes * 4, nstreams, hipMemcpyHostToDevice, hs));
+                NYQ_HIP(ctx, copy_rows(d_pt, nframes * 4, pf_tapset, hstride * 4, nframes * 4, nstreams, hipMemcpyHostToDevice, hs));
+            } else {
+                // the bytes form: every frame's bytes (a fortieth of the records they become) go up at once and the entropy stage
+                // runs for the whole call before the first window; the windows then overlap shapes + chain with the downloads
+                NYQ_HIP(ctx, up_bytes(0, nstreams, hs, h_es));
+                hipEvent_t ev_ent = ctx->ev_pool[2 * nwin + 1];
+                NYQ_HIP(ctx, hipEventRecord(ev_ent, hs));
+                NYQ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ev_ent, 0));
+                if ((rc = run_entropy(0, nstreams)) != NYQ_OK) return rc;
+            }
             // a window's output records: the stream's with t0 moved to the window's first sample (need_scratch above sized d_ds
             // for one set; the windows' sets live behind the symbol region: see n_dw)
             std::vector<nyq_out_desc> wdesc;
@@ -1416,15 +1479,16 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
             for (size_t w = 0; w < nwin; w++) {
                 const size_t f0 = w * W, len = nframes - f0 < W ? nframes - f0 : W;
                 hipEvent_t up = ctx->ev_pool[2 * w], done = ctx->ev_pool[2 * w + 1];
-                if (sym) NYQ_HIP(ctx, up_sym(0, nstreams, f0, len, hs));
+                if (bytes) {}
+                else if (sym) NYQ_HIP(ctx, up_sym(0, nstreams, f0, len, hs));
                 else NYQ_HIP(ctx, copy_rows(d_x + f0 * channels * N, nframes * channels * N * sizeof(float), freq + f0 * channels * N,
                                             hstride * channels * N * sizeof(float), len * channels * N * sizeof(float), nstreams, hipMemcpyHostToDevice, hs));
                 NYQ_HIP(ctx, hipEventRecord(up, hs));
                 NYQ_HIP(ctx, hipStreamWaitEvent(ctx->stream, up, 0));
                 if (sym) rc = shape_core(ctx, offsets ? d_sy : d_sy + f0 * rec, d_x + f0 * channels * N, nstreams, len, channels, nframes, nframes,
-                                         offsets ? d_of + f0 : nullptr, ostr, LM);
+                                         offsets ? d_of + f0 : nullptr, ostr, LM, rec);
                 if (rc == NYQ_OK)
-                    rc = chain_core(ctx, LM, d_x + f0 * channels * N, transient ? d_t + f0 : nullptr, d_pp + f0, d_pg + f0, d_pt + f0, pf_a, pf_b, d_ov,
+                    rc = chain_core(ctx, LM, d_x + f0 * channels * N, (transient || bytes) ? d_t + f0 : nullptr, d_pp + f0, d_pg + f0, d_pt + f0, pf_a, pf_b, d_ov,
                                     d_hi, d_de, d_out + f0 * N * channels, d_pcm, d_w, nstreams, len, channels, nframes,
                                     reinterpret_cast<const OutDesc *>(desc ? d_dw + w * nstreams : nullptr));
                 if (rc != NYQ_OK) return rc;                         // (DrainOnExit waits for what is in flight)
@@ -1442,6 +1506,7 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
                 NYQ_HIP(ctx, hipMemcpyAsync(h_hi, d_hi, nsc * kPostHist * sizeof(float), hipMemcpyDeviceToHost, ds));
                 NYQ_HIP(ctx, hipMemcpyAsync(h_de, d_de, nsc * sizeof(float), hipMemcpyDeviceToHost, ds));
                 NYQ_HIP(ctx, hipMemcpyAsync(h_pf, pf_a, nstreams * 6 * sizeof(float), hipMemcpyDeviceToHost, ds));
+                if (bytes) NYQ_HIP(ctx, hipMemcpyAsync(h_es, d_es, nstreams * sizeof(EnergyState), hipMemcpyDeviceToHost, ds));
             }
             if ((rc = wait_blocking(ctx, ds)) != NYQ_OK) return rc;
             if ((rc = wait_blocking(ctx, ctx->stream)) != NYQ_OK) return rc;
@@ -1467,16 +1532,20 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
         const size_t xw = nframes * channels * N * sizeof(float), xp = hstride * channels * N * sizeof(float);
         (void)xn;
         (void)fn;
-        if (sym) {
+        if (bytes) {
+            NYQ_HIP(ctx, up_bytes(s0, cnt, hs, h_es));
+        } else if (sym) {
             if (offsets && k == 0) NYQ_HIP(ctx, hipMemcpyAsync(d_of, h_off.data(), h_off.size() * sizeof(unsigned), hipMemcpyHostToDevice, hs));
             NYQ_HIP(ctx, up_sym(s0, cnt, 0, nframes, hs));
         } else {
             NYQ_HIP(ctx, copy_rows(d_x + xo, xw, freq + hx, xp, xw, cnt, hipMemcpyHostToDevice, hs));
         }
-        if (transient) NYQ_HIP(ctx, copy_rows(d_t + fo, nframes, transient + hf, hstride, nframes, cnt, hipMemcpyHostToDevice, hs));
-        NYQ_HIP(ctx, copy_rows(d_pg + fo, nframes * 4, pf_gain + hf, hstride * 4, nframes * 4, cnt, hipMemcpyHostToDevice, hs));
-        NYQ_HIP(ctx, copy_rows(d_pp + fo, nframes * 4, pf_pitch + hf, hstride * 4, nframes * 4, cnt, hipMemcpyHostToDevice, hs));
-        NYQ_HIP(ctx, copy_rows(d_pt + fo, nframes * 4, pf_tapset + hf, hstride * 4, nframes * 4, cnt, hipMemcpyHostToDevice, hs));
+        if (!bytes) {
+            if (transient) NYQ_HIP(ctx, copy_rows(d_t + fo, nframes, transient + hf, hstride, nframes, cnt, hipMemcpyHostToDevice, hs));
+            NYQ_HIP(ctx, copy_rows(d_pg + fo, nframes * 4, pf_gain + hf, hstride * 4, nframes * 4, cnt, hipMemcpyHostToDevice, hs));
+            NYQ_HIP(ctx, copy_rows(d_pp + fo, nframes * 4, pf_pitch + hf, hstride * 4, nframes * 4, cnt, hipMemcpyHostToDevice, hs));
+            NYQ_HIP(ctx, copy_rows(d_pt + fo, nframes * 4, pf_tapset + hf, hstride * 4, nframes * 4, cnt, hipMemcpyHostToDevice, hs));
+        }
         if (desc) NYQ_HIP(ctx, hipMemcpyAsync(d_ds + s0, desc + s0, cnt * sizeof(nyq_out_desc), hipMemcpyHostToDevice, hs));
         if (state) {
             NYQ_HIP(ctx, hipMemcpyAsync(d_ov + co * NYQ_HALF_OV, h_ov + co * NYQ_HALF_OV, cn * NYQ_HALF_OV * sizeof(float), hipMemcpyHostToDevice, hs));
@@ -1486,14 +1555,20 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
         }
         NYQ_HIP(ctx, hipEventRecord(up, hs));
         NYQ_HIP(ctx, hipStreamWaitEvent(ctx->stream, up, 0));
-        if (sym && (rc = shape_core(ctx, d_sy + fo * rec, d_x + xo, cnt, nframes, channels, nframes, 0, offsets ? d_of + s0 * ostr : nullptr, ostr, LM)) != NYQ_OK) {
+        if (bytes && (rc = run_entropy(s0, cnt)) != NYQ_OK) {
+            (void)hipStreamSynchronize(hs);
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipStreamSynchronize(ds);
+            return rc;
+        }
+        if (sym && (rc = shape_core(ctx, d_sy + fo * rec, d_x + xo, cnt, nframes, channels, nframes, 0, offsets ? d_of + s0 * ostr : nullptr, ostr, LM, rec)) != NYQ_OK) {
             (void)hipStreamSynchronize(hs);
             (void)hipStreamSynchronize(ctx->stream);
             (void)hipStreamSynchronize(ds);
             return rc;
         }
         // (one launch for 20 ms stereo frames, synthesis + post-filter through d_pcm otherwise)
-        rc = chain_core(ctx, LM, d_x + xo, transient ? d_t + fo : nullptr, d_pp + fo, d_pg + fo, d_pt + fo,
+        rc = chain_core(ctx, LM, d_x + xo, (transient || bytes) ? d_t + fo : nullptr, d_pp + fo, d_pg + fo, d_pt + fo,
                         state ? d_pfi + s0 * 6 : nullptr, state ? d_pfo + s0 * 6 : nullptr,
                         state ? d_ov + co * NYQ_HALF_OV : nullptr, state ? d_hi + co * kPostHist : nullptr,
                         state ? d_de + co : nullptr, d_out + xo, d_pcm + xo, d_w + s0 * work_per_stream, cnt, nframes, channels, 0,
@@ -1512,6 +1587,7 @@ static int frames_to_pcm_core(nyq_ctx *ctx, int LM, const float *freq, const uns
             NYQ_HIP(ctx, hipMemcpyAsync(h_hi + co * kPostHist, d_hi + co * kPostHist, cn * kPostHist * sizeof(float), hipMemcpyDeviceToHost, ds));
             NYQ_HIP(ctx, hipMemcpyAsync(h_de + co, d_de + co, cn * sizeof(float), hipMemcpyDeviceToHost, ds));
             NYQ_HIP(ctx, hipMemcpyAsync(h_pf + s0 * 6, d_pfo + s0 * 6, cnt * 6 * sizeof(float), hipMemcpyDeviceToHost, ds));
+            if (bytes) NYQ_HIP(ctx, hipMemcpyAsync(h_es + s0 * kEsFloats, d_es + s0, cnt * sizeof(EnergyState), hipMemcpyDeviceToHost, ds));
         }
     }
     if ((rc = wait_blocking(ctx, ctx->s_d2h)) != NYQ_OK) return rc;
@@ -1552,6 +1628,18 @@ extern "C" int nyq_celt_symbols_packed_to_pcm_mapped(nyq_ctx *ctx, int LM, const
     return frames_to_pcm_core(ctx, LM, nullptr, transient, pf_pitch, pf_gain, pf_tapset, out, state, nstreams, nframes, channels,
                               frames_per_stream, desc, static_cast<const unsigned char *>(sym), offsets, stream_bytes);
 }
+
+extern "C" int nyq_celt_bytes_to_pcm_mapped(nyq_ctx *ctx, int LM, const unsigned char *bytes, const unsigned *frame_words, float *out,
+                                            const nyq_out_desc *desc, float *state, size_t nstreams, size_t nframes, int channels,
+                                            size_t frames_per_stream) {
+    if (ctx && frames_per_stream < nframes)
+        return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_bytes_to_pcm_mapped: frames_per_stream is smaller than nframes");
+    if (ctx && (!bytes || !frame_words)) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_bytes_to_pcm_mapped: NULL buffer");
+    if (ctx && channels != 1 && channels != 2) return fail(ctx, NYQ_ERR_INVALID, "nyq_celt_bytes_to_pcm_mapped: mono and stereo streams");
+    return frames_to_pcm_core(ctx, LM, nullptr, nullptr, nullptr, nullptr, nullptr, out, state, nstreams, nframes, channels, frames_per_stream, desc,
+                              bytes, nullptr, 0, frame_words);
+}
+extern "C" size_t nyq_celt_byte_slot(void) { return kByteSlot; }
 
 extern "C" int nyq_celt_frames_to_pcm_window(nyq_ctx *ctx, int LM, const float *freq, const unsigned char *transient,
                                              const int *pf_pitch, const float *pf_gain, const int *pf_tapset, float *out,

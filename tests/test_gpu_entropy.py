@@ -259,3 +259,52 @@ def test_random_bytes_leave_the_entropy_stage_bounded(host, ctx):
             outs.append((b["info"].cpu().numpy().copy(), b["out"].cpu().numpy().copy()))
         assert np.array_equal(outs[0][0], outs[1][0])
         assert outs[0][1].shape == outs[1][1].shape
+
+
+def byte_slots(ctx, payload, desc):
+    """the host-buffer form's input: a frame's bytes at the start of its slot, and a word per frame"""
+    slot = int(ctx.lib.nyq_celt_byte_slot())
+    nf = len(desc)
+    fb = np.zeros((nf, slot), np.uint8)
+    for i in range(nf):
+        o, n = int(desc["offset"][i]), int(desc["len"][i])
+        fb[i, :n] = payload[o:o + n]
+    words = (desc["len"].astype(np.uint32) | desc["channels"].astype(np.uint32) << 16 | desc["end"].astype(np.uint32) << 24).astype(np.uint32)
+    return fb, words
+
+
+@pytest.mark.parametrize("name", ["short.opus", "corpus/mono_20ms_64k.opus", "corpus/st_10ms_96k.opus", "corpus/st_20ms_256k_cbr.opus"])
+def test_bytes_to_pcm_host_buffer_form(host, ctx, name):
+    """nyq_celt_bytes_to_pcm_mapped (frames' bytes in host memory, everything else on the device) against the host-record path:
+    in one call, in time windows (NYQ_OPT_HOST_WINDOW), and cut in two calls with the state carried between them."""
+    import libnyquist_amd as nyq
+    raw = open(os.path.join(GOLDEN, name), "rb").read()
+    ch, nf, lm, payload, desc = frame_table(host, raw)
+    need = host.nyqh_entropy_tables(None, 0)
+    tables = np.zeros(need, np.uint8)
+    host.nyqh_entropy_tables(tables.ctypes.data, need)
+    ctx.set_entropy_tables(tables)
+    fb, words = byte_slots(ctx, payload, desc)
+    slot = ctx.lib.nyq_celt_symbol_bytes_lm(ch, lm)
+    sym = np.zeros((nf, slot), np.uint8)
+    flags, gain, rng, hinfo = np.zeros((nf, 4), np.int32), np.zeros(nf, np.float32), np.zeros(nf, np.uint32), np.zeros(8, np.int64)
+    assert host.nyqh_decode_to_symbols(raw, len(raw), nf, sym, flags, gain, rng, hinfo) == 0 and int(hinfo[2]) == nf
+    tr, pp, pt = (np.ascontiguousarray(flags[:, k]) for k in range(3))
+    want = ctx.celt_symbols_to_pcm(sym, tr.astype(np.uint8), pp.astype(np.int32), gain, pt.astype(np.int32), 1, nf, ch, lm=lm)
+    got = ctx.celt_bytes_to_pcm(lm, fb, words, 1, nf, ch)
+    assert np.abs(got - want).max() <= 2e-6
+    if nf >= 128:
+        ctx.set_option(nyq.binding.OPT_HOST_WINDOW, 64)
+        try:
+            win = ctx.celt_bytes_to_pcm(lm, fb, words, 1, nf, ch)
+        finally:
+            ctx.set_option(nyq.binding.OPT_HOST_WINDOW, 0)
+        assert np.abs(win - want).max() <= 2e-6
+    # two calls, the second one continuing the first (state: synthesis, post-filter and the entropy stage's energies / range)
+    cut = (nf // 2) // 8 * 8
+    state = np.zeros(ctx.lib.nyq_celt_state_floats(1, ch), np.float32)
+    a = ctx.celt_bytes_to_pcm(lm, fb[:cut], words[:cut], 1, cut, ch, state=state)
+    b = ctx.celt_bytes_to_pcm(lm, fb[cut:], words[cut:], 1, nf - cut, ch, state=state)
+    assert np.abs(np.concatenate([a, b], axis=1) - want).max() <= 2e-6
+    est = state[-129:].view(np.uint32)
+    assert est[126] == rng[-1] and est[128] == 0                  # final range of the last frame; no frame in error
