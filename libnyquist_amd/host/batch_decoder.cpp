@@ -66,6 +66,7 @@ struct StreamFrames {
     bool symbols = false;
     uint32_t *off0 = nullptr;           // symbols: frame i's record at in0 + 16 * off0[i] (off0[i + 1] = its end)
     bool packed = true;                 // ... back to back (a record is as long as its content), or one per slot of frameBytes
+    bool bytesMode = false;             // the GPU runs the entropy stage too: in0 holds the frames' bytes (slots of frameBytes), pp0 a word per frame
     uint8_t *tr0 = nullptr;
     int *pp0 = nullptr, *pt0 = nullptr;
     float *pg0 = nullptr;
@@ -76,6 +77,8 @@ struct StreamFrames {
     std::atomic<long> *progress = nullptr;
     long sliceLen = 0;
 };
+
+std::atomic<long> g_deviceEntropyFrames{0};   // frames (padding included) whose entropy stage ran on the GPU, process-wide (a test hook)
 
 // one input file: its demultiplexed packets, header and elementary streams (one for mapping family 0)
 struct FileJob {
@@ -157,6 +160,15 @@ void entropyDecode(FileJob &job, OnSlice &&onSlice) {
                 Segment *L = seg[k] ? &s.later[seg[k] - 1] : nullptr;
                 CeltFrame info;
                 int rc;
+                if (!L && s.bytesMode) {                             // the packet walk is all the host does: the frame's bytes and what its packet says
+                    if (fr.second > 0) std::memcpy(s.in0 + (size_t)i * s.frameBytes, fr.first, (size_t)fr.second);
+                    s.pp0[i] = (int)((unsigned)fr.second | (unsigned)(pf.stereo ? 2 : 1) << 16 | (unsigned)pf.bandwidthEnd << 24);
+                    if (s.sliceLen > 0 && (i + 1) % s.sliceLen == 0) {
+                        s.progress->store(i + 1, std::memory_order_release);
+                        onSlice(s);
+                    }
+                    continue;
+                }
                 if (!L && s.symbols) {
                     rc = decs[k].decodeSymbols(fr.first, fr.second, pf.frameSize, s.in0 + (size_t)s.off0[i] * 16, info);
                     s.off0[i + 1] = s.off0[i] + (uint32_t)((s.packed ? info.recordBytes : s.frameBytes) / 16);
@@ -186,6 +198,7 @@ struct Group {
     bool mapped = false;                // its streams write through output records into their files' device buffers
     int ch = 0, LM = 0, dev = 0;        // dev: index into the decoder's device list
     bool symbols = false;               // the entropy stage stops at the symbols: the GPU builds the band shapes (20 ms, <= 2 channels)
+    bool bytes = false;                 // the entropy stage itself runs on the GPU: `in` holds the frames' bytes, `pp` their words
     size_t N = 0, ns = 0, maxF = 0;
     size_t frameBytes = 0;              // of GPU input per frame: freq[ch][N] or a symbol record
     std::vector<size_t> ids;            // flattened stream indices, slot order
@@ -327,6 +340,7 @@ public:
 
     // 20 ms mono / stereo streams hand SYMBOL records to the GPU (their band shapes are built there); off: freq[] as for every other shape
     bool symbolRecords_ = true;
+    bool deviceEntropy_ = false;        // NYQ_DEVICE_ENTROPY: eligible streams hand the GPU their frames' bytes
     bool symbolRecords() const { return symbolRecords_; }
     bool packedRecords_ = false;        // records back to back (half the upload) or one per slot (one strided copy per window)
     size_t pieceBytes_ = kPieceBytes;
@@ -436,7 +450,9 @@ private:
         for (size_t i = 0; i < n; i++) {
             const bool mapped = !streamed_[fileOf_[i]];
             const int dev = mapped ? fileDev_[fileOf_[i]] : (int)(seenOfClass[{sf(i).channels, sf(i).plan[0].LM}]++ % (size_t)ndev_);
-            const std::tuple<int, int, int, int> key{sf(i).channels, sf(i).plan[0].LM, dev, mapped ? 1 : 0};
+            // (the device's entropy stage takes streams of ONE frame size: a later segment would start from a host decoder that never ran)
+            const bool byBytes = deviceEntropy_ && sf(i).channels <= 2 && sf(i).plan.size() == 1;
+            const std::tuple<int, int, int, int> key{sf(i).channels, sf(i).plan[0].LM, dev, (mapped ? 1 : 0) | (byBytes ? 2 : 0)};
             auto it = groupOf.find(key);
             if (it == groupOf.end()) {
                 it = groupOf.emplace(key, groups_.size()).first;
@@ -446,9 +462,11 @@ private:
                 groups_.back().N = (size_t)120 << std::get<1>(key);
                 groups_.back().dev = dev;
                 groups_.back().mapped = mapped;
-                groups_.back().symbols = symbolRecords() && groups_.back().ch <= 2;
-                groups_.back().frameBytes = groups_.back().symbols ? nyq_celt_symbol_bytes_lm(groups_.back().ch, groups_.back().LM)
-                                                                   : (size_t)groups_.back().ch * groups_.back().N * sizeof(float);
+                groups_.back().bytes = byBytes;
+                groups_.back().symbols = !byBytes && symbolRecords() && groups_.back().ch <= 2;
+                groups_.back().frameBytes = byBytes ? nyq_celt_byte_slot()
+                                            : groups_.back().symbols ? nyq_celt_symbol_bytes_lm(groups_.back().ch, groups_.back().LM)
+                                                                     : (size_t)groups_.back().ch * groups_.back().N * sizeof(float);
             }
             Group &g = groups_[it->second];
             sf(i).group = it->second;
@@ -528,6 +546,7 @@ private:
                 s.in0 = g.in + k * g.maxF * g.frameBytes;
                 s.frameBytes = g.frameBytes;
                 s.symbols = g.symbols;
+                s.bytesMode = g.bytes;
                 s.off0 = g.symbols ? g.off + k * (g.maxF + 1) : nullptr;
                 s.packed = packedRecords_;
                 if (s.off0) s.off0[0] = 0;
@@ -541,7 +560,7 @@ private:
             }
         }
         for (Piece &p : pieces_)
-            if (p.nslices > 1 || p.anyMore) p.state.assign(nyq_celt_state_floats(p.k1 - p.k0, groups_[p.group].ch), 0.f);
+            if (p.nslices > 1 || p.anyMore || groups_[p.group].bytes) p.state.assign(nyq_celt_state_floats(p.k1 - p.k0, groups_[p.group].ch), 0.f);
     }
 
     // Files whose output is the decoded stream verbatim (one mono/stereo stream, identity mapping, unit gain) are
@@ -637,6 +656,7 @@ private:
                 }
             } else {
                 std::memset(s.in0 + have * g.frameBytes, 0, (g.maxF - have) * g.frameBytes);
+                if (s.bytesMode) std::memset(s.pp0 + have, 0, (g.maxF - have) * 4);      // (empty frames: silence)
             }
             if (!job.error.empty()) {
                 std::memset(s.tr0, 0, g.maxF);
@@ -702,7 +722,22 @@ private:
                 for (size_t k = p.k0; k < p.k1 && g.mapped; k++) desc[k - p.k0] = recordOf(g.ids[k], (int64_t)(f0 * g.N));
                 const uint8_t *in = g.symbols ? g.in + p.k0 * g.maxF * g.frameBytes : g.in + so * g.frameBytes;   // (packed: the streams' bases)
                 float *out = g.mapped ? nullptr : g.out + so * g.ch * g.N, *state = p.state.empty() ? nullptr : p.state.data();
-                if (g.symbols) {
+                if (g.bytes) {
+                    g_deviceEntropyFrames.fetch_add((long)((p.k1 - p.k0) * len), std::memory_order_relaxed);
+                    rc = nyq_celt_bytes_to_pcm_mapped(ctx, g.LM, g.in + so * g.frameBytes, reinterpret_cast<const unsigned *>(g.pp + so), out,
+                                                      g.mapped ? desc.data() : nullptr, state, p.k1 - p.k0, len, g.ch, g.maxF);
+                    // what the host stage reports by throwing: a frame that read past its end (the entropy stage's state, which
+                    // travels at the end of the piece's, counts them per stream)
+                    const size_t nsP = p.k1 - p.k0, es = sizeof(nyq_ent_state) / sizeof(float);
+                    for (size_t k = 0; rc == NYQ_OK && state && k < nsP; k++) {
+                        nyq_ent_state one;
+                        std::memcpy(&one, state + p.state.size() - (nsP - k) * es, sizeof one);
+                        if (one.errors == 0) continue;
+                        std::lock_guard<std::mutex> lk(mu_);
+                        std::string &err = jobs_[fileOf_[g.ids[p.k0 + k]]].error;
+                        if (err.empty()) err = "CELT frame failed to decode";
+                    }
+                } else if (g.symbols) {
                     rc = packedRecords_ ? nyq_celt_symbols_packed_to_pcm_mapped(ctx, g.LM, in, g.off + p.k0 * (g.maxF + 1) + f0, g.maxF * g.frameBytes,
                                                                                 g.tr + so, g.pp + so, g.pg + so, g.pt + so, out,
                                                                                 g.mapped ? desc.data() : nullptr, state, p.k1 - p.k0, len, g.ch, g.maxF)
@@ -1015,6 +1050,7 @@ BatchOpusDecoder::BatchOpusDecoder(const std::vector<int> &devices) : devices_(d
         if (v > 0) stagingBudget_ = (size_t)v;
     }
     if (const char *e = std::getenv("NYQ_HOST_SYMBOLS")) symbolRecords_ = std::atoi(e) != 0;   // (A/B switch, read once like the budget)
+    if (const char *e = std::getenv("NYQ_DEVICE_ENTROPY")) deviceEntropy_ = std::atoi(e) != 0; // (opt-in this round: DESIGN 4.11)
     if (const char *e = std::getenv("NYQ_BATCH_TRACE")) trace_ = std::atoi(e) != 0;
     long hostWindow = -1;                                   // (measurement switch: NYQ_OPT_HOST_WINDOW of every context)
     if (const char *e = std::getenv("NYQ_HOST_WINDOW")) hostWindow = std::atol(e);
@@ -1037,6 +1073,16 @@ BatchOpusDecoder::BatchOpusDecoder(const std::vector<int> &devices) : devices_(d
             }
             if (hostWindow >= 0) (void)nyq_ctx_set_option(c, NYQ_OPT_HOST_WINDOW, hostWindow);
             ctx_.push_back(c);
+            if (deviceEntropy_) {                               // the entropy stage's tables, from this library's own mode
+                std::vector<uint8_t> tables(entropyTablesBytes());
+                fillEntropyTables(tables.data());
+                if (nyq_ctx_set_entropy_tables(c, tables.data(), tables.size()) != NYQ_OK) {
+                    const std::string why = nyq_last_error(c);
+                    for (void *p : ctx_) nyq_ctx_destroy((nyq_ctx *)p);
+                    ctx_.clear();
+                    throw std::runtime_error("libnyq_imdct: " + why);
+                }
+            }
         }
 }
 
@@ -1141,7 +1187,8 @@ void BatchOpusDecoder::decodeImpl(const std::vector<const std::vector<uint8_t> *
             size_t bytes = 0;
             for (const auto &kv : shape) {
                 const size_t pcm = (size_t)kv.first.first * ((size_t)120 << kv.first.second) * sizeof(float);
-                const size_t in = symbolRecords_ && kv.first.first <= 2 ? nyq_celt_symbol_bytes_lm(kv.first.first, kv.first.second) : pcm;
+                const size_t in = deviceEntropy_ && kv.first.first <= 2 ? nyq_celt_byte_slot()
+                                  : symbolRecords_ && kv.first.first <= 2 ? nyq_celt_symbol_bytes_lm(kv.first.first, kv.first.second) : pcm;
                 bytes += kv.second.first * kv.second.second * (in + pcm);
             }
             return bytes;
@@ -1185,6 +1232,7 @@ void BatchOpusDecoder::decodeImpl(const std::vector<const std::vector<uint8_t> *
                 }
         SubBatch sb(jobs, out, members, ctx_.data(), (int)devices_.size(), kFeeders, threads, arenaFn, devArenaFn);
         sb.symbolRecords_ = symbolRecords_;
+        sb.deviceEntropy_ = deviceEntropy_;
         sb.packedRecords_ = packedRecords_;
         sb.pieceBytes_ = pieceBytes_;
         sb.longPieceStreams_ = longPieceStreams_;
@@ -1222,5 +1270,7 @@ void BatchOpusDecoder::decodeImpl(const std::vector<const std::vector<uint8_t> *
         stats->threads = threads;
     }
 }
+
+long deviceEntropyFrames() { return g_deviceEntropyFrames.load(); }
 
 }  // namespace nyq_host

@@ -89,6 +89,7 @@ private:
     std::vector<int> devices_;
     size_t stagingBudget_ = (size_t)12 << 30;
     bool symbolRecords_ = true;
+    bool deviceEntropy_ = false;              // NYQ_DEVICE_ENTROPY=1: the entropy stage of one-frame-size mono / stereo streams runs on the GPU
     size_t longPieceStreams_ = 0;             // NYQ_LONG_PIECE_STREAMS: streams per piece of time-sliced streams (0: as many as threads)
     size_t pieceBytes_ = (size_t)24 << 20;    // of GPU input per piece of short streams (NYQ_PIECE_BYTES at construction)
     bool packedRecords_ = false;              // NYQ_HOST_PACKED=1 at construction: symbol records packed back to back
@@ -98,5 +99,8 @@ private:
     std::vector<Arena> devArenas_;            // per device: device memory (Arena::pinned unused)
     std::vector<std::vector<float>> pool_;    // sample buffers of the sink form, capacity kept
 };
+
+// frames whose entropy stage ran on the GPU so far in this process (NYQ_DEVICE_ENTROPY=1; a test hook)
+long deviceEntropyFrames();
 
 }  // namespace nyq_host

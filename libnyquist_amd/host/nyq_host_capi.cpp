@@ -162,6 +162,7 @@ done:
 // every frame's bytes back to back in `payload` and a nyq_ent_desc per frame (one-stream files; the walk ends at the first frame
 // of another size, as above).  info = {channels, pre-skip, frames, frame size, payload bytes}.  Returns 0, -10 (not Ogg Opus),
 // -11 (not a one-stream CELT-only file), -12 (payload_cap too small).
+long nyqh_device_entropy_frames(void) { return deviceEntropyFrames(); }
 long nyqh_entropy_tables(void *out, long cap) {
     const long need = (long)entropyTablesBytes();
     if (!out) return need;

@@ -169,6 +169,14 @@ int nyq_celt_symbols_to_pcm_mapped(nyq_ctx *ctx, int LM, const void *sym, const 
                                                  nframes, channels, frames_per_stream);
 }
 
+// (the device's own entropy stage: the stand-in has none -- the scheduler tests run with NYQ_DEVICE_ENTROPY unset)
+int nyq_ctx_set_entropy_tables(nyq_ctx *, const void *, size_t) { return NYQ_ERR_INVALID; }
+size_t nyq_celt_byte_slot(void) { return 1280; }
+int nyq_celt_bytes_to_pcm_mapped(nyq_ctx *, int, const unsigned char *, const unsigned int *, float *, const nyq_out_desc *, float *, size_t, size_t, int,
+                                 size_t) {
+    return NYQ_ERR_INVALID;
+}
+
 int nyq_celt_frames_to_pcm_window(nyq_ctx *ctx, int LM, const float *freq, const unsigned char *transient, const int *pf_pitch,
                                   const float *pf_gain, const int *pf_tapset, float *out, float *state, size_t nstreams,
                                   size_t nframes, int channels, size_t frames_per_stream) {

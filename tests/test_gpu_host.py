@@ -417,3 +417,48 @@ def test_staging_forms_decode_to_the_same_samples(host, env):
         assert np.array_equal(other, first)
     else:
         assert np.abs(other - first).max() <= 2e-6
+
+
+def test_device_entropy_mode_of_the_batch_decoder_decodes_to_the_same_samples(host):
+    """NYQ_DEVICE_ENTROPY=1 (read at a decoder's construction: a process of its own): streams of one frame size hand the GPU their
+    frames' BYTES -- the host only walks the packets -- and the files come out as through the host entropy stage: long streams in
+    time slices (sb-reverie), mono / stereo / 10 ms / 256 kbit/s corpus files, the 7.1 file's five elementary streams; short.opus
+    (a closing 2.5 ms frame: two frame sizes) stays on the host path, bit for bit."""
+    import subprocess
+    import sys
+    names = ["sb-reverie.opus", "short.opus", "corpus/st_20ms_32k.opus", "corpus/mono_20ms_64k.opus", "corpus/st_10ms_96k.opus",
+             "corpus/st_20ms_256k_cbr.opus", "corpus/surround71_20ms_320k.opus", "corpus/mono_2p5ms_48k.opus"]
+    code = ("import sys, ctypes as C, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from test_host_decoder import load_host\n"
+            "H = load_host()\n"
+            "H.nyqh_nyquistio_load_buffer.argtypes = [C.c_char_p, C.c_long, C.c_void_p, C.c_long, np.ctypeslib.ndpointer(np.int64)]\n"
+            "H.nyqh_nyquistio_load_buffer.restype = C.c_long\n"
+            "H.nyqh_device_entropy_frames.restype = C.c_long\n"
+            "outs = []\n"
+            "for p in sys.argv[2:]:\n"
+            "    raw = open(p, 'rb').read(); info = np.zeros(4, np.int64)\n"
+            "    n = H.nyqh_nyquistio_load_buffer(raw, len(raw), None, 0, info)\n"
+            "    assert n > 0, (p, n)\n"
+            "    a = np.zeros(n, np.float32)\n"
+            "    assert H.nyqh_nyquistio_load_buffer(raw, len(raw), a.ctypes.data_as(C.c_void_p), n, info) == n\n"
+            "    outs.append(a)\n"
+            "np.concatenate(outs).tofile(sys.argv[1]); print('frames', H.nyqh_device_entropy_frames(), [len(o) for o in outs])\n") % (ROOT, os.path.join(ROOT, "tests"))
+    paths = [os.path.join(GOLDEN, n) for n in names]
+    res = {}
+    for tag, env in (("host", {}), ("device", {"NYQ_DEVICE_ENTROPY": "1"})):
+        out = os.path.join("/tmp", "nyq_device_entropy_%s.bin" % tag)
+        r = subprocess.run([sys.executable, "-c", code, out] + paths, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("frames")][-1]
+        res[tag] = (np.fromfile(out, np.float32), int(line.split()[1]), eval(line.split(" ", 2)[2]))
+        os.unlink(out)
+    assert res["host"][1] == 0 and res["device"][1] >= 2 * 11184                # (two loads per file; padding frames count too)
+    assert res["host"][2] == res["device"][2]
+    a, b = res["host"][0], res["device"][0]
+    lens = res["host"][2]
+    at = 0
+    for n, name in zip(lens, names):
+        d = np.abs(a[at:at + n] - b[at:at + n]).max()
+        print(name, n, d)
+        assert d <= (0.0 if name == "short.opus" else 2e-6), name
+        at += n
