@@ -227,6 +227,27 @@ def device_entropy_leg(ctx, dev, streams=32):
                     "which the host entropy stage bounds"}
 
 
+def device_entropy_files_leg(streams=128, threads=None):
+    """File-level decode of `streams` x sb-reverie.opus through the batch decoder with the entropy stage on the host (today's
+    default) and on the device (NYQ_DEVICE_ENTROPY=1, read when a decoder is constructed: each form in a process of its own,
+    tools/e2e_bench.py), back to back."""
+    import subprocess
+    out = {}
+    for tag, v in (("host_entropy_stage", "0"), ("device_entropy_stage", "1")):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_bench.py"), str(streams), str(threads or cpu_share()), "sb-reverie.opus"],
+                           env=dict(os.environ, NYQ_DEVICE_ENTROPY=v), capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            raise RuntimeError(r.stderr[-500:])
+        j = json.loads(r.stdout.strip().splitlines()[-1])
+        out[tag] = {"wall_s": j["wall_s_of_the_call"], "frames_per_sec": j["frames_per_s"], "host_stage_s": j["breakdown"]["cpu_entropy_s"],
+                    "after_host_stage_s": j["breakdown"]["after_cpu_s"]}
+    out["streams"] = streams
+    out["speedup"] = out["host_entropy_stage"]["wall_s"] / out["device_entropy_stage"]["wall_s"]
+    out["pcm_GBps_out_device_form"] = streams * 21472602 * 4 / out["device_entropy_stage"]["wall_s"] / 1e9
+    out["note"] = "with the entropy stage on the device the job waits for the PCM's way out (PCIe down + hand-over), not for the host"
+    return out
+
+
 def opus_file_decode_leg(count=256, fname="short.opus", n=421930, threads=None, device=0, channels=2):
     """File-level decode of `count` copies of tests/golden/<fname> (short.opus: 220 stereo 20 ms CELT frames + one
     closing 2.5 ms frame, 123 kbit/s; sb-reverie.opus: 11184 frames = 224 s, BASELINE config 4's file) as ONE
@@ -653,6 +674,10 @@ def main():
                     file_leg["entropy_stage_on_device"] = device_entropy_leg(ctx, dev)
                 except Exception as e:  # noqa: BLE001
                     file_leg["entropy_stage_on_device"] = {"error": str(e)}
+                try:
+                    file_leg["long_streams_128_host_vs_device_entropy"] = device_entropy_files_leg(128, thr)
+                except Exception as e:  # noqa: BLE001
+                    file_leg["long_streams_128_host_vs_device_entropy"] = {"error": str(e)}
                 file_leg["surround_7_1"] = opus_file_decode_leg(128, os.path.join("corpus", "surround71_20ms_320k.opus"), 384000, threads=thr,
                                                                 device=local_rank, channels=8)
         except Exception as e:
