@@ -602,12 +602,13 @@ def test_frames_to_pcm_pipelined_pieces_equal_single_calls(ctx, oracle):
     out = ctx.celt_frames_to_pcm(3, freq, tr, pp, pg, pt, ch, state=state)
     assert np.isfinite(out).all() and np.abs(out).max() > 0
     nsc = ns * ch
-    ov, hi, de, pf = np.split(state, [nsc * 60, nsc * 60 + nsc * 1088, nsc * 60 + nsc * 1088 + nsc])
+    # (layout of nyq_celt_state_floats: overlap | history | de-emphasis | post-filter parameters | the entropy stage's state, unused here)
+    ov, hi, de, pf, _ = np.split(state, [nsc * 60, nsc * 60 + nsc * 1088, nsc * 60 + nsc * 1088 + nsc, nsc * 60 + nsc * 1088 + nsc + ns * 6])
     for k in (0, 1, 218, 219, 220, 437, 438, ns - 1):
         st1 = np.zeros(int(ctx.lib.nyq_celt_state_floats(1, ch)), np.float32)
         o1 = ctx.celt_frames_to_pcm(3, freq[k:k + 1], tr[k:k + 1], pp[k:k + 1], pg[k:k + 1], pt[k:k + 1], ch, state=st1)
         assert np.array_equal(o1[0], out[k])
-        o_ov, o_hi, o_de, o_pf = np.split(st1, [ch * 60, ch * 60 + ch * 1088, ch * 60 + ch * 1088 + ch])
+        o_ov, o_hi, o_de, o_pf, _ = np.split(st1, [ch * 60, ch * 60 + ch * 1088, ch * 60 + ch * 1088 + ch, ch * 60 + ch * 1088 + ch + 6])
         assert np.array_equal(o_ov, ov[k * ch * 60:(k + 1) * ch * 60])
         assert np.array_equal(o_hi, hi[k * ch * 1088:(k + 1) * ch * 1088])
         assert np.array_equal(o_de, de[k * ch:(k + 1) * ch])
