@@ -160,8 +160,8 @@ def band_shapes_leg(ctx, dev, rep=8):
 def device_entropy_leg(ctx, dev, streams=32):
     """The entropy stage ON THE DEVICE (nyq_celt_entropy_dev: a frame per lane, then the energy pass, a wave per stream) on
     `streams` copies of sb-reverie.opus' 11184 frames as independent streams, bytes resident in HBM: frames/s of the stage, and of
-    bytes -> PCM through it (entropy + band shapes + synthesis + post-filter, device-resident).  An operator-level capability this
-    round: the batch decoder (opus_file_decode) still runs the entropy stage on the host."""
+    bytes -> PCM through it (entropy + band shapes + synthesis + post-filter, device-resident).  The batch decoder uses it under
+    NYQ_DEVICE_ENTROPY=1 (leg long_streams_128_host_vs_device_entropy); by default it runs the entropy stage on the host."""
     import torch
     H = ctypes.CDLL(os.path.join(ROOT, "libnyquist_amd", "libnyquist_host.so"))
     u8 = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
