@@ -50,6 +50,8 @@ struct Segment {
     std::vector<uint8_t> transient;
     std::vector<int> pfPitch, pfTapset;
     std::vector<float> pfGain;
+    std::vector<uint8_t> bytes;         // (device entropy stage: the frames' bytes in slots of nyq_celt_byte_slot, and a word per frame)
+    std::vector<uint32_t> words;
 };
 
 // one elementary (mono or coupled) Opus stream
@@ -136,6 +138,11 @@ void entropyDecode(FileJob &job, OnSlice &&onSlice) {
             Segment &L = s.later[g - 1];
             L.LM = s.plan[g].LM;
             L.nframes = s.plan[g].nframes;
+            if (s.bytesMode) {
+                L.bytes.assign((size_t)L.nframes * nyq_celt_byte_slot(), 0);
+                L.words.assign((size_t)L.nframes, 0);
+                continue;
+            }
             L.freq.resize((size_t)L.nframes * s.channels * ((size_t)120 << L.LM));
             L.transient.resize(L.nframes);
             L.pfPitch.resize(L.nframes);
@@ -160,9 +167,15 @@ void entropyDecode(FileJob &job, OnSlice &&onSlice) {
                 Segment *L = seg[k] ? &s.later[seg[k] - 1] : nullptr;
                 CeltFrame info;
                 int rc;
-                if (!L && s.bytesMode) {                             // the packet walk is all the host does: the frame's bytes and what its packet says
+                if (s.bytesMode) {                                   // the packet walk is all the host does: the frame's bytes and what its packet says
+                    const unsigned word = (unsigned)fr.second | (unsigned)(pf.stereo ? 2 : 1) << 16 | (unsigned)pf.bandwidthEnd << 24;
+                    if (L) {
+                        if (fr.second > 0) std::memcpy(L->bytes.data() + (size_t)i * nyq_celt_byte_slot(), fr.first, (size_t)fr.second);
+                        L->words[(size_t)i] = word;
+                        continue;
+                    }
                     if (fr.second > 0) std::memcpy(s.in0 + (size_t)i * s.frameBytes, fr.first, (size_t)fr.second);
-                    s.pp0[i] = (int)((unsigned)fr.second | (unsigned)(pf.stereo ? 2 : 1) << 16 | (unsigned)pf.bandwidthEnd << 24);
+                    s.pp0[i] = (int)word;
                     if (s.sliceLen > 0 && (i + 1) % s.sliceLen == 0) {
                         s.progress->store(i + 1, std::memory_order_release);
                         onSlice(s);
@@ -315,7 +328,9 @@ void stateOfStream(const float *batch, size_t ns, int ch, size_t k, float *one) 
     std::memcpy(one, ov + k * ch * 60, sizeof(float) * ch * 60); one += ch * 60;
     std::memcpy(one, hi + k * ch * 1088, sizeof(float) * ch * 1088); one += ch * 1088;
     std::memcpy(one, de + k * ch, sizeof(float) * ch); one += ch;
-    std::memcpy(one, pf + k * 6, sizeof(float) * 6);
+    std::memcpy(one, pf + k * 6, sizeof(float) * 6); one += 6;
+    const size_t es = nyq_celt_state_floats(1, ch) - ((size_t)ch * (60 + 1088 + 1) + 6);   // (the entropy stage's state, where the library has one)
+    std::memcpy(one, pf + ns * 6 + k * es, sizeof(float) * es);
 }
 void stateIntoBatch(float *batch, size_t ns, int ch, size_t k, const float *one) {
     const size_t nsc = ns * ch;
@@ -323,7 +338,9 @@ void stateIntoBatch(float *batch, size_t ns, int ch, size_t k, const float *one)
     std::memcpy(ov + k * ch * 60, one, sizeof(float) * ch * 60); one += ch * 60;
     std::memcpy(hi + k * ch * 1088, one, sizeof(float) * ch * 1088); one += ch * 1088;
     std::memcpy(de + k * ch, one, sizeof(float) * ch); one += ch;
-    std::memcpy(pf + k * 6, one, sizeof(float) * 6);
+    std::memcpy(pf + k * 6, one, sizeof(float) * 6); one += 6;
+    const size_t es = nyq_celt_state_floats(1, ch) - ((size_t)ch * (60 + 1088 + 1) + 6);
+    std::memcpy(pf + ns * 6 + k * es, one, sizeof(float) * es);
 }
 
 // One memory-bounded sub-batch of files on its way through passes 1-3 (see batch_decoder.hpp).
@@ -450,8 +467,7 @@ private:
         for (size_t i = 0; i < n; i++) {
             const bool mapped = !streamed_[fileOf_[i]];
             const int dev = mapped ? fileDev_[fileOf_[i]] : (int)(seenOfClass[{sf(i).channels, sf(i).plan[0].LM}]++ % (size_t)ndev_);
-            // (the device's entropy stage takes streams of ONE frame size: a later segment would start from a host decoder that never ran)
-            const bool byBytes = deviceEntropy_ && sf(i).channels <= 2 && sf(i).plan.size() == 1;
+            const bool byBytes = deviceEntropy_ && sf(i).channels <= 2;
             const std::tuple<int, int, int, int> key{sf(i).channels, sf(i).plan[0].LM, dev, (mapped ? 1 : 0) | (byBytes ? 2 : 0)};
             auto it = groupOf.find(key);
             if (it == groupOf.end()) {
@@ -871,7 +887,9 @@ private:
             if ((size_t)s.plan[0].nframes != g.maxF) {
                 std::vector<float> out1((size_t)s.plan[0].nframes * g.N * g.ch);
                 const size_t nf0 = (size_t)s.plan[0].nframes;
-                if ((g.symbols ? nyq_celt_symbols_packed_to_pcm_mapped(ctx, g.LM, s.in0, s.off0, 0, s.tr0, s.pp0, s.pg0, s.pt0, out1.data(), nullptr,
+                if ((g.bytes   ? nyq_celt_bytes_to_pcm_mapped(ctx, g.LM, s.in0, reinterpret_cast<const unsigned *>(s.pp0), out1.data(), nullptr, st1.data(), 1,
+                                                              nf0, g.ch, g.maxF)
+                     : g.symbols ? nyq_celt_symbols_packed_to_pcm_mapped(ctx, g.LM, s.in0, s.off0, 0, s.tr0, s.pp0, s.pg0, s.pt0, out1.data(), nullptr,
                                                                        st1.data(), 1, nf0, g.ch, g.maxF)
                                : nyq_celt_frames_to_pcm(ctx, g.LM, reinterpret_cast<const float *>(s.in0), s.tr0, s.pp0, s.pg0, s.pt0, out1.data(),
                                                         st1.data(), 1, nf0, g.ch)) != NYQ_OK)
@@ -915,27 +933,34 @@ private:
             for (size_t i = 0; i < n; i++)
                 if (sf(i).later.size() >= r && !stateOf_[i].empty())   // (no state: the file failed in pass 1)
                     shapes[std::make_tuple(groups_[sf(i).group].dev, sf(i).channels, sf(i).later[r - 1].LM, sf(i).later[r - 1].nframes,
-                                           groups_[sf(i).group].mapped ? 1 : 0)]
+                                           (groups_[sf(i).group].mapped ? 1 : 0) | (sf(i).bytesMode ? 2 : 0))]
                         .push_back(i);
             if (shapes.empty()) break;
             for (const auto &kv : shapes) {
                 nyq_ctx *ctx = (nyq_ctx *)ctxs_[(size_t)std::get<0>(kv.first) * (size_t)feedersPerDev_];
                 const int ch = std::get<1>(kv.first), LM = std::get<2>(kv.first);
                 const size_t nf = (size_t)std::get<3>(kv.first), N = (size_t)120 << LM;
-                const bool mapped = std::get<4>(kv.first) != 0;
+                const bool mapped = (std::get<4>(kv.first) & 1) != 0, byBytes = (std::get<4>(kv.first) & 2) != 0;
                 const std::vector<size_t> &ids = kv.second;
-                const size_t ns = ids.size(), per = nf * ch * N;
-                std::vector<float> freq(ns * per), pcm(mapped ? 0 : ns * per), pg(ns * nf), state(nyq_celt_state_floats(ns, ch));
+                const size_t ns = ids.size(), per = nf * ch * N, bslot = nyq_celt_byte_slot();
+                std::vector<float> freq(byBytes ? 0 : ns * per), pcm(mapped ? 0 : ns * per), pg(ns * nf), state(nyq_celt_state_floats(ns, ch));
+                std::vector<uint8_t> fbytes(byBytes ? ns * nf * bslot : 0);
+                std::vector<uint32_t> fwords(byBytes ? ns * nf : 0);
                 std::vector<nyq_out_desc> desc(mapped ? ns : 0);
                 std::vector<int> pp(ns * nf), pt(ns * nf);
                 std::vector<uint8_t> tr(ns * nf);
                 for (size_t k = 0; k < ns; k++) {
                     const Segment &sg = sf(ids[k]).later[r - 1];
-                    std::memcpy(&freq[k * per], sg.freq.data(), per * sizeof(float));
-                    std::memcpy(&tr[k * nf], sg.transient.data(), nf);
-                    std::memcpy(&pp[k * nf], sg.pfPitch.data(), nf * sizeof(int));
-                    std::memcpy(&pt[k * nf], sg.pfTapset.data(), nf * sizeof(int));
-                    std::memcpy(&pg[k * nf], sg.pfGain.data(), nf * sizeof(float));
+                    if (byBytes) {
+                        std::memcpy(&fbytes[k * nf * bslot], sg.bytes.data(), nf * bslot);
+                        std::memcpy(&fwords[k * nf], sg.words.data(), nf * sizeof(uint32_t));
+                    } else {
+                        std::memcpy(&freq[k * per], sg.freq.data(), per * sizeof(float));
+                        std::memcpy(&tr[k * nf], sg.transient.data(), nf);
+                        std::memcpy(&pp[k * nf], sg.pfPitch.data(), nf * sizeof(int));
+                        std::memcpy(&pt[k * nf], sg.pfTapset.data(), nf * sizeof(int));
+                        std::memcpy(&pg[k * nf], sg.pfGain.data(), nf * sizeof(float));
+                    }
                     stateIntoBatch(state.data(), ns, ch, k, stateOf_[ids[k]].data());
                     if (mapped) {                                   // samples decoded before this segment: where it starts in the stream
                         const StreamFrames &st = sf(ids[k]);
@@ -944,11 +969,18 @@ private:
                         desc[k] = recordOf(ids[k], t0);
                     }
                 }
-                const int rc = mapped ? nyq_celt_frames_to_pcm_mapped(ctx, LM, freq.data(), tr.data(), pp.data(), pg.data(), pt.data(), nullptr,
+                const int rc = byBytes ? nyq_celt_bytes_to_pcm_mapped(ctx, LM, fbytes.data(), fwords.data(), mapped ? nullptr : pcm.data(),
+                                                                      mapped ? desc.data() : nullptr, state.data(), ns, nf, ch, nf)
+                               : mapped ? nyq_celt_frames_to_pcm_mapped(ctx, LM, freq.data(), tr.data(), pp.data(), pg.data(), pt.data(), nullptr,
                                                                      desc.data(), state.data(), ns, nf, ch, nf)
                                       : nyq_celt_frames_to_pcm(ctx, LM, freq.data(), tr.data(), pp.data(), pg.data(), pt.data(), pcm.data(),
                                                                state.data(), ns, nf, ch);
                 if (rc != NYQ_OK) throw std::runtime_error(std::string("libnyq_imdct: ") + nyq_last_error(ctx));
+                for (size_t k = 0; k < ns && byBytes; k++) {                 // frames in error fail their file (as the host stage's exception does)
+                    nyq_ent_state one;
+                    std::memcpy(&one, state.data() + state.size() - (ns - k) * (sizeof one / sizeof(float)), sizeof one);
+                    if (one.errors && jobs_[fileOf_[ids[k]]].error.empty()) jobs_[fileOf_[ids[k]]].error = "CELT frame failed to decode";
+                }
                 for (size_t k = 0; k < ns; k++) {
                     const size_t i = ids[k];
                     if (!mapped) laterPcm_[i].insert(laterPcm_[i].end(), &pcm[k * per], &pcm[k * per] + per);

@@ -422,12 +422,14 @@ def test_staging_forms_decode_to_the_same_samples(host, env):
 def test_device_entropy_mode_of_the_batch_decoder_decodes_to_the_same_samples(host):
     """NYQ_DEVICE_ENTROPY=1 (read at a decoder's construction: a process of its own): streams of one frame size hand the GPU their
     frames' BYTES -- the host only walks the packets -- and the files come out as through the host entropy stage: long streams in
-    time slices (sb-reverie), mono / stereo / 10 ms / 256 kbit/s corpus files, the 7.1 file's five elementary streams; short.opus
-    (a closing 2.5 ms frame: two frame sizes) stays on the host path, bit for bit."""
+    time slices (sb-reverie), mono / stereo / 10 ms / 256 kbit/s corpus files, the 7.1 file's five elementary streams, and streams
+    that change frame size (short.opus' closing 2.5 ms frame, 20 ms then 10 ms): every segment's entropy stage on the device, the
+    stage's state carried from segment to segment."""
     import subprocess
     import sys
     names = ["sb-reverie.opus", "short.opus", "corpus/st_20ms_32k.opus", "corpus/mono_20ms_64k.opus", "corpus/st_10ms_96k.opus",
-             "corpus/st_20ms_256k_cbr.opus", "corpus/surround71_20ms_320k.opus", "corpus/mono_2p5ms_48k.opus"]
+             "corpus/st_20ms_256k_cbr.opus", "corpus/surround71_20ms_320k.opus", "corpus/mono_2p5ms_48k.opus",
+             "corpus/twosize_st_20ms_then_10ms_10s.opus", "corpus/surround51_10ms_192k.opus", "corpus/monohead_st_20ms_32k.opus"]
     code = ("import sys, ctypes as C, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
             "from test_host_decoder import load_host\n"
             "H = load_host()\n"
@@ -445,7 +447,7 @@ def test_device_entropy_mode_of_the_batch_decoder_decodes_to_the_same_samples(ho
             "np.concatenate(outs).tofile(sys.argv[1]); print('frames', H.nyqh_device_entropy_frames(), [len(o) for o in outs])\n") % (ROOT, os.path.join(ROOT, "tests"))
     paths = [os.path.join(GOLDEN, n) for n in names]
     res = {}
-    for tag, env in (("host", {}), ("device", {"NYQ_DEVICE_ENTROPY": "1"})):
+    for tag, env in (("host", {"NYQ_DEVICE_ENTROPY": "0"}), ("device", {"NYQ_DEVICE_ENTROPY": "1"})):
         out = os.path.join("/tmp", "nyq_device_entropy_%s.bin" % tag)
         r = subprocess.run([sys.executable, "-c", code, out] + paths, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
@@ -460,5 +462,5 @@ def test_device_entropy_mode_of_the_batch_decoder_decodes_to_the_same_samples(ho
     for n, name in zip(lens, names):
         d = np.abs(a[at:at + n] - b[at:at + n]).max()
         print(name, n, d)
-        assert d <= (0.0 if name == "short.opus" else 2e-6), name
+        assert d <= 2e-6, name
         at += n
