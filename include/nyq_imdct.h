@@ -389,8 +389,9 @@ int nyq_celt_synth(nyq_ctx *ctx, int LM, const float *freq, const unsigned char 
  * Host buffers; layouts as in the two _dev functions; out [nstreams][nframes*N][channels].
  * `state` (host, in/out, nyq_celt_state_floats() floats) carries the decoders from one call to the
  * next, e.g. across a change of frame size: [nsc][60] overlap carry, [nsc][1088] filtered history,
- * [nsc] de-emphasis memory, [nstreams][6] post-filter state (nsc = nstreams*channels).  NULL means
- * freshly reset decoders and discards the final state. */
+ * [nsc] de-emphasis memory, [nstreams][6] post-filter state (nsc = nstreams*channels), then [nstreams] nyq_ent_state (the
+ * entropy stage's energies, range and error count: read and written by nyq_celt_bytes_to_pcm_mapped only; the other entry
+ * points leave it alone).  NULL means freshly reset decoders and discards the final state. */
 size_t nyq_celt_state_floats(size_t nstreams, int channels);
 int nyq_celt_frames_to_pcm(nyq_ctx *ctx, int LM, const float *freq, const unsigned char *transient,
                            const int *pf_pitch, const float *pf_gain, const int *pf_tapset,
